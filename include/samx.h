@@ -1,0 +1,211 @@
+/* samx.h — C ABI of libsamx: the MI355X (gfx950) implementation of SAM's replayed-minibatch
+ * update step (lionelblonde/sam-tf).
+ *
+ * The reference has no FFI: its boundary for this path is the Python object protocol that
+ * imitation/imitation_algorithms/sam.py uses.  libsamx is what the Python mirror
+ * of that protocol (sam_tf_amd/{agent,discriminator,memory}.py) binds through ctypes; each entry
+ * point below cites the reference code it replaces (paths relative to /root/reference/imitation).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every pointer is DEVICE memory unless its name ends in
+ *    `_host`.  `stream` is a hipStream_t passed as void*; calls only enqueue work on it.
+ *  - Return 0 on success, <0 on error (SAMX_ERR_*); samx_last_error() returns the message of the
+ *    calling thread's last failure.  Nothing throws across the ABI.
+ *  - Matrices are row-major float32.  Flat parameter / gradient vectors use the reference's variable
+ *    creation order (networks.py:50-70,359-404 ; tf_util.py:137-151):
+ *       W1[in,h1] b1[h1] (beta1[h1] gamma1[h1]) W2[h1,h2] b2[h2] (beta2 gamma2) W3[h2,out] b3[out]
+ *  - Calls that need scratch take `ws`/`ws_bytes`; ask samx_*_ws_bytes() for the size.  The library
+ *    itself allocates nothing on these paths.
+ */
+#ifndef SAMX_H
+#define SAMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMX_OK 0
+#define SAMX_ERR_ARG (-1)
+#define SAMX_ERR_HIP (-2)
+#define SAMX_ERR_WORKSPACE (-3)
+#define SAMX_ERR_UNSUPPORTED (-4)
+
+const char* samx_last_error(void);
+int samx_version(void);
+
+/* ---- network description ------------------------------------------------------------------ */
+/* Two hidden layers, leaky-ReLU(0.2), optional post-activation LayerNorm (eps 1e-8):
+ * helpers/networks.py:45-72 (stack_fc_layers), helpers/network_util.py:5-72.
+ * actor: in=ob, out=ac (networks.py:262-323); critic / reward net: in=ob+ac (action concatenated at
+ * the first layer, ac_branch_in=1), out=1 (networks.py:222-259,337-404). */
+typedef struct samx_mlp {
+    int32_t in_dim, h1, h2, out_dim, layernorm;
+} samx_mlp;
+
+int64_t samx_mlp_param_count(const samx_mlp* d);
+
+/* ---- segment trees / prioritized replay (bit-exact, float64) ------------------------------- */
+/* Trees are device arrays of 2*cap doubles, root at [1], leaves at [cap..2cap) — the layout of
+ * helpers/segment_tree.py:22-23.  `stamp` is an int32[cap] scratch that must hold -1 everywhere
+ * between calls (samx_tree_init sets it). */
+
+/* SegmentTree.__init__ (segment_tree.py:6-24): neutral elements 0.0 / +inf. */
+int samx_tree_init(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap, void* stream);
+
+/* A batch of SegmentTree.__setitem__ (segment_tree.py:55-64) applied to BOTH trees in index order:
+ * duplicates resolve as in the reference's sequential loop (last writer wins,
+ * imitation_algorithms/memory.py:370-379).  idxs int64[n], leaf float64[n]. */
+int samx_tree_set(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                  const int64_t* idxs, const double* leaf, int64_t n, void* stream);
+
+/* SegmentTree.reduce (segment_tree.py:26-53) in the reference's recursive association order.
+ * kind 0 = sum, 1 = min.  `end` exclusive; end < 0 wraps by +cap; pass cap for None. out: double[1]. */
+int samx_tree_reduce(const double* tree, int64_t cap, int kind, int64_t start, int64_t end,
+                     double* out, void* stream);
+
+/* SumSegmentTree.find_prefixsum_idx (segment_tree.py:82-97) for n prefix sums. */
+int samx_tree_find_prefixsum(const double* sum_tree, int64_t cap, const double* prefix, int64_t n,
+                             int64_t* idx_out, void* stream);
+
+/* PrioritizedRB._sample_w_priorities + the weight loop of _sample (memory.py:248-309).
+ * u: the B unit uniforms the reference draws with random.random() (host generates them with the
+ * same generator and copies them in).  idxs_out int64[B]; iws_out float64[B] (and, if not NULL,
+ * iws_f32_out float32[B] — what the critic loss is fed).  Requires num_entries >= 2.
+ * Indices and all tree sums are bit-exact; iws use the device pow and agree to ~1e-15 relative. */
+int samx_per_sample(const double* sum_tree, const double* min_tree, int64_t cap,
+                    int64_t num_entries, const double* u, int64_t B, double beta,
+                    int64_t* idxs_out, double* iws_out, float* iws_f32_out, void* stream);
+
+/* HOST helper: leaf values `priority ** alpha` with the host libm pow — the same routine CPython's
+ * float.__pow__ reaches in memory.py:341-342,376-377 — so leaves are bit-identical to the
+ * reference's.  Adds demos_eps to entries whose index is < num_demos (memory.py:373-375), returns
+ * through *max_priority_host the running max(priority) (memory.py:379).  All pointers HOST. */
+int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host, int64_t n,
+                              double alpha, int64_t num_demos, double demos_eps,
+                              double* leaf_out_host, double* max_priority_host);
+
+/* ---- replay storage ------------------------------------------------------------------------ */
+/* RingBuffer.get_batch for the five atoms at once (memory.py:33-34,74-84): row = (start+idx)%maxlen.
+ * Any output may be NULL. */
+int samx_replay_gather(const float* obs0, const float* acs, const float* rews, const float* dones1,
+                       const float* obs1, int64_t maxlen, int64_t start, int ob_dim, int ac_dim,
+                       const int64_t* idxs, int64_t B, float* o_obs0, float* o_acs, float* o_rews,
+                       float* o_dones1, float* o_obs1, void* stream);
+
+/* RingBuffer.append of one staged transition (memory.py:36-57,177-184): `row` is the physical
+ * slot the host ring arithmetic chose; packed = [obs0(ob) | acs(ac) | rew | obs1(ob) | done]. */
+int samx_replay_write(float* obs0, float* acs, float* rews, float* dones1, float* obs1,
+                      int ob_dim, int ac_dim, const float* packed, const int64_t* rows, int64_t n,
+                      void* stream);
+
+/* ---- running mean / std (helpers/mpi_running_mean_std.py) ---------------------------------- */
+/* update() lines 47-53: addvec = [sum_x(dim), sum_x^2(dim), count] in float64 over the rows of x1
+ * (n1 rows) followed by x2 (n2 rows, may be NULL/0).  The all-reduce of line 55 is the caller's
+ * (RCCL) between this call and samx_rms_commit. */
+int samx_rms_batch_sums(const float* x1, int64_t n1, const float* x2, int64_t n2, int dim,
+                        double* addvec, void* stream);
+/* lines 40-45 + 31-34: sums += addvec ; mean = f32(sum/count) ;
+ * std = sqrt(max(f32(sumsq/count) - mean^2, 1e-2)). sums: double[2*dim+1]. */
+int samx_rms_commit(double* sums, const double* addvec, int dim, float* mean_out, float* std_out,
+                    void* stream);
+
+/* ---- optimiser ----------------------------------------------------------------------------- */
+/* MpiAdamOptimizer step (helpers/mpi_adam.py:18-36 + tf.train.AdamOptimizer): grad is the SUM over
+ * workers of the local flat gradients (after the RCCL all-reduce; grad_scale = 1/world gives the
+ * mean of line 27), then clip_by_global_norm (lines 31-33; clip_norm <= 0 disables), then TF1 Adam
+ * with epsilon outside the square root; `step` is the 1-based update count.  If targ != NULL the
+ * Polyak update of sam_agent.py:31-34 (targ = (1-tau) targ + tau param) is applied to the fresh
+ * parameters in the same pass.  partials: float[samx_adam_partials()] scratch. */
+int samx_adam_partials(void);
+int samx_clip_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int64_t step, float clip_norm,
+                   float grad_scale, float* targ, float tau, float* partials, void* stream);
+
+/* get_target_updates (sam_agent.py:20-37): tau = 1 is the hard copy. */
+int samx_polyak(float* targ, const float* param, int64_t n, float tau, void* stream);
+
+/* flatgrad(..., clip_norm) (helpers/tf_util.py:137-151): out = grad * clip/max(|grad|, clip) — the
+ * locally clipped gradient SAMAgent.train returns for logging (sam_agent.py:433,520,706-711). */
+int samx_clip_copy(const float* grad, int64_t n, float clip_norm, float* out, float* partials,
+                   void* stream);
+
+/* check_synced (helpers/mpi_adam.py:55-72): *mismatch_out (int32) = number of differing words. */
+int samx_count_mismatch(const float* a, const float* b, int64_t n, int32_t* mismatch_out,
+                        void* stream);
+
+/* ---- network passes ------------------------------------------------------------------------ */
+/* ob_mean/ob_std: float[ob] from samx_rms_commit, or NULL when rmsify_obs is off
+ * (sam_agent.py:150-159).  Observations are normalised and clipped to [-5, 5] inside.
+ * Calls that take only a critic-shaped network get `ob_dim` (the action width is in_dim - ob_dim). */
+
+/* Scratch bytes that cover every agent-side call below for batch B (reward_net may be NULL). */
+size_t samx_nets_ws_bytes(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward_net,
+                          int64_t B);
+
+/* SAMAgent.act_q (sam_agent.py:177,186,209-212 ; predict at 592-619): ac = clip(high*tanh(actor)),
+ * q = critic(obz, ac).  ac_out float[B,ac]; q_out float[B] or NULL. */
+int samx_act_q(const samx_mlp* actor, const float* actor_params, const samx_mlp* critic,
+               const float* critic_params, const float* obs, const float* ob_mean,
+               const float* ob_std, int64_t B, float ac_high, float* ac_out, float* q_out,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* get_targ_q (sam_agent.py:196-205,225-226): rews + gamma^td_len * (1-dones1) * Q'(obz1, mu'(obz1)).
+ * td_len NULL means 1 for every row (sam_agent.py:648-654). out float[B]. */
+int samx_targ_q(const samx_mlp* actor, const float* targ_actor_params, const samx_mlp* critic,
+                const float* targ_critic_params, const float* obs1, const float* rews,
+                const float* dones1, const float* td_len, const float* ob_mean,
+                const float* ob_std, int64_t B, float gamma, float ac_high, float* out, void* ws,
+                size_t ws_bytes, void* stream);
+
+/* setup_critic (sam_agent.py:457-520): td = Q(obz0, acs) - tc1s ; loss = mean(huber(td) * iws) *
+ * td_scale + wd_scale * (|W1|^2 + |W2|^2)/2.  iws NULL for uniform replay.
+ * losses_out float[3] = {critic_td_loss_1, critic_wd, critic_total_loss}; grad_out float[P] the
+ * unclipped flat gradient; td_out float[B] or NULL. */
+int samx_critic_grad(const samx_mlp* critic, const float* critic_params, const float* obs0,
+                     const float* acs, const float* iws, const float* tc1s, const float* ob_mean,
+                     const float* ob_std, int64_t B, int ob_dim, float td_scale, float wd_scale,
+                     float* losses_out, float* grad_out, float* td_out, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* critic_ops['td_errors'] (sam_agent.py:534-538,693-701): Q(obz0, acs) - tc1s, float[B]. */
+int samx_td_errors(const samx_mlp* critic, const float* critic_params, const float* obs0,
+                   const float* acs, const float* tc1s, const float* ob_mean, const float* ob_std,
+                   int64_t B, int ob_dim, float* td_out, void* ws, size_t ws_bytes, void* stream);
+
+/* setup_actor (sam_agent.py:406-433): loss = -q_scale*mean Q(obz0, mu(obz0))
+ *                                           -d_scale*mean D(obz0, mu(obz0)), gradient wrt the actor only.
+ * reward_params may be NULL when d_scale == 0.  losses_out float[3] = {actor_q_loss, actor_d_loss,
+ * actor_total_loss}; grad_out float[P_actor]. */
+int samx_actor_grad(const samx_mlp* actor, const float* actor_params, const samx_mlp* critic,
+                    const float* critic_params, const samx_mlp* reward_net,
+                    const float* reward_params, const float* obs0, const float* ob_mean,
+                    const float* ob_std, int64_t B, float ac_high, float q_scale, float d_scale,
+                    float* losses_out, float* grad_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Discriminator losses + gradient (imitation_algorithms/discriminator.py:77-161): BCE(policy,
+ * fake) + BCE(expert, real) - ent_reg_scale*mean entropy + 10 * gradient penalty on the
+ * interpolates eps*p + (1-eps)*e.  The tensors TF draws at run time are inputs here:
+ * eps_ob float[B,ob], eps_ac float[B,ac] ~ U[0,1) (lines 129-134); real_labels / fake_labels float[B]
+ * (lines 89-109; NULL means 1 / 0).  losses_out float[8] in the order of lines 145-158;
+ * grad_out float[P_d] unclipped. */
+size_t samx_disc_ws_bytes(const samx_mlp* reward_net, int64_t B);
+int samx_disc_grad(const samx_mlp* reward_net, const float* params, const float* p_obs,
+                   const float* p_acs, const float* e_obs, const float* e_acs,
+                   const float* eps_ob, const float* eps_ac, const float* real_labels,
+                   const float* fake_labels, const float* ob_mean, const float* ob_std, int64_t B,
+                   int ob_dim, float ent_reg_scale, float* losses_out, float* grad_out, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* compute_reward (discriminator.py:180-194), batched: -log(1 - sigmoid(s) + 1e-8), or
+ * log_sigmoid(s) when non_satur_grad.  out float[B]. */
+int samx_reward(const samx_mlp* reward_net, const float* params, const float* obs, const float* acs,
+                const float* ob_mean, const float* ob_std, int64_t B, int ob_dim, int non_satur_grad,
+                float* out,
+                void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMX_H */

@@ -117,6 +117,20 @@ def mlp(P, x, d):
     return h @ P['W3'] + P['b3']
 
 
+def min_abs_preact(flat, d, x, dtype=torch.float64):
+    """Per row, the smallest |pre-activation| over both hidden layers.  Leaky-ReLU has a kink at 0:
+    a row whose pre-activation is within rounding distance of it has a precision-dependent gradient
+    (mask 1 vs 0.2), so parity tests keep their inputs away from the kink by a stated margin."""
+    P = unflatten(_t(flat, dtype), d)
+    x = _t(x, dtype)
+    z1 = x @ P['W1'] + P['b1']
+    h = lrelu(z1)
+    if d.layernorm:
+        h = layer_norm(h, P['beta1'], P['gamma1'])
+    z2 = h @ P['W2'] + P['b2']
+    return torch.minimum(z1.abs().min(dim=1).values, z2.abs().min(dim=1).values).numpy()
+
+
 def rms_mean_std(sums, dim):
     """sums = [sum(dim), sumsq(dim), count] float64 -> (mean f32, std f32)
     (mpi_running_mean_std.py:31-34: the subtraction happens in float32)."""
@@ -298,8 +312,11 @@ def smooth_labels(u_real, u_fake=None):
 
 
 def adam_tf1(theta, m, v, g, lr, t, b1=0.9, b2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer dense update at step t (1-based)."""
+    """tf.train.AdamOptimizer dense update at step t (1-based).  TF casts lr/beta1/beta2/epsilon
+    to the variable dtype (float32) before use, so 1-beta2 is 1-fl32(0.999), 1.3e-5 off 1e-3; the
+    oracle keeps that rounding of the hyper-parameters and does the rest in float64."""
     theta, m, v, g = (np.asarray(a, dtype=np.float64) for a in (theta, m, v, g))
+    lr, b1, b2, eps = (float(np.float32(x)) for x in (lr, b1, b2, eps))
     lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
     m = b1 * m + (1.0 - b1) * g
     v = b2 * v + (1.0 - b2) * g * g

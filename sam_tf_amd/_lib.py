@@ -1,0 +1,100 @@
+"""ctypes binding of libsamx.so (include/samx.h).  There is no fallback: if the HIP extension is
+missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libsamx.so')
+
+
+class SamxError(RuntimeError):
+    pass
+
+
+class MlpDesc(C.Structure):
+    """Mirror of `struct samx_mlp`."""
+    _fields_ = [('in_dim', C.c_int32), ('h1', C.c_int32), ('h2', C.c_int32),
+                ('out_dim', C.c_int32), ('layernorm', C.c_int32)]
+
+    def __repr__(self):
+        return 'MlpDesc(in=%d, h1=%d, h2=%d, out=%d, ln=%d)' % (
+            self.in_dim, self.h1, self.h2, self.out_dim, self.layernorm)
+
+
+_P, _I64, _I32, _F, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_size_t
+_MP = C.POINTER(MlpDesc)
+
+# name -> (restype, argtypes); must list every symbol include/samx.h declares
+SIGNATURES = {
+    'samx_last_error': (C.c_char_p, []),
+    'samx_version': (C.c_int, []),
+    'samx_mlp_param_count': (_I64, [_MP]),
+    'samx_tree_init': (C.c_int, [_P, _P, _P, _I64, _P]),
+    'samx_tree_set': (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+    'samx_tree_reduce': (C.c_int, [_P, _I64, C.c_int, _I64, _I64, _P, _P]),
+    'samx_tree_find_prefixsum': (C.c_int, [_P, _I64, _P, _I64, _P, _P]),
+    'samx_per_sample': (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _D, _P, _P, _P, _P]),
+    'samx_per_leaf_values_host': (C.c_int, [_P, _P, _I64, _D, _I64, _D, _P, _P]),
+    'samx_replay_gather': (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
+                                     _P, _P, _P, _P, _P, _P]),
+    'samx_replay_write': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _I64, _P]),
+    'samx_rms_batch_sums': (C.c_int, [_P, _I64, _P, _I64, C.c_int, _P, _P]),
+    'samx_rms_commit': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    'samx_adam_partials': (C.c_int, []),
+    'samx_clip_adam': (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _F, _P, _F, _P,
+                                 _P]),
+    'samx_polyak': (C.c_int, [_P, _P, _I64, _F, _P]),
+    'samx_clip_copy': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
+    'samx_count_mismatch': (C.c_int, [_P, _P, _I64, _P, _P]),
+    'samx_nets_ws_bytes': (_SZ, [_MP, _MP, _MP, _I64]),
+    'samx_act_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    'samx_targ_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _P, _P, _SZ,
+                              _P]),
+    'samx_critic_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _F, _F, _P, _P,
+                                   _P, _P, _SZ, _P]),
+    'samx_td_errors': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _P, _P, _SZ, _P]),
+    'samx_actor_grad': (C.c_int, [_MP, _P, _MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _F, _F, _P, _P,
+                                  _P, _SZ, _P]),
+    'samx_disc_ws_bytes': (_SZ, [_MP, _I64]),
+    'samx_disc_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int,
+                                 _F, _P, _P, _P, _SZ, _P]),
+    'samx_reward': (C.c_int, [_MP, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises SamxError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise SamxError('libsamx.so not found at %s: build it with `python -m sam_tf_amd.build` '
+                            '(there is no CPU fallback)' % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SamxError('libsamx error %d: %s' % (rc, lib().samx_last_error().decode()))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        assert t.is_contiguous(), 'libsamx needs contiguous tensors'
+        return C.c_void_p(t.data_ptr())
+    assert t.flags['C_CONTIGUOUS']
+    return C.c_void_p(t.ctypes.data)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

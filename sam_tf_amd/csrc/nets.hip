@@ -1,0 +1,770 @@
+// Layer-wise network passes for the actor / critic / reward net: row-local kernels (input prep,
+// heads, losses) around the MFMA GEMM of gemm.hip.  This is the general path (any width / batch);
+// small networks additionally have whole-network fused kernels (fused_small.hip).
+//   sam_agent.py:145-205,406-520 ; discriminator.py:61-194 ; networks.py:45-72,222-404
+#include "samx_common.h"
+#include "gemm.h"
+#include "../../include/samx.h"
+#include <math.h>
+
+namespace samx {
+namespace {
+
+struct Net {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int in, h1, h2, out;
+    int64_t oW1, ob1, oW2, ob2, oW3, ob3;  // offsets in the flat vector
+};
+
+Net split(const samx_mlp* d, const float* p) {
+    Net n;
+    n.in = d->in_dim; n.h1 = d->h1; n.h2 = d->h2; n.out = d->out_dim;
+    int64_t o = 0;
+    n.oW1 = o; o += (int64_t)n.in * n.h1;
+    n.ob1 = o; o += n.h1;
+    if (d->layernorm) o += 2 * n.h1;
+    n.oW2 = o; o += (int64_t)n.h1 * n.h2;
+    n.ob2 = o; o += n.h2;
+    if (d->layernorm) o += 2 * n.h2;
+    n.oW3 = o; o += (int64_t)n.h2 * n.out;
+    n.ob3 = o;
+    n.W1 = p + n.oW1; n.b1 = p + n.ob1; n.W2 = p + n.oW2; n.b2 = p + n.ob2;
+    n.W3 = p + n.oW3; n.b3 = p + n.ob3;
+    return n;
+}
+
+int check_desc(const samx_mlp* d, const char* who) {
+    SAMX_REQUIRE(d, "%s: null network description", who);
+    SAMX_REQUIRE(d->in_dim > 0 && d->h1 > 0 && d->h2 > 0 && d->out_dim > 0,
+                 "%s: non-positive layer size", who);
+    SAMX_REQUIRE(d->h1 <= 4096 && d->h2 <= 4096 && d->in_dim <= 65536, "%s: layer too wide", who);
+    if (d->layernorm) return fail(SAMX_ERR_UNSUPPORTED, "%s: layernorm path not built yet", who);
+    return SAMX_OK;
+}
+
+// ---------------------------------------------------------------- row-local kernels
+
+// out[row, 0:ob] = clip((obs - mean)/std, -5, 5)  (sam_agent.py:150-156, math_util.py:8-12) ;
+// out[row, ob:ob+ac] = acs[row]  (critic / reward-net input concat, networks.py:238,363)
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ obs,
+                                                   const float* __restrict__ acs,
+                                                   const float* __restrict__ mean,
+                                                   const float* __restrict__ stdv, int64_t B, int ob,
+                                                   int ac, float* __restrict__ out, int ld) {
+    const int w = ob + (acs ? ac : 0);
+    const int64_t tot = B * w;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / w;
+        const int c = (int)(t % w);
+        float v;
+        if (c < ob) {
+            v = obs[row * ob + c];
+            if (mean) v = fminf(fmaxf((v - mean[c]) / stdv[c], -5.f), 5.f);
+        } else {
+            v = acs[row * ac + (c - ob)];
+        }
+        out[row * ld + c] = v;
+    }
+}
+
+// rows [0,B): policy pair, [B,2B): expert pair, [2B,3B): eps*policy + (1-eps)*expert on the
+// NORMALISED observations and raw actions (discriminator.py:71-72,129-134)
+__global__ __launch_bounds__(256) void disc_prep_kernel(
+    const float* __restrict__ p_obs, const float* __restrict__ p_acs, const float* __restrict__ e_obs,
+    const float* __restrict__ e_acs, const float* __restrict__ eps_ob,
+    const float* __restrict__ eps_ac, const float* __restrict__ mean, const float* __restrict__ stdv,
+    int64_t B, int ob, int ac, float* __restrict__ X) {
+    const int w = ob + ac;
+    const int64_t tot = B * w;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / w;
+        const int c = (int)(t % w);
+        float p, e, eps;
+        if (c < ob) {
+            p = p_obs[row * ob + c];
+            e = e_obs[row * ob + c];
+            if (mean) {
+                p = fminf(fmaxf((p - mean[c]) / stdv[c], -5.f), 5.f);
+                e = fminf(fmaxf((e - mean[c]) / stdv[c], -5.f), 5.f);
+            }
+            eps = eps_ob[row * ob + c];
+        } else {
+            p = p_acs[row * ac + (c - ob)];
+            e = e_acs[row * ac + (c - ob)];
+            eps = eps_ac[row * ac + (c - ob)];
+        }
+        X[row * w + c] = p;
+        X[(B + row) * w + c] = e;
+        X[(2 * B + row) * w + c] = eps * p + (1.f - eps) * e;
+    }
+}
+
+enum HeadMode { HEAD_Q, HEAD_TARG, HEAD_TD, HEAD_CRITIC, HEAD_ACTOR_Q, HEAD_DISC, HEAD_REWARD };
+
+struct HeadArgs {
+    const float* H2;   // [M, h2] last hidden activation
+    const float* w3;   // [h2] (out_dim == 1)
+    const float* b3;   // [1]
+    int64_t M;
+    int h2;
+    // mode-specific
+    const float* r0 = nullptr;   // rews | tc1s | fake labels
+    const float* r1 = nullptr;   // dones1 | iws | real labels
+    const float* r2 = nullptr;   // td_len
+    float c0 = 0.f, c1 = 0.f;    // gamma | coefficient | ent scale
+    int64_t B = 0;               // rows per section (HEAD_DISC)
+    int flag = 0;                // non_satur_grad
+    float* out0 = nullptr;       // q | targ | td | rowloss | reward | ds
+    float* out1 = nullptr;       // td | ce
+    float* out2 = nullptr;       // dq | ent
+    float* out3 = nullptr;       // sigmoid
+    float* DZ2 = nullptr;        // [M, h2]
+};
+
+__device__ __forceinline__ float wave_sum(float x) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x z + log1p(exp(-|x|))
+__device__ __forceinline__ float sig_ce(float x, float z) {
+    return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// one wave per row: s = <H2[row], w3> + b3, then the mode's row-local tail
+template <int MODE>
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const float* h = a.H2 + row * a.h2;
+    float acc = 0.f;
+    for (int c = lane; c < a.h2; c += 64) acc = fmaf(h[c], a.w3[c], acc);
+    const float s = wave_sum(acc) + a.b3[0];
+    float dq = 0.f;
+    if (MODE == HEAD_Q) {
+        if (lane == 0) a.out0[row] = s;
+        return;
+    }
+    if (MODE == HEAD_TARG) {
+        if (lane == 0) {
+            // rews + gamma^td_len * (1 - dones1) * q'   (sam_agent.py:202-205)
+            const float g = a.r2 ? powf(a.c0, a.r2[row]) : a.c0;
+            a.out0[row] = a.r0[row] + g * ((1.f - a.r1[row]) * s);
+        }
+        return;
+    }
+    if (MODE == HEAD_TD) {
+        if (lane == 0) a.out0[row] = s - a.r0[row];
+        return;
+    }
+    if (MODE == HEAD_REWARD) {
+        if (lane == 0) {
+            // discriminator.py:180-190
+            a.out0[row] = a.flag ? (fminf(s, 0.f) - log1pf(expf(-fabsf(s))))
+                                 : -logf(1.f - sigmoidf_(s) + 1e-8f);
+        }
+        return;
+    }
+    if (MODE == HEAD_CRITIC) {
+        const float td = s - a.r0[row];
+        const float iw = a.r1 ? a.r1[row] : 1.f;
+        const float ad = fabsf(td);
+        const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;      // math_util.py:22-29
+        const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
+        dq = a.c0 * dh * iw;                                          // c0 = td_scale / B
+        if (lane == 0) {
+            a.out0[row] = hub * iw;
+            if (a.out1) a.out1[row] = td;
+            a.out2[row] = dq;
+        }
+    }
+    if (MODE == HEAD_ACTOR_Q) {
+        dq = a.c0;  // -scale / B
+        if (lane == 0) a.out0[row] = s;
+    }
+    if (MODE == HEAD_DISC) {
+        if (row < 2 * a.B) {
+            const bool pol = row < a.B;
+            const float z = pol ? (a.r0 ? a.r0[row] : 0.f) : (a.r1 ? a.r1[row - a.B] : 1.f);
+            const float sg = sigmoidf_(s);
+            // d/ds [CE(s,z)/B - ent_scale * CE(s, sigmoid(s)) / 2B]
+            dq = (sg - z) / (float)a.B + a.c1 * s * sg * (1.f - sg) / (float)(2 * a.B);
+            if (lane == 0) {
+                a.out1[row] = sig_ce(s, z);
+                a.out2[row] = sig_ce(s, sg);
+                a.out3[row] = sg;
+            }
+        } else {
+            dq = 1.f;  // interpolate rows: seed of d(sum scores)/d(inputs) (discriminator.py:136)
+        }
+        if (lane == 0) a.out0[row] = dq;
+    }
+    // dZ2 = dq * w3 * lrelu'(A2)
+    float* dz = a.DZ2 + row * a.h2;
+    for (int c = lane; c < a.h2; c += 64) dz[c] = dq * a.w3[c] * (h[c] >= 0.f ? 1.f : 0.2f);
+}
+
+template <int MODE>
+int launch_head(const HeadArgs& a, hipStream_t st) {
+    head_kernel<MODE><<<(unsigned)((a.M + 3) / 4), 256, 0, st>>>(a);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+__device__ __forceinline__ double block_sum_d(double x, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    __syncthreads();  // protect sh reuse across consecutive calls
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;  // same value on every thread
+}
+
+__device__ double sum_f32(const float* x, int64_t n, double* sh) {
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) a += (double)x[i];
+    return block_sum_d(a, sh);
+}
+__device__ double sumsq_f32(const float* x, int64_t n, double* sh) {
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) a += (double)x[i] * (double)x[i];
+    return block_sum_d(a, sh);
+}
+
+// {critic_td_loss_1, critic_wd, critic_total_loss}  (sam_agent.py:473-517)
+__global__ __launch_bounds__(1024) void critic_losses_kernel(const float* rowloss, int64_t B,
+                                                             float td_scale, float wd_scale,
+                                                             const float* W1, int64_t n1,
+                                                             const float* W2, int64_t n2,
+                                                             float* losses) {
+    __shared__ double sh[16];
+    const double l = sum_f32(rowloss, B, sh) / (double)B * td_scale;
+    double wd = 0.0;
+    if (wd_scale > 0.f) wd = 0.5 * wd_scale * (sumsq_f32(W1, n1, sh) + sumsq_f32(W2, n2, sh));
+    if (threadIdx.x == 0) {
+        losses[0] = (float)l;
+        losses[1] = (float)wd;
+        losses[2] = (float)(l + wd);
+    }
+}
+
+// {actor_q_loss, actor_d_loss, actor_total_loss}  (sam_agent.py:412-430)
+__global__ __launch_bounds__(1024) void actor_losses_kernel(const float* rowq, const float* rowd,
+                                                            int64_t B, float q_scale, float d_scale,
+                                                            float* losses) {
+    __shared__ double sh[16];
+    const double q = -sum_f32(rowq, B, sh) / (double)B * q_scale;
+    const double d = rowd ? -sum_f32(rowd, B, sh) / (double)B * d_scale : 0.0;
+    if (threadIdx.x == 0) {
+        losses[0] = (float)q;
+        losses[1] = (float)d;
+        losses[2] = (float)(q + d);
+    }
+}
+
+// gradient-penalty reduction (discriminator.py:138-140): per-block partial sums of g^2 split into
+// observation and action columns
+constexpr int kGpBlocks = 128;
+__global__ __launch_bounds__(256) void gp_sumsq_kernel(const float* __restrict__ G, int64_t B, int ob,
+                                                       int ac, double* __restrict__ partials) {
+    __shared__ double sh[4];
+    const int w = ob + ac;
+    const int64_t tot = B * w;
+    double so = 0.0, sa = 0.0;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256) {
+        const double g = (double)G[t];
+        if ((int)(t % w) < ob) so += g * g; else sa += g * g;
+    }
+    so = block_sum_d(so, sh);
+    sa = block_sum_d(sa, sh);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = so;
+        partials[2 * blockIdx.x + 1] = sa;
+    }
+}
+
+// V = dGP_total/dg = 10 * 2 (N-1)/N * g / (B*dim_part), N = sqrt(mean g_ob^2 + mean g_ac^2)
+__global__ __launch_bounds__(256) void gp_scale_kernel(const float* __restrict__ G, int64_t B, int ob,
+                                                       int ac, const double* __restrict__ partials,
+                                                       int np, float coeff, float* __restrict__ V,
+                                                       float* __restrict__ gp_out) {
+    __shared__ double sh[4];
+    double so = 0.0, sa = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) {
+        so += partials[2 * i];
+        sa += partials[2 * i + 1];
+    }
+    so = block_sum_d(so, sh);
+    sa = block_sum_d(sa, sh);
+    const double mo = so / ((double)B * ob), ma = sa / ((double)B * ac);
+    const double N = sqrt(mo + ma);
+    const double k = (double)coeff * 2.0 * (N - 1.0) / N;
+    const float co = (float)(k / ((double)B * ob)), ca = (float)(k / ((double)B * ac));
+    if (blockIdx.x == 0 && threadIdx.x == 0) gp_out[0] = (float)((N - 1.0) * (N - 1.0));
+    const int w = ob + ac;
+    const int64_t tot = B * w;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256)
+        V[t] = G[t] * (((int)(t % w) < ob) ? co : ca);
+}
+
+// the 8 discriminator losses in the order of discriminator.py:145-158
+__global__ __launch_bounds__(1024) void disc_losses_kernel(const float* ce, const float* ent,
+                                                           const float* sg, const float* gp,
+                                                           int64_t B, float ent_scale, float coeff,
+                                                           float* losses) {
+    __shared__ double sh[16];
+    const double pl = sum_f32(ce, B, sh) / (double)B;
+    const double el = sum_f32(ce + B, B, sh) / (double)B;
+    const double em = sum_f32(ent, 2 * B, sh) / (double)(2 * B);
+    const double pa = sum_f32(sg, B, sh) / (double)B;
+    const double ea = sum_f32(sg + B, B, sh) / (double)B;
+    if (threadIdx.x == 0) {
+        const double eloss = -(double)ent_scale * em;
+        losses[0] = (float)pl;
+        losses[1] = (float)el;
+        losses[2] = (float)em;
+        losses[3] = (float)eloss;
+        losses[4] = (float)pa;
+        losses[5] = (float)ea;
+        losses[6] = gp[0];
+        losses[7] = (float)(pl + el + eloss + (double)coeff * (double)gp[0]);
+    }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld, int64_t B, int n,
+                                 float* __restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < B * n) dst[t] = src[(t / n) * ld + (t % n)];
+}
+
+// ---------------------------------------------------------------- GEMM wrappers
+
+// Y[M,N] = epi(X[M,K] W[K,N] + b)
+int fwd(const float* X, int64_t ldx, int64_t M, int K, const float* W, const float* b, int N, float* Y,
+        int64_t ldy, Epilogue epi, float alpha, const float* aux, int64_t ld_aux, hipStream_t st) {
+    GemmArgs g;
+    g.A = X; g.a_si = ldx; g.a_sr = 1;
+    g.B = W; g.b_sr = N; g.b_sj = 1;
+    g.C = Y; g.ldc = ldy;
+    g.M = (int)M; g.N = N; g.R = K;
+    g.epi = epi; g.bias = b; g.alpha = alpha; g.aux = aux; g.ld_aux = ld_aux;
+    return gemm(g, st);
+}
+
+// dX[M,K] = epi(dZ[M,N] W[K,N]^T)   (W row stride ldw: pass a row-offset W to take a column band)
+int bwd_data(const float* dZ, int64_t ldz, int64_t M, int N, const float* W, int64_t ldw, int K,
+             float* dX, int64_t ldx, Epilogue epi, const float* aux, int64_t ld_aux, const float* add,
+             int64_t ld_add, float alpha, hipStream_t st) {
+    GemmArgs g;
+    g.A = dZ; g.a_si = ldz; g.a_sr = 1;
+    g.B = W; g.b_sr = 1; g.b_sj = ldw;
+    g.C = dX; g.ldc = ldx;
+    g.M = (int)M; g.N = K; g.R = N;
+    g.epi = epi; g.aux = aux; g.ld_aux = ld_aux; g.add = add; g.ld_add = ld_add; g.alpha = alpha;
+    return gemm(g, st);
+}
+
+// [dW; db] ([K+1, N], contiguous in the flat gradient) = [X, 1]^T dZ (+ wd * W), reduction over rows;
+// the ones column is 1 for rows < ones_rows
+int wgrad(const float* X, int64_t ldx, int K, const float* dZ, int64_t ldz, int N, int64_t rows,
+          int64_t ones_rows, float* dW, float wd, const float* W, float* partials,
+          size_t partial_floats, hipStream_t st) {
+    GemmArgs g;
+    g.A = X; g.a_si = 1; g.a_sr = ldx;
+    g.B = dZ; g.b_sr = ldz; g.b_sj = 1;
+    g.C = dW; g.ldc = N;
+    g.M = K; g.N = N; g.R = (int)rows;
+    g.a_ones_rows = (int)ones_rows;
+    if (wd > 0.f) { g.epi = EPI_AXPY; g.alpha = wd; g.aux = W; g.ld_aux = N; }
+    g.nsplit = pick_nsplit(K + 1, N, (int)rows);
+    if ((size_t)g.nsplit * (K + 1) * N > partial_floats) g.nsplit = 1;
+    g.partials = partials;
+    return gemm(g, st);
+}
+
+size_t wgrad_partial_floats(const samx_mlp* d, int64_t rows) {
+    size_t m = 0;
+    const int dims[3][2] = {{d->in_dim + 1, d->h1}, {d->h1 + 1, d->h2}, {d->h2 + 1, d->out_dim}};
+    for (auto& q : dims) {
+        size_t s = (size_t)pick_nsplit(q[0], q[1], (int)rows) * q[0] * q[1];
+        if (s > m) m = s;
+    }
+    return m;
+}
+
+#define TRY(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != SAMX_OK) return rc__; \
+    } while (0)
+
+int grid1d(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// ---------------------------------------------------------------- role: shared forward pieces
+
+// XC[:, 0:ob] = obz ; XC[:, ob:] = actor(obz) ; returns hidden activations in A1a/A2a
+int actor_into(const samx_mlp* da, const Net& a, const float* obs, const float* mean,
+               const float* stdv, int64_t B, int acdim, float high, float* XC, float* A1a, float* A2a,
+               hipStream_t st) {
+    const int ob = a.in, ld = ob + acdim;
+    prep_kernel<<<grid1d(B * ob), 256, 0, st>>>(obs, nullptr, mean, stdv, B, ob, 0, XC, ld);
+    SAMX_LAUNCH_CHECK();
+    TRY(fwd(XC, ld, B, ob, a.W1, a.b1, a.h1, A1a, a.h1, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    TRY(fwd(A1a, a.h1, B, a.h1, a.W2, a.b2, a.h2, A2a, a.h2, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    TRY(fwd(A2a, a.h2, B, a.h2, a.W3, a.b3, a.out, XC + ob, ld, EPI_BIAS_TANH, high, nullptr, 0, st));
+    return SAMX_OK;
+}
+
+int hidden(const Net& c, const float* X, int64_t M, float* A1, float* A2, hipStream_t st) {
+    TRY(fwd(X, c.in, M, c.in, c.W1, c.b1, c.h1, A1, c.h1, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    TRY(fwd(A1, c.h1, M, c.h1, c.W2, c.b2, c.h2, A2, c.h2, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    return SAMX_OK;
+}
+
+struct AgentWs {
+    float *XC, *A1a, *A2a, *A1c, *A2c, *DZ2c, *DZ1c, *A1d, *A2d, *DZ2d, *DZ1d, *dAd, *dPre, *DZ2a,
+        *DZ1a, *row0, *row1, *row2, *partials;
+    size_t partial_floats;
+};
+
+AgentWs carve_agent(Arena& ar, const samx_mlp* da, const samx_mlp* dc, const samx_mlp* dd, int64_t B) {
+    AgentWs w;
+    const int acdim = dc->in_dim - (da ? da->in_dim : 0);
+    const int h1a = da ? da->h1 : 1, h2a = da ? da->h2 : 1;
+    w.XC = ar.take<float>(B * dc->in_dim);
+    w.A1a = ar.take<float>(B * h1a);
+    w.A2a = ar.take<float>(B * h2a);
+    w.A1c = ar.take<float>(B * dc->h1);
+    w.A2c = ar.take<float>(B * dc->h2);
+    w.DZ2c = ar.take<float>(B * dc->h2);
+    w.DZ1c = ar.take<float>(B * dc->h1);
+    const int h1d = dd ? dd->h1 : 1, h2d = dd ? dd->h2 : 1;
+    w.A1d = ar.take<float>(B * h1d);
+    w.A2d = ar.take<float>(B * h2d);
+    w.DZ2d = ar.take<float>(B * h2d);
+    w.DZ1d = ar.take<float>(B * h1d);
+    w.dAd = ar.take<float>(B * (acdim > 0 ? acdim : 1));
+    w.dPre = ar.take<float>(B * (acdim > 0 ? acdim : 1));
+    w.DZ2a = ar.take<float>(B * h2a);
+    w.DZ1a = ar.take<float>(B * h1a);
+    w.row0 = ar.take<float>(B);
+    w.row1 = ar.take<float>(B);
+    w.row2 = ar.take<float>(B);
+    size_t pf = wgrad_partial_floats(dc, B);
+    if (da) { size_t s = wgrad_partial_floats(da, B); if (s > pf) pf = s; }
+    w.partial_floats = pf;
+    w.partials = ar.take<float>(pf);
+    return w;
+}
+
+}  // namespace
+}  // namespace samx
+
+using namespace samx;
+
+extern "C" {
+
+size_t samx_nets_ws_bytes(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward_net,
+                          int64_t B) {
+    if (!actor || !critic || B <= 0) return 0;
+    Arena ar(nullptr, 0);
+    carve_agent(ar, actor, critic, reward_net, B);
+    return align_up(ar.off, 256) + 256;
+}
+
+int samx_act_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
+               const float* obs, const float* mean, const float* stdv, int64_t B, float high,
+               float* ac_out, float* q_out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(da, "samx_act_q(actor)"));
+    TRY(check_desc(dc, "samx_act_q(critic)"));
+    SAMX_REQUIRE(pa && pc && obs && ac_out && ws, "samx_act_q: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_act_q: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dc->in_dim == da->in_dim + da->out_dim && dc->out_dim == 1,
+                 "samx_act_q: critic input must be ob+ac and its output 1");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, da, dc, nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_act_q: workspace %zu < %zu", ws_bytes, ar.off);
+    Net a = split(da, pa), c = split(dc, pc);
+    TRY(actor_into(da, a, obs, mean, stdv, B, da->out_dim, high, w.XC, w.A1a, w.A2a, st));
+    copy_cols_kernel<<<grid1d(B * da->out_dim), 256, 0, st>>>(w.XC + da->in_dim, dc->in_dim, B,
+                                                             da->out_dim, ac_out);
+    SAMX_LAUNCH_CHECK();
+    if (q_out) {
+        TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+        HeadArgs h;
+        h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.out0 = q_out;
+        TRY(launch_head<HEAD_Q>(h, st));
+    }
+    return SAMX_OK;
+}
+
+int samx_targ_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
+                const float* obs1, const float* rews, const float* dones1, const float* td_len,
+                const float* mean, const float* stdv, int64_t B, float gamma, float high, float* out,
+                void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(da, "samx_targ_q(actor)"));
+    TRY(check_desc(dc, "samx_targ_q(critic)"));
+    SAMX_REQUIRE(pa && pc && obs1 && rews && dones1 && out && ws, "samx_targ_q: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_targ_q: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dc->in_dim == da->in_dim + da->out_dim && dc->out_dim == 1,
+                 "samx_targ_q: critic input must be ob+ac and its output 1");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, da, dc, nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_targ_q: workspace %zu < %zu", ws_bytes, ar.off);
+    Net a = split(da, pa), c = split(dc, pc);
+    TRY(actor_into(da, a, obs1, mean, stdv, B, da->out_dim, high, w.XC, w.A1a, w.A2a, st));
+    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+    HeadArgs h;
+    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
+    h.r0 = rews; h.r1 = dones1; h.r2 = td_len; h.c0 = gamma; h.out0 = out;
+    return launch_head<HEAD_TARG>(h, st);
+}
+
+int samx_td_errors(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
+                   const float* tc1s, const float* mean, const float* stdv, int64_t B, int ob_dim,
+                   float* td_out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(dc, "samx_td_errors"));
+    SAMX_REQUIRE(pc && obs0 && acs && tc1s && td_out && ws, "samx_td_errors: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_td_errors: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dc->out_dim == 1 && ob_dim > 0 && ob_dim < dc->in_dim,
+                 "samx_td_errors: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, nullptr, dc, nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_td_errors: workspace %zu < %zu", ws_bytes, ar.off);
+    Net c = split(dc, pc);
+    prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs0, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
+                                                 c.in);
+    SAMX_LAUNCH_CHECK();
+    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+    HeadArgs h;
+    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.r0 = tc1s; h.out0 = td_out;
+    return launch_head<HEAD_TD>(h, st);
+}
+
+int samx_reward(const samx_mlp* dd, const float* pd, const float* obs, const float* acs,
+                const float* mean, const float* stdv, int64_t B, int ob_dim, int non_satur_grad,
+                float* out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(dd, "samx_reward"));
+    SAMX_REQUIRE(pd && obs && acs && out && ws, "samx_reward: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_reward: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dd->out_dim == 1 && ob_dim > 0 && ob_dim < dd->in_dim, "samx_reward: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, nullptr, dd, nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_reward: workspace %zu < %zu", ws_bytes, ar.off);
+    Net c = split(dd, pd);
+    prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
+                                                 c.in);
+    SAMX_LAUNCH_CHECK();
+    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+    HeadArgs h;
+    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.flag = non_satur_grad; h.out0 = out;
+    return launch_head<HEAD_REWARD>(h, st);
+}
+
+int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
+                     const float* iws, const float* tc1s, const float* mean, const float* stdv,
+                     int64_t B, int ob_dim, float td_scale, float wd_scale, float* losses_out,
+                     float* grad_out, float* td_out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(dc, "samx_critic_grad"));
+    SAMX_REQUIRE(pc && obs0 && acs && tc1s && losses_out && grad_out && ws,
+                 "samx_critic_grad: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_critic_grad: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dc->out_dim == 1 && ob_dim > 0 && ob_dim < dc->in_dim,
+                 "samx_critic_grad: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, nullptr, dc, nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_critic_grad: workspace %zu < %zu", ws_bytes, ar.off);
+    Net c = split(dc, pc);
+    prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs0, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
+                                                 c.in);
+    SAMX_LAUNCH_CHECK();
+    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+    HeadArgs h;
+    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
+    h.r0 = tc1s; h.r1 = iws; h.c0 = td_scale / (float)B;
+    h.out0 = w.row0; h.out1 = td_out; h.out2 = w.row1; h.DZ2 = w.DZ2c;
+    TRY(launch_head<HEAD_CRITIC>(h, st));
+    TRY(wgrad(w.A2c, c.h2, c.h2, w.row1, 1, 1, B, B, grad_out + c.oW3, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    TRY(wgrad(w.A1c, c.h1, c.h1, w.DZ2c, c.h2, c.h2, B, B, grad_out + c.oW2, wd_scale, c.W2, w.partials,
+              w.partial_floats, st));
+    TRY(bwd_data(w.DZ2c, c.h2, B, c.h2, c.W2, c.h2, c.h1, w.DZ1c, c.h1, EPI_MASK, w.A1c, c.h1, nullptr, 0,
+                 0.f, st));
+    TRY(wgrad(w.XC, c.in, c.in, w.DZ1c, c.h1, c.h1, B, B, grad_out + c.oW1, wd_scale, c.W1, w.partials,
+              w.partial_floats, st));
+    critic_losses_kernel<<<1, 1024, 0, st>>>(w.row0, B, td_scale, wd_scale, c.W1, (int64_t)c.in * c.h1,
+                                             c.W2, (int64_t)c.h1 * c.h2, losses_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
+                    const samx_mlp* dd, const float* pd, const float* obs0, const float* mean,
+                    const float* stdv, int64_t B, float high, float q_scale, float d_scale,
+                    float* losses_out, float* grad_out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(da, "samx_actor_grad(actor)"));
+    TRY(check_desc(dc, "samx_actor_grad(critic)"));
+    const bool use_d = d_scale != 0.f;
+    if (use_d) {
+        TRY(check_desc(dd, "samx_actor_grad(reward net)"));
+        SAMX_REQUIRE(pd, "samx_actor_grad: d_scale != 0 needs reward-net parameters");
+        SAMX_REQUIRE(dd->in_dim == dc->in_dim && dd->out_dim == 1, "samx_actor_grad: reward-net shape");
+    }
+    SAMX_REQUIRE(pa && pc && obs0 && losses_out && grad_out && ws, "samx_actor_grad: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_actor_grad: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dc->in_dim == da->in_dim + da->out_dim && dc->out_dim == 1,
+                 "samx_actor_grad: critic input must be ob+ac and its output 1");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    AgentWs w = carve_agent(ar, da, dc, use_d ? dd : nullptr, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_actor_grad: workspace %zu < %zu", ws_bytes, ar.off);
+    Net a = split(da, pa), c = split(dc, pc);
+    const int ob = a.in, A = a.out, ld = ob + A;
+    TRY(actor_into(da, a, obs0, mean, stdv, B, A, high, w.XC, w.A1a, w.A2a, st));
+    // Q branch: forward, then back to the action input
+    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
+    HeadArgs h;
+    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
+    h.c0 = -q_scale / (float)B; h.out0 = w.row0; h.DZ2 = w.DZ2c;
+    TRY(launch_head<HEAD_ACTOR_Q>(h, st));
+    TRY(bwd_data(w.DZ2c, c.h2, B, c.h2, c.W2, c.h2, c.h1, w.DZ1c, c.h1, EPI_MASK, w.A1c, c.h1, nullptr, 0,
+                 0.f, st));
+    const float* add = nullptr;
+    if (use_d) {
+        Net d = split(dd, pd);
+        TRY(hidden(d, w.XC, B, w.A1d, w.A2d, st));
+        HeadArgs hd;
+        hd.H2 = w.A2d; hd.w3 = d.W3; hd.b3 = d.b3; hd.M = B; hd.h2 = d.h2;
+        hd.c0 = -d_scale / (float)B; hd.out0 = w.row1; hd.DZ2 = w.DZ2d;
+        TRY(launch_head<HEAD_ACTOR_Q>(hd, st));
+        TRY(bwd_data(w.DZ2d, d.h2, B, d.h2, d.W2, d.h2, d.h1, w.DZ1d, d.h1, EPI_MASK, w.A1d, d.h1, nullptr,
+                     0, 0.f, st));
+        TRY(bwd_data(w.DZ1d, d.h1, B, d.h1, d.W1 + (int64_t)ob * d.h1, d.h1, A, w.dAd, A, EPI_NONE,
+                     nullptr, 0, nullptr, 0, 0.f, st));
+        add = w.dAd;
+    }
+    // d loss / d pre-tanh = (dQ/da [+ dD/da]) * high * (1 - tanh^2)
+    TRY(bwd_data(w.DZ1c, c.h1, B, c.h1, c.W1 + (int64_t)ob * c.h1, c.h1, A, w.dPre, A, EPI_ADD_TANHGRAD,
+                 w.XC + ob, ld, add, A, high, st));
+    TRY(wgrad(w.A2a, a.h2, a.h2, w.dPre, A, A, B, B, grad_out + a.oW3, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    TRY(bwd_data(w.dPre, A, B, A, a.W3, A, a.h2, w.DZ2a, a.h2, EPI_MASK, w.A2a, a.h2, nullptr, 0, 0.f, st));
+    TRY(wgrad(w.A1a, a.h1, a.h1, w.DZ2a, a.h2, a.h2, B, B, grad_out + a.oW2, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    TRY(bwd_data(w.DZ2a, a.h2, B, a.h2, a.W2, a.h2, a.h1, w.DZ1a, a.h1, EPI_MASK, w.A1a, a.h1, nullptr, 0,
+                 0.f, st));
+    TRY(wgrad(w.XC, ld, ob, w.DZ1a, a.h1, a.h1, B, B, grad_out + a.oW1, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    actor_losses_kernel<<<1, 1024, 0, st>>>(w.row0, use_d ? w.row1 : nullptr, B, q_scale, d_scale,
+                                            losses_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+namespace {
+struct DiscWs {
+    float *X, *A1, *A2, *DS, *DZ2, *DZ1, *G, *ce, *ent, *sg, *gp, *partials;
+    double* gp_part;
+    size_t partial_floats;
+};
+DiscWs carve_disc(Arena& ar, const samx_mlp* dd, int64_t B) {
+    DiscWs w;
+    w.X = ar.take<float>(3 * B * dd->in_dim);
+    w.A1 = ar.take<float>(3 * B * dd->h1);
+    w.A2 = ar.take<float>(3 * B * dd->h2);
+    w.DS = ar.take<float>(3 * B);
+    w.DZ2 = ar.take<float>(3 * B * dd->h2);
+    w.DZ1 = ar.take<float>(3 * B * dd->h1);
+    w.G = ar.take<float>(B * dd->in_dim);
+    w.ce = ar.take<float>(2 * B);
+    w.ent = ar.take<float>(2 * B);
+    w.sg = ar.take<float>(2 * B);
+    w.gp = ar.take<float>(4);
+    w.gp_part = ar.take<double>(2 * kGpBlocks);
+    w.partial_floats = wgrad_partial_floats(dd, 3 * B);
+    w.partials = ar.take<float>(w.partial_floats);
+    return w;
+}
+}  // namespace
+
+size_t samx_disc_ws_bytes(const samx_mlp* dd, int64_t B) {
+    if (!dd || B <= 0) return 0;
+    Arena ar(nullptr, 0);
+    carve_disc(ar, dd, B);
+    return align_up(ar.off, 256) + 256;
+}
+
+int samx_disc_grad(const samx_mlp* dd, const float* pd, const float* p_obs, const float* p_acs,
+                   const float* e_obs, const float* e_acs, const float* eps_ob, const float* eps_ac,
+                   const float* real_labels, const float* fake_labels, const float* mean,
+                   const float* stdv, int64_t B, int ob_dim, float ent_reg_scale, float* losses_out,
+                   float* grad_out, void* ws, size_t ws_bytes, void* stream) {
+    TRY(check_desc(dd, "samx_disc_grad"));
+    SAMX_REQUIRE(pd && p_obs && p_acs && e_obs && e_acs && eps_ob && eps_ac && losses_out && grad_out && ws,
+                 "samx_disc_grad: null pointer");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_disc_grad: mean/std must come together");
+    SAMX_REQUIRE(B > 0 && dd->out_dim == 1 && ob_dim > 0 && ob_dim < dd->in_dim, "samx_disc_grad: bad sizes");
+    SAMX_REQUIRE(ent_reg_scale >= 0.f, "samx_disc_grad: ent_reg_scale must be non-negative");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    DiscWs w = carve_disc(ar, dd, B);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_disc_grad: workspace %zu < %zu", ws_bytes, ar.off);
+    Net d = split(dd, pd);
+    const int ob = ob_dim, ac = d.in - ob_dim;
+    const int64_t M = 3 * B;
+    const float gp_coeff = 10.f;  // discriminator.py:154
+    disc_prep_kernel<<<grid1d(B * d.in), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, mean,
+                                                      stdv, B, ob, ac, w.X);
+    SAMX_LAUNCH_CHECK();
+    TRY(hidden(d, w.X, M, w.A1, w.A2, st));
+    HeadArgs h;
+    h.H2 = w.A2; h.w3 = d.W3; h.b3 = d.b3; h.M = M; h.h2 = d.h2; h.B = B;
+    h.r0 = fake_labels; h.r1 = real_labels; h.c1 = ent_reg_scale;
+    h.out0 = w.DS; h.out1 = w.ce; h.out2 = w.ent; h.out3 = w.sg; h.DZ2 = w.DZ2;
+    TRY(launch_head<HEAD_DISC>(h, st));
+    // back to the first pre-activation for all 3B rows; for the interpolate rows this is the
+    // input-gradient chain of discriminator.py:136
+    TRY(bwd_data(w.DZ2, d.h2, M, d.h2, d.W2, d.h2, d.h1, w.DZ1, d.h1, EPI_MASK, w.A1, d.h1, nullptr, 0, 0.f,
+                 st));
+    const float* DZ1i = w.DZ1 + 2 * B * d.h1;
+    TRY(bwd_data(DZ1i, d.h1, B, d.h1, d.W1, d.h1, d.in, w.G, d.in, EPI_NONE, nullptr, 0, nullptr, 0, 0.f,
+                 st));
+    gp_sumsq_kernel<<<kGpBlocks, 256, 0, st>>>(w.G, B, ob, ac, w.gp_part);
+    SAMX_LAUNCH_CHECK();
+    // V (cotangent of the input gradient) replaces the interpolates in X: they are not needed again
+    float* Xi = w.X + 2 * B * d.in;
+    gp_scale_kernel<<<grid1d(B * d.in), 256, 0, st>>>(w.G, B, ob, ac, w.gp_part, kGpBlocks, gp_coeff, Xi,
+                                                     w.gp);
+    SAMX_LAUNCH_CHECK();
+    // tangent pass along V through the interpolate rows, in place over their activations
+    float* A1i = w.A1 + 2 * B * d.h1;
+    float* A2i = w.A2 + 2 * B * d.h2;
+    TRY(fwd(Xi, d.in, B, d.in, d.W1, nullptr, d.h1, A1i, d.h1, EPI_MASK, 0.f, A1i, d.h1, st));
+    TRY(fwd(A1i, d.h1, B, d.h1, d.W2, nullptr, d.h2, A2i, d.h2, EPI_MASK, 0.f, A2i, d.h2, st));
+    // parameter gradients: one reduction over the 3B stacked rows per layer
+    TRY(wgrad(w.A2, d.h2, d.h2, w.DS, 1, 1, M, 2 * B, grad_out + d.oW3, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    TRY(wgrad(w.A1, d.h1, d.h1, w.DZ2, d.h2, d.h2, M, 2 * B, grad_out + d.oW2, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    TRY(wgrad(w.X, d.in, d.in, w.DZ1, d.h1, d.h1, M, 2 * B, grad_out + d.oW1, 0.f, nullptr, w.partials,
+              w.partial_floats, st));
+    disc_losses_kernel<<<1, 1024, 0, st>>>(w.ce, w.ent, w.sg, w.gp, B, ent_reg_scale, gp_coeff,
+                                           losses_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// Replay row gather / write and running mean-std sums.
+//   imitation_algorithms/memory.py:33-57,74-84 ; helpers/mpi_running_mean_std.py:31-59
+// All HBM-bound byte moving; the gather reads B random rows of (2*ob+ac+2) floats.
+#include "samx_common.h"
+#include "../../include/samx.h"
+
+namespace {
+
+// one wave per sampled row; lanes stride over the row's floats
+__global__ __launch_bounds__(256) void gather_kernel(
+    const float* __restrict__ obs0, const float* __restrict__ acs, const float* __restrict__ rews,
+    const float* __restrict__ dones1, const float* __restrict__ obs1, int64_t maxlen, int64_t start,
+    int ob, int ac, const int64_t* __restrict__ idxs, int64_t B, float* __restrict__ o_obs0,
+    float* __restrict__ o_acs, float* __restrict__ o_rews, float* __restrict__ o_dones1,
+    float* __restrict__ o_obs1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    int64_t idx = idxs[row];
+    int64_t src = (start + idx) % maxlen;
+    if (src < 0) src += maxlen;
+    if (o_obs0)
+        for (int c = lane; c < ob; c += 64) o_obs0[row * ob + c] = obs0[src * ob + c];
+    if (o_obs1)
+        for (int c = lane; c < ob; c += 64) o_obs1[row * ob + c] = obs1[src * ob + c];
+    if (o_acs)
+        for (int c = lane; c < ac; c += 64) o_acs[row * ac + c] = acs[src * ac + c];
+    if (lane == 0) {
+        if (o_rews) o_rews[row] = rews[src];
+        if (o_dones1) o_dones1[row] = dones1[src];
+    }
+}
+
+__global__ __launch_bounds__(256) void write_kernel(float* __restrict__ obs0, float* __restrict__ acs,
+                                                    float* __restrict__ rews,
+                                                    float* __restrict__ dones1,
+                                                    float* __restrict__ obs1, int ob, int ac,
+                                                    const float* __restrict__ packed,
+                                                    const int64_t* __restrict__ rows, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int w = 2 * ob + ac + 2;
+    const float* p = packed + i * w;
+    const int64_t r = rows[i];
+    for (int c = lane; c < ob; c += 64) obs0[r * ob + c] = p[c];
+    for (int c = lane; c < ac; c += 64) acs[r * ac + c] = p[ob + c];
+    for (int c = lane; c < ob; c += 64) obs1[r * ob + c] = p[ob + ac + 1 + c];
+    if (lane == 0) {
+        rews[r] = p[ob + ac];
+        dones1[r] = p[2 * ob + ac + 1];
+    }
+}
+
+// Column sums of x and x^2 in float64.  Block = 16 row-lanes x 16 columns; every row-lane adds its
+// rows in increasing order, the 16 partials are then added in lane order: a fixed association, so
+// results are reproducible run to run (they differ from numpy's strictly sequential order only in
+// the last bits of a double).
+constexpr int kRmsRows = 16, kRmsCols = 16;
+__global__ __launch_bounds__(kRmsRows* kRmsCols) void rms_sums_kernel(
+    const float* __restrict__ x1, int64_t n1, const float* __restrict__ x2, int64_t n2, int dim,
+    double* __restrict__ addvec) {
+    __shared__ double s1[kRmsRows][kRmsCols], s2[kRmsRows][kRmsCols];
+    const int cx = threadIdx.x % kRmsCols, ry = threadIdx.x / kRmsCols;
+    const int col = blockIdx.x * kRmsCols + cx;
+    double a = 0.0, q = 0.0;
+    if (col < dim) {
+        const int64_t n = n1 + n2;
+        for (int64_t r = ry; r < n; r += kRmsRows) {
+            double v = (r < n1) ? (double)x1[r * dim + col] : (double)x2[(r - n1) * dim + col];
+            a = __dadd_rn(a, v);
+            q = __dadd_rn(q, __dmul_rn(v, v));
+        }
+    }
+    s1[ry][cx] = a;
+    s2[ry][cx] = q;
+    __syncthreads();
+    if (ry == 0 && col < dim) {
+        double ta = 0.0, tq = 0.0;
+        for (int r = 0; r < kRmsRows; ++r) {
+            ta = __dadd_rn(ta, s1[r][cx]);
+            tq = __dadd_rn(tq, s2[r][cx]);
+        }
+        addvec[col] = ta;
+        addvec[dim + col] = tq;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) addvec[2 * dim] = (double)(n1 + n2);
+}
+
+__global__ void rms_commit_kernel(double* __restrict__ sums, const double* __restrict__ addvec,
+                                  int dim, float* __restrict__ mean_out,
+                                  float* __restrict__ std_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const double cnt = sums[2 * dim] + (addvec ? addvec[2 * dim] : 0.0);
+    if (c < dim) {
+        double s = sums[c], q = sums[dim + c];
+        if (addvec) {
+            s = __dadd_rn(s, addvec[c]);
+            q = __dadd_rn(q, addvec[dim + c]);
+            sums[c] = s;
+            sums[dim + c] = q;
+        }
+        // mpi_running_mean_std.py:31-34: the casts to float32 come BEFORE the subtraction
+        const float mean = (float)(s / cnt);
+        const float msq = (float)(q / cnt);
+        const float var = __fsub_rn(msq, __fmul_rn(mean, mean));
+        mean_out[c] = mean;
+        std_out[c] = sqrtf(fmaxf(var, 1e-2f));
+    }
+    // the count is written by a thread that cannot race with readers of the old value: the grid is
+    // one block whenever dim <= blockDim, otherwise readers may see either count — so do it last
+    // from a separate tiny launch (see host wrapper)
+}
+
+__global__ void rms_count_kernel(double* sums, const double* addvec, int dim) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sums[2 * dim] = sums[2 * dim] + addvec[2 * dim];
+}
+
+}  // namespace
+
+extern "C" {
+
+int samx_replay_gather(const float* obs0, const float* acs, const float* rews, const float* dones1,
+                       const float* obs1, int64_t maxlen, int64_t start, int ob_dim, int ac_dim,
+                       const int64_t* idxs, int64_t B, float* o_obs0, float* o_acs, float* o_rews,
+                       float* o_dones1, float* o_obs1, void* stream) {
+    SAMX_REQUIRE(idxs, "samx_replay_gather: null idxs");
+    SAMX_REQUIRE(maxlen > 0 && ob_dim > 0 && ac_dim > 0 && B >= 0, "samx_replay_gather: bad sizes");
+    SAMX_REQUIRE((!o_obs0 || obs0) && (!o_acs || acs) && (!o_rews || rews) &&
+                     (!o_dones1 || dones1) && (!o_obs1 || obs1),
+                 "samx_replay_gather: an output was requested without its source array");
+    if (B == 0) return SAMX_OK;
+    gather_kernel<<<(unsigned)((B + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        obs0, acs, rews, dones1, obs1, maxlen, start, ob_dim, ac_dim, idxs, B, o_obs0, o_acs, o_rews,
+        o_dones1, o_obs1);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_replay_write(float* obs0, float* acs, float* rews, float* dones1, float* obs1, int ob_dim,
+                      int ac_dim, const float* packed, const int64_t* rows, int64_t n, void* stream) {
+    SAMX_REQUIRE(obs0 && acs && rews && dones1 && obs1 && packed && rows,
+                 "samx_replay_write: null pointer");
+    SAMX_REQUIRE(ob_dim > 0 && ac_dim > 0 && n >= 0, "samx_replay_write: bad sizes");
+    if (n == 0) return SAMX_OK;
+    write_kernel<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        obs0, acs, rews, dones1, obs1, ob_dim, ac_dim, packed, rows, n);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_rms_batch_sums(const float* x1, int64_t n1, const float* x2, int64_t n2, int dim,
+                        double* addvec, void* stream) {
+    SAMX_REQUIRE(addvec && dim > 0, "samx_rms_batch_sums: bad arguments");
+    SAMX_REQUIRE(n1 >= 0 && n2 >= 0 && (n1 == 0 || x1) && (n2 == 0 || x2),
+                 "samx_rms_batch_sums: row count without data");
+    rms_sums_kernel<<<samx::cdiv(dim, kRmsCols), kRmsRows * kRmsCols, 0, (hipStream_t)stream>>>(
+        x1, n1, x2, n2, dim, addvec);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_rms_commit(double* sums, const double* addvec, int dim, float* mean_out, float* std_out,
+                    void* stream) {
+    SAMX_REQUIRE(sums && mean_out && std_out && dim > 0, "samx_rms_commit: bad arguments");
+    rms_commit_kernel<<<samx::cdiv(dim, 256), 256, 0, (hipStream_t)stream>>>(sums, addvec, dim,
+                                                                            mean_out, std_out);
+    SAMX_LAUNCH_CHECK();
+    if (addvec) {
+        rms_count_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, addvec, dim);
+        SAMX_LAUNCH_CHECK();
+    }
+    return SAMX_OK;
+}
+
+}  // extern "C"

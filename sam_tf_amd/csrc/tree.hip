@@ -1,0 +1,287 @@
+// Segment-tree and prioritized-replay kernels (float64, bit-exact with the reference's Python).
+//   helpers/segment_tree.py:26-97 ; imitation_algorithms/memory.py:248-309,337-379
+// HBM/latency-bound pointer chasing over a 2*cap double array (16 MiB at cap 2^20); no MFMA here.
+#include "samx_common.h"
+#include "../../include/samx.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kTreeThreads = 1024;
+constexpr int kMaxLevels = 48;
+
+__device__ __forceinline__ double tree_op(int kind, double a, double b) {
+    // kind 0: operator.add ; kind 1: Python min(a, b) = b if b < a else a
+    if (kind == 0) return __dadd_rn(a, b);
+    return (b < a) ? b : a;
+}
+
+__global__ void tree_init_kernel(double* s, double* m, int32_t* stamp, int64_t cap) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < 2 * cap) {
+        s[i] = 0.0;
+        m[i] = INFINITY;
+    }
+    if (i < cap) stamp[i] = -1;
+}
+
+// One workgroup. Phase 1 elects, per distinct leaf, the LAST position in the batch (the reference
+// loop is sequential, so the last write survives); phase 2 writes the elected leaves; then every
+// level is recomputed bottom-up as value[2i] + value[2i+1] (or min), one barrier per level.
+// Threads that share an ancestor compute and store the same value, which is harmless.
+__global__ __launch_bounds__(kTreeThreads) void tree_set_kernel(double* __restrict__ s,
+                                                                double* __restrict__ m,
+                                                                int32_t* __restrict__ stamp,
+                                                                int64_t cap,
+                                                                const int64_t* __restrict__ idxs,
+                                                                const double* __restrict__ leaf,
+                                                                int n, int levels) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += kTreeThreads) {
+        int64_t idx = idxs[i];
+        if (idx >= 0 && idx < cap) atomicMax(&stamp[idx], i);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kTreeThreads) {
+        int64_t idx = idxs[i];
+        if (idx >= 0 && idx < cap) {
+            int32_t w = __hip_atomic_load(&stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == i) {
+                double v = leaf[i];
+                s[cap + idx] = v;
+                m[cap + idx] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kTreeThreads) {
+        int64_t idx = idxs[i];
+        if (idx >= 0 && idx < cap) stamp[idx] = -1;
+    }
+    for (int l = 1; l <= levels; ++l) {
+        __syncthreads();
+        for (int i = tid; i < n; i += kTreeThreads) {
+            int64_t idx = idxs[i];
+            if (idx < 0 || idx >= cap) continue;
+            int64_t node = (cap + idx) >> l;
+            s[node] = __dadd_rn(s[2 * node], s[2 * node + 1]);
+            double a = m[2 * node], b = m[2 * node + 1];
+            m[node] = (b < a) ? b : a;
+        }
+    }
+}
+
+// reduce over leaves [lo, hi] (inclusive) with the association order of the reference recursion
+// (segment_tree.py:26-39): descend to the split node, then the left part is a suffix query folded
+// left-nested and the right part a prefix query folded right-nested.
+__device__ double range_reduce(const double* __restrict__ v, int64_t cap, int kind, int64_t lo,
+                               int64_t hi) {
+    int64_t node = 1, nlo = 0, nhi = cap - 1;
+    while (true) {
+        if (lo == nlo && hi == nhi) return v[node];
+        int64_t mid = (nlo + nhi) / 2;
+        if (hi <= mid) {
+            node = 2 * node;
+            nhi = mid;
+        } else if (lo >= mid + 1) {
+            node = 2 * node + 1;
+            nlo = mid + 1;
+        } else {
+            break;
+        }
+    }
+    const int64_t mid0 = (nlo + nhi) / 2;
+    double terms[kMaxLevels];
+    // left child: suffix [lo, mid0]
+    double left;
+    {
+        int64_t nd = 2 * node, a = nlo, b = mid0;
+        int nt = 0;
+        while (lo != a) {
+            int64_t mid = (a + b) / 2;
+            if (lo >= mid + 1) {
+                nd = 2 * nd + 1;
+                a = mid + 1;
+            } else {
+                terms[nt++] = v[2 * nd + 1];
+                nd = 2 * nd;
+                b = mid;
+            }
+        }
+        double acc = v[nd];
+        for (int t = nt - 1; t >= 0; --t) acc = tree_op(kind, acc, terms[t]);
+        left = acc;
+    }
+    // right child: prefix [mid0+1, hi]
+    double right;
+    {
+        int64_t nd = 2 * node + 1, a = mid0 + 1, b = nhi;
+        int nt = 0;
+        while (hi != b) {
+            int64_t mid = (a + b) / 2;
+            if (hi <= mid) {
+                nd = 2 * nd;
+                b = mid;
+            } else {
+                terms[nt++] = v[2 * nd];
+                nd = 2 * nd + 1;
+                a = mid + 1;
+            }
+        }
+        double acc = v[nd];
+        for (int t = nt - 1; t >= 0; --t) acc = tree_op(kind, terms[t], acc);
+        right = acc;
+    }
+    return tree_op(kind, left, right);
+}
+
+__global__ void tree_reduce_kernel(const double* v, int64_t cap, int kind, int64_t lo, int64_t hi,
+                                   double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = range_reduce(v, cap, kind, lo, hi);
+}
+
+__device__ __forceinline__ int64_t prefix_descent(const double* __restrict__ v, int64_t cap,
+                                                  double s) {
+    int64_t node = 1;
+    while (node < cap) {
+        double left = v[2 * node];
+        if (left > s) {
+            node = 2 * node;
+        } else {
+            s = __dadd_rn(s, -left);
+            node = 2 * node + 1;
+        }
+    }
+    return node - cap;
+}
+
+__global__ void tree_find_kernel(const double* v, int64_t cap, const double* prefix, int64_t n,
+                                 int64_t* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = prefix_descent(v, cap, prefix[i]);
+}
+
+__global__ __launch_bounds__(256) void per_sample_kernel(
+    const double* __restrict__ sumv, const double* __restrict__ minv, int64_t cap, int64_t n_ent,
+    const double* __restrict__ u, int64_t B, double beta, int64_t* __restrict__ idxs,
+    double* __restrict__ iws, float* __restrict__ iws32) {
+    // every block recomputes the three scalar reductions (a few dozen L2 reads) instead of a
+    // second launch or a cross-block hand-off
+    __shared__ double sh[3];
+    if (threadIdx.x == 0) sh[0] = range_reduce(sumv, cap, 0, 0, n_ent - 2);  // memory.py:270
+    if (threadIdx.x == 64) sh[1] = range_reduce(sumv, cap, 0, 0, n_ent - 1);  // memory.py:299,306
+    if (threadIdx.x == 128) sh[2] = range_reduce(minv, cap, 1, 0, n_ent - 1);
+    __syncthreads();
+    const double p_total = sh[0], total = sh[1], lowest_p = sh[2];
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const double piece = p_total / (double)B;
+    const double s = __dadd_rn(__dmul_rn(u[i], piece), __dmul_rn((double)i, piece));
+    const int64_t idx = prefix_descent(sumv, cap, s);
+    idxs[i] = idx;
+    const double n = (double)n_ent;
+    const double lowest = lowest_p / total;
+    const double max_w = pow(__dmul_rn(n, lowest), -beta);
+    const double prob = sumv[cap + idx] / total;
+    const double w = pow(__dmul_rn(n, prob), -beta) / max_w;
+    iws[i] = w;
+    if (iws32) iws32[i] = (float)w;
+}
+
+int levels_of(int64_t cap) {
+    int l = 0;
+    while ((int64_t(1) << l) < cap) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int samx_tree_init(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap, void* stream) {
+    SAMX_REQUIRE(sum_tree && min_tree && stamp, "samx_tree_init: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_tree_init: cap %lld is not a power of two",
+                 (long long)cap);
+    int64_t n = 2 * cap;
+    tree_init_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sum_tree, min_tree,
+                                                                                  stamp, cap);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_tree_set(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                  const int64_t* idxs, const double* leaf, int64_t n, void* stream) {
+    SAMX_REQUIRE(sum_tree && min_tree && stamp && idxs && leaf, "samx_tree_set: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_tree_set: cap %lld is not a power of two",
+                 (long long)cap);
+    SAMX_REQUIRE(n >= 0 && n <= (1 << 24), "samx_tree_set: batch %lld out of range", (long long)n);
+    if (n == 0) return SAMX_OK;
+    tree_set_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(sum_tree, min_tree, stamp, cap, idxs,
+                                                                leaf, (int)n, levels_of(cap));
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_tree_reduce(const double* tree, int64_t cap, int kind, int64_t start, int64_t end,
+                     double* out, void* stream) {
+    SAMX_REQUIRE(tree && out, "samx_tree_reduce: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_tree_reduce: cap not a power of two");
+    SAMX_REQUIRE(kind == 0 || kind == 1, "samx_tree_reduce: kind must be 0 (sum) or 1 (min)");
+    if (end < 0) end += cap;  // segment_tree.py:50-51
+    int64_t hi = end - 1;     // segment_tree.py:52
+    SAMX_REQUIRE(start >= 0 && hi >= start && hi < cap,
+                 "samx_tree_reduce: empty or out-of-range query [%lld, %lld) on cap %lld",
+                 (long long)start, (long long)end, (long long)cap);
+    tree_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>(tree, cap, kind, start, hi, out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_tree_find_prefixsum(const double* sum_tree, int64_t cap, const double* prefix, int64_t n,
+                             int64_t* idx_out, void* stream) {
+    SAMX_REQUIRE(sum_tree && prefix && idx_out, "samx_tree_find_prefixsum: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_tree_find_prefixsum: bad cap");
+    if (n <= 0) return SAMX_OK;
+    tree_find_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sum_tree, cap,
+                                                                                  prefix, n, idx_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_per_sample(const double* sum_tree, const double* min_tree, int64_t cap,
+                    int64_t num_entries, const double* u, int64_t B, double beta,
+                    int64_t* idxs_out, double* iws_out, float* iws_f32_out, void* stream) {
+    SAMX_REQUIRE(sum_tree && min_tree && u && idxs_out && iws_out, "samx_per_sample: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_sample: bad cap");
+    // num_entries == 1 makes the reference issue the degenerate query reduce(0, -1)
+    // (memory.py:270 with segment_tree.py:52); refuse instead of emulating it.
+    SAMX_REQUIRE(num_entries >= 2 && num_entries <= cap,
+                 "samx_per_sample: num_entries %lld must be in [2, cap]", (long long)num_entries);
+    SAMX_REQUIRE(B > 0, "samx_per_sample: batch must be positive");
+    SAMX_REQUIRE(beta > 0, "samx_per_sample: beta must be positive");
+    per_sample_kernel<<<(unsigned)((B + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        sum_tree, min_tree, cap, num_entries, u, B, beta, idxs_out, iws_out, iws_f32_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host, int64_t n,
+                              double alpha, int64_t num_demos, double demos_eps,
+                              double* leaf_out_host, double* max_priority_host) {
+    SAMX_REQUIRE(prios_host && leaf_out_host && max_priority_host,
+                 "samx_per_leaf_values_host: null pointer");
+    SAMX_REQUIRE(num_demos == 0 || idxs_host, "samx_per_leaf_values_host: idxs needed with demos");
+    double mp = *max_priority_host;
+    for (int64_t i = 0; i < n; ++i) {
+        double p = prios_host[i];
+        SAMX_REQUIRE(p > 0, "samx_per_leaf_values_host: priority %lld is not positive",
+                     (long long)i);  // memory.py:371
+        if (num_demos > 0 && idxs_host[i] < num_demos) p += demos_eps;
+        leaf_out_host[i] = pow(p, alpha);
+        if (p > mp) mp = p;
+    }
+    *max_priority_host = mp;
+    return SAMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+"""Tensor-level wrappers over the libsamx C ABI (include/samx.h).
+
+Every function takes torch CUDA tensors (device memory owner = torch's allocator, stream = torch's
+current stream), checks shapes/dtypes on the host — a wrong shape must never reach a kernel — and
+enqueues the HIP work.  There is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MlpDesc, check, ptr, stream_ptr
+
+
+def _L():
+    return _lib.lib()
+
+
+def mlp_desc(in_dim, h1, h2, out_dim, layernorm=False):
+    return MlpDesc(int(in_dim), int(h1), int(h2), int(out_dim), int(bool(layernorm)))
+
+
+def param_count(d):
+    return int(_L().samx_mlp_param_count(C.byref(d)))
+
+
+def _chk(t, dtype, shape=None, name='tensor'):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError('%s must be a CUDA tensor' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError('%s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+def _opt(t, dtype, shape, name):
+    return None if t is None else _chk(t, dtype, shape, name)
+
+
+F32, F64, I64, I32 = torch.float32, torch.float64, torch.int64, torch.int32
+
+
+# ------------------------------------------------------------------ segment trees / PER
+
+class DeviceTrees(object):
+    """Sum + min tree pair in HBM (2*cap doubles each) plus the dedupe stamp array."""
+
+    def __init__(self, cap, device='cuda'):
+        assert cap > 0 and cap & (cap - 1) == 0
+        self.cap = cap
+        self.sum = torch.empty(2 * cap, dtype=F64, device=device)
+        self.min = torch.empty(2 * cap, dtype=F64, device=device)
+        self.stamp = torch.empty(cap, dtype=I32, device=device)
+        self._out = torch.empty(1, dtype=F64, device=device)
+        check(_L().samx_tree_init(ptr(self.sum), ptr(self.min), ptr(self.stamp), cap, stream_ptr()))
+
+    def set(self, idxs, leaf):
+        n = idxs.numel()
+        _chk(idxs, I64, (n,), 'idxs'); _chk(leaf, F64, (n,), 'leaf')
+        check(_L().samx_tree_set(ptr(self.sum), ptr(self.min), ptr(self.stamp), self.cap, ptr(idxs),
+                                 ptr(leaf), n, stream_ptr()))
+
+    def reduce(self, kind, start=0, end=None):
+        tree = self.sum if kind == 'sum' else self.min
+        check(_L().samx_tree_reduce(ptr(tree), self.cap, 0 if kind == 'sum' else 1, int(start),
+                                    self.cap if end is None else int(end), ptr(self._out),
+                                    stream_ptr()))
+        return float(self._out.item())
+
+    def find_prefixsum(self, prefix):
+        n = prefix.numel()
+        _chk(prefix, F64, (n,), 'prefix')
+        out = torch.empty(n, dtype=I64, device=prefix.device)
+        check(_L().samx_tree_find_prefixsum(ptr(self.sum), self.cap, ptr(prefix), n, ptr(out),
+                                            stream_ptr()))
+        return out
+
+    def per_sample(self, num_entries, u, beta, idxs_out=None, iws_out=None, iws32_out=None):
+        B = u.numel()
+        _chk(u, F64, (B,), 'u')
+        dev = u.device
+        idxs_out = torch.empty(B, dtype=I64, device=dev) if idxs_out is None else idxs_out
+        iws_out = torch.empty(B, dtype=F64, device=dev) if iws_out is None else iws_out
+        _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out')
+        _opt(iws32_out, F32, (B,), 'iws32_out')
+        check(_L().samx_per_sample(ptr(self.sum), ptr(self.min), self.cap, int(num_entries), ptr(u), B,
+                                   float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out),
+                                   stream_ptr()))
+        return idxs_out, iws_out
+
+
+def per_leaf_values_host(idxs, prios, alpha, num_demos, demos_eps, max_priority):
+    """numpy in, numpy out; host libm pow (see include/samx.h)."""
+    prios = np.ascontiguousarray(prios, dtype=np.float64)
+    idxs = np.ascontiguousarray(idxs, dtype=np.int64)
+    assert idxs.shape == prios.shape
+    leaf = np.empty_like(prios)
+    mp = C.c_double(float(max_priority))
+    check(_L().samx_per_leaf_values_host(ptr(idxs), ptr(prios), prios.size, float(alpha),
+                                         int(num_demos), float(demos_eps), ptr(leaf), C.byref(mp)))
+    return leaf, mp.value
+
+
+# ------------------------------------------------------------------ replay rows
+
+def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None):
+    """store: dict atom -> tensor [maxlen, dim] ; returns dict atom -> [B, dim]."""
+    B = idxs.numel()
+    _chk(idxs, I64, (B,), 'idxs')
+    maxlen, ob = store['obs0'].shape
+    ac = store['acs'].shape[1]
+    dims = dict(obs0=ob, acs=ac, rews=1, dones1=1, obs1=ob)
+    out = {} if out is None else out
+    for k in want:
+        if k not in out:
+            out[k] = torch.empty(B, dims[k], dtype=F32, device=idxs.device)
+        _chk(out[k], F32, (B, dims[k]), 'out[%s]' % k)
+    for k in dims:
+        _chk(store[k], F32, (maxlen, dims[k]), 'store[%s]' % k)
+    check(_L().samx_replay_gather(ptr(store['obs0']), ptr(store['acs']), ptr(store['rews']),
+                                  ptr(store['dones1']), ptr(store['obs1']), maxlen, int(start), ob, ac,
+                                  ptr(idxs), B, ptr(out.get('obs0')), ptr(out.get('acs')),
+                                  ptr(out.get('rews')), ptr(out.get('dones1')), ptr(out.get('obs1')),
+                                  stream_ptr()))
+    return out
+
+
+def replay_write(store, packed, rows):
+    n = rows.numel()
+    maxlen, ob = store['obs0'].shape
+    ac = store['acs'].shape[1]
+    _chk(rows, I64, (n,), 'rows'); _chk(packed, F32, (n, 2 * ob + ac + 2), 'packed')
+    check(_L().samx_replay_write(ptr(store['obs0']), ptr(store['acs']), ptr(store['rews']),
+                                 ptr(store['dones1']), ptr(store['obs1']), ob, ac, ptr(packed),
+                                 ptr(rows), n, stream_ptr()))
+
+
+# ------------------------------------------------------------------ running mean / std
+
+def rms_batch_sums(x1, x2, addvec):
+    dim = x1.shape[1]
+    _chk(x1, F32, (x1.shape[0], dim), 'x1')
+    if x2 is not None:
+        _chk(x2, F32, (x2.shape[0], dim), 'x2')
+    _chk(addvec, F64, (2 * dim + 1,), 'addvec')
+    check(_L().samx_rms_batch_sums(ptr(x1), x1.shape[0], ptr(x2), 0 if x2 is None else x2.shape[0],
+                                   dim, ptr(addvec), stream_ptr()))
+
+
+def rms_commit(sums, addvec, mean, std):
+    dim = mean.numel()
+    _chk(sums, F64, (2 * dim + 1,), 'sums'); _opt(addvec, F64, (2 * dim + 1,), 'addvec')
+    _chk(mean, F32, (dim,), 'mean'); _chk(std, F32, (dim,), 'std')
+    check(_L().samx_rms_commit(ptr(sums), ptr(addvec), dim, ptr(mean), ptr(std), stream_ptr()))
+
+
+# ------------------------------------------------------------------ optimiser
+
+def adam_partials(device='cuda'):
+    return torch.empty(_L().samx_adam_partials(), dtype=F32, device=device)
+
+
+def clip_adam(param, grad, m, v, lr, step, clip_norm, partials, grad_scale=1.0, targ=None, tau=0.0,
+              beta1=0.9, beta2=0.999, eps=1e-8):
+    n = param.numel()
+    for t, nm in ((param, 'param'), (grad, 'grad'), (m, 'm'), (v, 'v')):
+        _chk(t, F32, (n,), nm)
+    _opt(targ, F32, (n,), 'targ')
+    _chk(partials, F32, (_L().samx_adam_partials(),), 'partials')
+    check(_L().samx_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), n, float(lr), float(beta1),
+                              float(beta2), float(eps), int(step),
+                              float(clip_norm) if clip_norm else 0.0, float(grad_scale), ptr(targ),
+                              float(tau), ptr(partials), stream_ptr()))
+
+
+def polyak(targ, param, tau):
+    n = param.numel()
+    _chk(targ, F32, (n,), 'targ'); _chk(param, F32, (n,), 'param')
+    check(_L().samx_polyak(ptr(targ), ptr(param), n, float(tau), stream_ptr()))
+
+
+def clip_copy(grad, clip_norm, partials, out=None):
+    n = grad.numel()
+    _chk(grad, F32, (n,), 'grad')
+    out = torch.empty_like(grad) if out is None else _chk(out, F32, (n,), 'out')
+    check(_L().samx_clip_copy(ptr(grad), n, float(clip_norm) if clip_norm else 0.0, ptr(out),
+                              ptr(partials), stream_ptr()))
+    return out
+
+
+def count_mismatch(a, b, out=None):
+    n = a.numel()
+    _chk(a, F32, (n,), 'a'); _chk(b, F32, (n,), 'b')
+    out = torch.empty(1, dtype=I32, device=a.device) if out is None else out
+    check(_L().samx_count_mismatch(ptr(a), ptr(b), n, ptr(out), stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------ network passes
+
+def nets_ws(da, dc, dd, B, device='cuda'):
+    n = _L().samx_nets_ws_bytes(C.byref(da), C.byref(dc), C.byref(dd) if dd is not None else None,
+                                int(B))
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+def disc_ws(dd, B, device='cuda'):
+    return torch.empty(int(_L().samx_disc_ws_bytes(C.byref(dd), int(B))), dtype=torch.uint8,
+                       device=device)
+
+
+def _ms(mean, std, ob):
+    if mean is None:
+        assert std is None
+        return None, None
+    return _chk(mean, F32, (ob,), 'ob_mean'), _chk(std, F32, (ob,), 'ob_std')
+
+
+def _flat(p, d, name):
+    return _chk(p, F32, (param_count(d),), name)
+
+
+def act_q(da, pa, dc, pc, obs, mean, std, high, ws, ac_out=None, q_out=None, want_q=True):
+    B, ob = obs.shape
+    _chk(obs, F32, (B, da.in_dim), 'obs'); _flat(pa, da, 'actor params'); _flat(pc, dc, 'critic params')
+    mean, std = _ms(mean, std, ob)
+    ac_out = torch.empty(B, da.out_dim, dtype=F32, device=obs.device) if ac_out is None else ac_out
+    _chk(ac_out, F32, (B, da.out_dim), 'ac_out')
+    if want_q and q_out is None:
+        q_out = torch.empty(B, dtype=F32, device=obs.device)
+    _opt(q_out, F32, (B,), 'q_out')
+    check(_L().samx_act_q(C.byref(da), ptr(pa), C.byref(dc), ptr(pc), ptr(obs), ptr(mean), ptr(std), B,
+                          float(high), ptr(ac_out), ptr(q_out), ptr(ws), ws.numel(), stream_ptr()))
+    return ac_out, q_out
+
+
+def targ_q(da, pa_t, dc, pc_t, obs1, rews, dones1, td_len, mean, std, gamma, high, ws, out=None):
+    B, ob = obs1.shape
+    _chk(obs1, F32, (B, da.in_dim), 'obs1'); _flat(pa_t, da, 'targ actor'); _flat(pc_t, dc, 'targ critic')
+    rews = _chk(rews.reshape(B), F32, (B,), 'rews'); dones1 = _chk(dones1.reshape(B), F32, (B,), 'dones1')
+    td_len = None if td_len is None else _chk(td_len.reshape(B), F32, (B,), 'td_len')
+    mean, std = _ms(mean, std, ob)
+    out = torch.empty(B, dtype=F32, device=obs1.device) if out is None else _chk(out, F32, (B,), 'out')
+    check(_L().samx_targ_q(C.byref(da), ptr(pa_t), C.byref(dc), ptr(pc_t), ptr(obs1), ptr(rews),
+                           ptr(dones1), ptr(td_len), ptr(mean), ptr(std), B, float(gamma), float(high),
+                           ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    return out
+
+
+def critic_grad(dc, pc, obs0, acs, iws, tc1s, mean, std, td_scale, wd_scale, ws, losses=None,
+                grad=None, td=None):
+    B, ob = obs0.shape
+    ac = dc.in_dim - ob
+    _chk(obs0, F32, (B, ob), 'obs0'); _chk(acs, F32, (B, ac), 'acs'); _flat(pc, dc, 'critic params')
+    iws = None if iws is None else _chk(iws.reshape(B), F32, (B,), 'iws')
+    tc1s = _chk(tc1s.reshape(B), F32, (B,), 'tc1s')
+    mean, std = _ms(mean, std, ob)
+    dev = obs0.device
+    losses = torch.empty(3, dtype=F32, device=dev) if losses is None else _chk(losses, F32, (3,), 'losses')
+    grad = torch.empty(param_count(dc), dtype=F32, device=dev) if grad is None else _flat(grad, dc, 'grad')
+    td = torch.empty(B, dtype=F32, device=dev) if td is None else _chk(td, F32, (B,), 'td')
+    check(_L().samx_critic_grad(C.byref(dc), ptr(pc), ptr(obs0), ptr(acs), ptr(iws), ptr(tc1s), ptr(mean),
+                                ptr(std), B, ob, float(td_scale), float(wd_scale), ptr(losses), ptr(grad),
+                                ptr(td), ptr(ws), ws.numel(), stream_ptr()))
+    return losses, grad, td
+
+
+def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None):
+    B, ob = obs0.shape
+    ac = dc.in_dim - ob
+    _chk(obs0, F32, (B, ob), 'obs0'); _chk(acs, F32, (B, ac), 'acs'); _flat(pc, dc, 'critic params')
+    tc1s = _chk(tc1s.reshape(B), F32, (B,), 'tc1s')
+    mean, std = _ms(mean, std, ob)
+    out = torch.empty(B, dtype=F32, device=obs0.device) if out is None else _chk(out, F32, (B,), 'out')
+    check(_L().samx_td_errors(C.byref(dc), ptr(pc), ptr(obs0), ptr(acs), ptr(tc1s), ptr(mean), ptr(std),
+                              B, ob, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    return out
+
+
+def actor_grad(da, pa, dc, pc, dd, pd, obs0, mean, std, high, q_scale, d_scale, ws, losses=None,
+               grad=None):
+    B, ob = obs0.shape
+    _chk(obs0, F32, (B, da.in_dim), 'obs0'); _flat(pa, da, 'actor params'); _flat(pc, dc, 'critic params')
+    if pd is not None:
+        _flat(pd, dd, 'reward-net params')
+    mean, std = _ms(mean, std, ob)
+    dev = obs0.device
+    losses = torch.empty(3, dtype=F32, device=dev) if losses is None else _chk(losses, F32, (3,), 'losses')
+    grad = torch.empty(param_count(da), dtype=F32, device=dev) if grad is None else _flat(grad, da, 'grad')
+    check(_L().samx_actor_grad(C.byref(da), ptr(pa), C.byref(dc), ptr(pc),
+                               C.byref(dd) if dd is not None else None, ptr(pd), ptr(obs0), ptr(mean),
+                               ptr(std), B, float(high), float(q_scale), float(d_scale), ptr(losses),
+                               ptr(grad), ptr(ws), ws.numel(), stream_ptr()))
+    return losses, grad
+
+
+def disc_grad(dd, pd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real, fake, mean, std, ent_scale, ws,
+              losses=None, grad=None):
+    B, ob = p_obs.shape
+    ac = dd.in_dim - ob
+    for t, s, nm in ((p_obs, (B, ob), 'p_obs'), (e_obs, (B, ob), 'e_obs'), (eps_ob, (B, ob), 'eps_ob'),
+                     (p_acs, (B, ac), 'p_acs'), (e_acs, (B, ac), 'e_acs'), (eps_ac, (B, ac), 'eps_ac')):
+        _chk(t, F32, s, nm)
+    _flat(pd, dd, 'reward-net params')
+    real = None if real is None else _chk(real.reshape(B), F32, (B,), 'real_labels')
+    fake = None if fake is None else _chk(fake.reshape(B), F32, (B,), 'fake_labels')
+    mean, std = _ms(mean, std, ob)
+    dev = p_obs.device
+    losses = torch.empty(8, dtype=F32, device=dev) if losses is None else _chk(losses, F32, (8,), 'losses')
+    grad = torch.empty(param_count(dd), dtype=F32, device=dev) if grad is None else _flat(grad, dd, 'grad')
+    check(_L().samx_disc_grad(C.byref(dd), ptr(pd), ptr(p_obs), ptr(p_acs), ptr(e_obs), ptr(e_acs),
+                              ptr(eps_ob), ptr(eps_ac), ptr(real), ptr(fake), ptr(mean), ptr(std), B, ob,
+                              float(ent_scale), ptr(losses), ptr(grad), ptr(ws), ws.numel(),
+                              stream_ptr()))
+    return losses, grad
+
+
+def reward(dd, pd, obs, acs, mean, std, non_satur_grad, ws, out=None):
+    B, ob = obs.shape
+    ac = dd.in_dim - ob
+    _chk(obs, F32, (B, ob), 'obs'); _chk(acs, F32, (B, ac), 'acs'); _flat(pd, dd, 'reward-net params')
+    mean, std = _ms(mean, std, ob)
+    out = torch.empty(B, dtype=F32, device=obs.device) if out is None else _chk(out, F32, (B,), 'out')
+    check(_L().samx_reward(C.byref(dd), ptr(pd), ptr(obs), ptr(acs), ptr(mean), ptr(std), B, ob,
+                           int(bool(non_satur_grad)), ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    return out

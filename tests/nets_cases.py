@@ -1,0 +1,107 @@
+"""Shared seeded inputs for the network parity tests (CPU oracle side and GPU side)."""
+import numpy as np
+
+from oracle import nets_oracle as NO
+
+# BASELINE.json configs C1-C5: (ob, ac, h1, h2, B)
+CONFIGS = {
+    'C1': (4, 1, 64, 64, 32),
+    'C2': (11, 3, 64, 64, 256),
+    'C3': (17, 6, 64, 64, 256),
+    'C4': (376, 17, 256, 256, 1024),
+    'C5': (376, 17, 400, 300, 8192),
+    'ragged': (5, 2, 33, 70, 37),   # nothing a multiple of a tile
+}
+
+
+def relerr(a, b):
+    """max-norm relative error: max|a-b| / max|b| (the 1e-5 bar of north_star is on this)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+KINK_MARGIN = 1e-4
+
+
+def _row_margin(c):
+    """Smallest |pre-activation| per batch row over every pass the parity tests run (fp64)."""
+    import torch
+    P, D, da, dc, dd = c['P'], c['D'], c['da'], c['dc'], c['dd']
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    ob0 = NO.obz(t(D['obs0']), t(c['mean']), t(c['std'])).numpy()
+    obe = NO.obz(t(D['e_obs']), t(c['mean']), t(c['std'])).numpy()
+    xp = np.concatenate([ob0, D['acs']], axis=1)
+    xe = np.concatenate([obe, D['e_acs']], axis=1)
+    eps = np.concatenate([D['eps_ob'], D['eps_ac']], axis=1).astype(np.float64)
+    xi = eps * xp + (1 - eps) * xe
+    Pa = NO.unflatten(t(P['pa']), da)
+    a = NO.actor_act(Pa, t(ob0), da, 0.4).numpy()
+    xa = np.concatenate([ob0, a], axis=1)
+    m = NO.min_abs_preact(P['pa'], da, ob0)
+    for flat, d, x in ((P['pc'], dc, xp), (P['pc'], dc, xa), (P['pd'], dd, xa), (P['pd'], dd, xp),
+                       (P['pd'], dd, xe), (P['pd'], dd, xi)):
+        m = np.minimum(m, NO.min_abs_preact(flat, d, x))
+    return m
+
+
+def keep_off_the_kink(c, rs, margin=KINK_MARGIN, max_iter=60):
+    """Redraw the rows that put some leaky-ReLU pre-activation within `margin` of 0 (see
+    nets_oracle.min_abs_preact): there the gradient depends on the last bit of an fp32 sum, and even
+    torch's own fp32 result differs from the fp64 one by ~1e-4 of the gradient's max."""
+    D, ob, ac = c['D'], c['ob'], c['ac']
+    for _ in range(max_iter):
+        bad = np.where(_row_margin(c) < margin)[0]
+        if bad.size == 0:
+            return c
+        n = bad.size
+        D['obs0'][bad] = (rs.randn(n, ob) * 1.5 + 0.3).astype(np.float32)
+        D['acs'][bad] = rs.uniform(-1, 1, (n, ac)).astype(np.float32)
+        D['e_obs'][bad] = (rs.randn(n, ob) + 0.5).astype(np.float32)
+        D['e_acs'][bad] = rs.uniform(-1, 1, (n, ac)).astype(np.float32)
+        D['eps_ob'][bad] = rs.rand(n, ob).astype(np.float32)
+        D['eps_ac'][bad] = rs.rand(n, ac).astype(np.float32)
+    raise RuntimeError('could not move every row off the kink')
+
+
+def make_case(name, ln=False, seed=0, off_kink=True):
+    ob, ac, h1, h2, B = CONFIGS[name]
+    rs = np.random.RandomState(seed + 17 * len(name))
+    da = NO.MLP(ob, h1, h2, ac, ln)
+    dc = NO.MLP(ob + ac, h1, h2, 1, ln)
+    dd = NO.MLP(ob + ac, h1, h2, 1, ln)
+
+    def perturb(p, s):
+        return (p + rs.randn(p.size).astype(np.float32) * s).astype(np.float32)
+    P = dict(
+        pa=perturb(NO.init_params(da, rs, 'actor'), 0.01),
+        pa_t=perturb(NO.init_params(da, rs, 'actor'), 0.01),
+        # trained-looking critic / reward nets (the U(+-3e-3) init would make every test trivial)
+        pc=perturb(NO.init_params(dc, rs, 'reward'), 0.02),
+        pc_t=perturb(NO.init_params(dc, rs, 'reward'), 0.02),
+        pd=perturb(NO.init_params(dd, rs, 'reward'), 0.02),
+    )
+    for k in ('pc', 'pc_t', 'pd'):
+        sl = NO.param_slices(dc)
+        o, s = sl['W3']
+        P[k][o:o + h2] = rs.randn(h2).astype(np.float32) * (1.0 / np.sqrt(h2))
+    D = dict(
+        obs0=(rs.randn(B, ob) * 1.5 + 0.3).astype(np.float32),
+        obs1=(rs.randn(B, ob) * 1.5 + 0.3).astype(np.float32),
+        acs=rs.uniform(-1, 1, (B, ac)).astype(np.float32),
+        rews=rs.uniform(0, 5, (B,)).astype(np.float32),
+        dones1=(rs.rand(B) < 0.1).astype(np.float32),
+        iws=rs.uniform(0.05, 1.0, (B,)).astype(np.float32),
+        e_obs=(rs.randn(B, ob) + 0.5).astype(np.float32),
+        e_acs=rs.uniform(-1, 1, (B, ac)).astype(np.float32),
+        eps_ob=rs.rand(B, ob).astype(np.float32),
+        eps_ac=rs.rand(B, ac).astype(np.float32),
+        td_len=rs.randint(1, 5, size=B).astype(np.float32),
+    )
+    real, fake = NO.smooth_labels(rs.rand(B), rs.rand(B))
+    D['real'], D['fake'] = real.astype(np.float32), fake.astype(np.float32)
+    sums = NO.rms_update(NO.rms_init(ob), rs.randn(4000, ob) * 1.3 + 0.2, ob)
+    mean, std = NO.rms_mean_std(sums, ob)
+    c = dict(da=da, dc=dc, dd=dd, P=P, D=D, mean=mean, std=std, B=B, ob=ob, ac=ac)
+    return keep_off_the_kink(c, rs) if off_kink else c

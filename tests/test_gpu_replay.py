@@ -1,0 +1,149 @@
+"""HIP replay / segment-tree kernels vs the golden vectors recorded from the reference and vs the
+C oracle at full capacity.  Bit-exact for indices, tree nodes and sums (tolerance: none); IS
+weights use the device pow and are held to 1e-13 relative (include/samx.h, samx_per_sample)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests import replay_cases as RC
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_trees(cap):
+    from sam_tf_amd import ops
+    t = ops.DeviceTrees(cap)
+
+    def t_set(i, v):
+        t.set(torch.tensor([i], dtype=torch.int64, device='cuda'),
+              torch.tensor([v], dtype=torch.float64, device='cuda'))
+
+    def prefix(s):
+        return int(t.find_prefixsum(torch.tensor([s], dtype=torch.float64, device='cuda')).item())
+    return (t_set, lambda a, b: t.reduce('sum', a, b), lambda a, b: t.reduce('min', a, b), prefix,
+            lambda kind: (t.sum if kind == 'sum' else t.min).cpu().numpy())
+
+
+@pytest.mark.parametrize('name', ['replay_tree_cap16', 'replay_tree_cap1024'])
+def test_tree_golden(golden_dir, name):
+    RC.run_tree_fixture(np.load(os.path.join(golden_dir, name + '.npz')), _dev_trees)
+
+
+def test_tree_known_answers():
+    """The reference's own unit tests (segment_tree_test.py:6-95) through the C ABI."""
+    from sam_tf_amd import ops
+    t = ops.DeviceTrees(4)
+    dev = 'cuda'
+
+    def put(i, v):
+        t.set(torch.tensor([i], device=dev), torch.tensor([v], dtype=torch.float64, device=dev))
+    put(2, 1.0); put(3, 3.0)
+    assert t.reduce('sum') == 4.0 and t.reduce('sum', 0, 2) == 0.0 and t.reduce('sum', 0, 3) == 1.0
+    assert t.reduce('sum', 2, 3) == 1.0 and t.reduce('sum', 2, -1) == 1.0 and t.reduce('sum', 2, 4) == 4.0
+    pre = torch.tensor([0.0, 0.5, 0.99, 1.01, 3.0, 4.0], dtype=torch.float64, device=dev)
+    assert t.find_prefixsum(pre).tolist() == [2, 2, 2, 3, 3, 3]
+    m = ops.DeviceTrees(4)
+
+    def putm(i, v):
+        m.set(torch.tensor([i], device=dev), torch.tensor([v], dtype=torch.float64, device=dev))
+    putm(0, 1.0); putm(2, 0.5); putm(3, 3.0)
+    assert m.reduce('min') == 0.5 and m.reduce('min', 0, 2) == 1.0 and m.reduce('min', 3, 4) == 3.0
+    putm(2, 4.0)
+    assert m.reduce('min') == 1.0 and m.reduce('min', 2, 4) == 3.0 and m.reduce('min', 2, -1) == 4.0
+
+
+@pytest.mark.parametrize('name', ['replay_per_a', 'replay_per_b', 'replay_per_demos'])
+def test_per_golden(golden_dir, name):
+    from sam_tf_amd.memory import PrioritizedRB
+    fx = np.load(os.path.join(golden_dir, name + '.npz'))
+    rb = RC.run_per_fixture(
+        fx, lambda limit, ob, ac, alpha, beta: PrioritizedRB(limit, (ob,), (ac,), alpha, beta),
+        iws_exact=False)
+    assert np.array_equal(rb.store['obs0'].cpu().numpy(), fx['final_obs0'])
+    assert np.array_equal(rb.store['rews'].cpu().numpy().ravel(), fx['final_rews'].ravel())
+    assert rb.start == int(fx['final_start']) and rb.length == int(fx['final_length'])
+
+
+@pytest.mark.parametrize('name', ['replay_rb', 'replay_rb_partial'])
+def test_rb_golden(golden_dir, name):
+    from sam_tf_amd.memory import RB
+    RC.run_rb_fixture(np.load(os.path.join(golden_dir, name + '.npz')),
+                      lambda limit, ob, ac: RB(limit, (ob,), (ac,)))
+
+
+@pytest.mark.parametrize('cap_log2,B', [(20, 256), (22, 8192), (10, 1)])
+def test_per_full_capacity_vs_c_oracle(cap_log2, B):
+    """BASELINE configs C3 (1M, B=256) and C5 (4M, B=8192): sample -> update rounds, every index,
+    every tree node bit-equal to oracle/per_tree.c.  Duplicates inside one update batch occur
+    (stratified sampling of a skewed tree) and must resolve last-writer-wins."""
+    from oracle.per_tree_c import PerTreesC
+    from sam_tf_amd import ops
+    cap = 1 << cap_log2
+    n = cap - 7 if cap_log2 > 10 else 600
+    rs = np.random.RandomState(cap_log2)
+    ct = PerTreesC(cap)
+    ct.fill_range(0, n, 1.0 ** 0.3)
+    dt = ops.DeviceTrees(cap)
+    dt.set(torch.arange(n, device='cuda'), torch.full((n,), 1.0 ** 0.3, dtype=torch.float64, device='cuda'))
+    max_c = max_d = 1.0
+    for r in range(4):
+        u = rs.rand(B)
+        ic, wc = ct.per_sample(n, u, 1.0)
+        idd, wd = dt.per_sample(n, torch.as_tensor(u).cuda(), 1.0)
+        assert np.array_equal(ic, idd.cpu().numpy()), 'round %d idxs' % r
+        np.testing.assert_allclose(wd.cpu().numpy(), wc, rtol=1e-13)
+        # heavy-tailed priorities make later rounds revisit the same leaves -> duplicates
+        pr = np.abs(rs.standard_cauchy(B)) + 1e-6
+        if B > 1:
+            ic[B // 2] = ic[0]  # force one duplicate pair with different priorities
+            idd = torch.as_tensor(ic).cuda()
+        max_c = ct.per_update(ic, pr, 0.3, max_priority=max_c)
+        leaf, max_d = ops.per_leaf_values_host(ic, pr, 0.3, 0, 0.1, max_d)
+        dt.set(idd, torch.as_tensor(leaf).cuda())
+        assert max_c == max_d
+        assert dt.reduce('sum', 0, n) == ct.sum(0, n)
+        assert dt.reduce('sum', 0, n - 1) == ct.sum(0, n - 1)
+        assert dt.reduce('min', 0, n) == ct.min(0, n)
+        assert dt.reduce('sum', 12345 % n, n - 3) == ct.sum(12345 % n, n - 3)
+    assert np.array_equal(dt.sum.cpu().numpy(), ct.sumv)
+    assert np.array_equal(dt.min.cpu().numpy(), ct.minv)
+    assert int((dt.stamp != -1).sum().item()) == 0
+
+
+def test_per_rejects_degenerate_sizes():
+    from sam_tf_amd import ops, _lib
+    dt = ops.DeviceTrees(8)
+    u = torch.rand(4, dtype=torch.float64, device='cuda')
+    with pytest.raises(_lib.SamxError):
+        dt.per_sample(1, u, 1.0)  # num_entries == 1: reference issues reduce(0, -1)
+    with pytest.raises(_lib.SamxError):
+        dt.reduce('sum', 3, 3)  # empty range
+
+
+def test_gather_roundtrip_and_rms():
+    """gather == indexing; running sums == float64 numpy column sums; mean/std formula of
+    mpi_running_mean_std.py:31-34 (tolerance 1e-6 relative on the float32 outputs)."""
+    from sam_tf_amd import ops
+    from oracle import nets_oracle as NO
+    rs = np.random.RandomState(3)
+    O = 376
+    x1 = rs.randn(1024, O).astype(np.float32) * 3 + 1
+    x2 = rs.randn(1000, O).astype(np.float32)
+    add = torch.empty(2 * O + 1, dtype=torch.float64, device='cuda')
+    ops.rms_batch_sums(torch.as_tensor(x1).cuda(), torch.as_tensor(x2).cuda(), add)
+    sums0 = NO.rms_init(O)
+    exp = NO.rms_update(sums0, np.concatenate([x1, x2]), O)
+    np.testing.assert_allclose(add.cpu().numpy(), exp - sums0, rtol=1e-12)
+    sums = torch.as_tensor(sums0).cuda()
+    mean = torch.empty(O, device='cuda'); std = torch.empty(O, device='cuda')
+    ops.rms_commit(sums, add, mean, std)
+    np.testing.assert_allclose(sums.cpu().numpy(), exp, rtol=1e-12)
+    em, es = NO.rms_mean_std(exp, O)
+    np.testing.assert_allclose(mean.cpu().numpy(), em, rtol=1e-6)
+    np.testing.assert_allclose(std.cpu().numpy(), es, rtol=1e-6)
+    # second commit with nothing to add only re-derives mean/std
+    ops.rms_commit(sums, None, mean, std)
+    np.testing.assert_allclose(mean.cpu().numpy(), em, rtol=1e-6)
