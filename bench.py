@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""SAM update steps/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2] [--no-graph] [--no-cpu]
+
+One "step" = 1 discriminator update + 1 actor/critic update (+ PER refresh) + Polyak target update on
+one replayed minibatch (sam_tf_amd/driver.py; reference loop body sam.py:323-433 with
+d_steps = g_steps = 1).  Inputs (replay storage, expert pool, weights, optimiser state) are resident
+in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), each rank its
+own replay shard and minibatch (weak scaling), gradients and running-mean sums all-reduced.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     — the dominant device pass of the step, timed with HIP events on the launch stream
+  cpu_baseline — the CPU restatement of the reference (oracle/, reference call structure, 1 thread)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# (ob, ac, h1, h2, batch, prioritized, mem_size)
+CONFIGS = {
+    'C1': dict(ob=4, ac=1, h=(64, 64), B=32, per=False, mem=100000, name='InvertedPendulum-shaped'),
+    'C2': dict(ob=11, ac=3, h=(64, 64), B=256, per=False, mem=1000000, name='Hopper-shaped'),
+    'C3': dict(ob=17, ac=6, h=(64, 64), B=256, per=True, mem=1000000, name='HalfCheetah-shaped'),
+    'C4': dict(ob=376, ac=17, h=(256, 256), B=1024, per=False, mem=1000000, name='Humanoid-shaped'),
+    'C5': dict(ob=376, ac=17, h=(400, 300), B=8192, per=True, mem=4000000, name='Humanoid-stress'),
+}
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA (exact f32) peak
+PEAK_HBM_GBS = 8000.0
+
+
+def weight_elems(ob, ac, h):
+    wa = ob * h[0] + h[0] * h[1] + h[1] * ac
+    wc = (ob + ac) * h[0] + h[0] * h[1] + h[1]
+    return wa, wc, wc
+
+
+def flops_per_step(cfg):
+    """F = B*(8 Wa + 12 Wc [+2 Wc if PER] + 22 Wd)."""
+    wa, wc, wd = weight_elems(cfg['ob'], cfg['ac'], cfg['h'])
+    return cfg['B'] * (8 * wa + (14 if cfg['per'] else 12) * wc + 22 * wd)
+
+
+def role_flops(cfg):
+    wa, wc, wd = weight_elems(cfg['ob'], cfg['ac'], cfg['h'])
+    B = cfg['B']
+    return {'disc_grad': 22 * wd * B, 'targ_q': 2 * (wa + wc) * B, 'actor_grad': (6 * wa + 4 * wc) * B,
+            'critic_grad': 6 * wc * B}
+
+
+def build_learner(cfg, comm, device, seed, use_graph):
+    from sam_tf_amd.hps import make_hps, SyntheticEnv
+    from sam_tf_amd.discriminator import Discriminator
+    from sam_tf_amd.agent import SAMAgent
+    from sam_tf_amd.demo_pool import DevicePairPool
+    from sam_tf_amd.driver import UpdateStepDriver
+    rank = comm.Get_rank()
+    env = SyntheticEnv(cfg['ob'], cfg['ac'], 1.0)
+    hps = make_hps(hid_widths=cfg['h'], batch_size=cfg['B'], mem_size=cfg['mem'],
+                   prioritized_replay=cfg['per'], seed=seed)
+    d = Discriminator('d', env, hps, comm, device=device)
+    mu = SAMAgent('mu', comm, env, hps, d, device=device)
+    # synthetic transitions: obs ~ N(0,1), acs ~ U(-1,1), rews ~ U(0,5),
+    # dones ~ Bernoulli(1/1000); each rank its own shard (run_sam.py:30-34 seeds by rank)
+    g = torch.Generator(device=device); g.manual_seed(1234 + rank)
+    n = min(cfg['mem'], 1 << 20)
+    r = lambda *s: torch.randn(*s, generator=g, device=device)
+    u = lambda *s: torch.rand(*s, generator=g, device=device)
+    obs0, obs1 = r(n, cfg['ob']), r(n, cfg['ob'])
+    mu.replay_buffer.extend_device(obs0, u(n, cfg['ac']) * 2 - 1, u(n) * 5, obs1,
+                                   (u(n) < 1e-3).float())
+    if hps.rmsify_obs:  # what store_transition would have accumulated (sam_agent.py:627-629)
+        mu.obs_rms.update_device(obs0, None, comm)
+    del obs0, obs1
+    rs = np.random.RandomState(4321 + rank)
+    np.random.seed(seed + 1000003 * rank)
+    import random
+    random.seed(seed + 1000003 * rank)
+    pool = DevicePairPool(rs.randn(32000, cfg['ob']) + 0.5, rs.uniform(-1, 1, (32000, cfg['ac'])),
+                          device=device)
+    mu.initialize_target_nets()
+    mu.sync_from_root()
+    d.sync_from_root()
+    if cfg['per']:  # warm the priorities (200 rounds of |N(0,1)| + 1e-6)
+        rb = mu.replay_buffer
+        for _ in range(200):
+            idx = rs.randint(0, rb.num_entries, size=cfg['B'])
+            rb.update_priorities(idx, np.abs(rs.randn(cfg['B'])) + 1e-6)
+    drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph)
+    return mu, d, pool, drv
+
+
+def time_roles(drv, cfg, iters=20):
+    """Average device time of each network pass of the step, HIP events on the launch stream."""
+    from sam_tf_amd import ops
+    mu, d = drv.mu, drv.d
+    st = torch.cuda.current_stream()
+    batch = dict(drv.ab); batch['iws32'] = drv.iws32
+    mean, std = mu._mean_std()
+    hp = mu.hps
+
+    def disc():
+        d.grads_device(drv.pb['obs0'], drv.pb['acs'], drv.eb['obs0'], drv.eb['acs'],
+                       randoms=(drv.eps_ob, drv.eps_ac, drv.real, None))
+
+    def targ():
+        ops.targ_q(mu.da, mu.targ_actor.flat, mu.dc, mu.targ_critic.flat, batch['obs1'], batch['rews'],
+                   batch['dones1'], None, mean, std, hp.gamma, mu.ac_high, mu.ws, out=mu.targ_q)
+
+    def actor():
+        ops.actor_grad(mu.da, mu.actor.flat, mu.dc, mu.critic.flat, mu.d_desc, mu.d_params,
+                       batch['obs0'], mean, std, mu.ac_high, hp.q_actor_loss_scale,
+                       hp.d_actor_loss_scale, mu.ws, losses=mu.actor_losses, grad=mu.actor_grad)
+
+    def critic():
+        ops.critic_grad(mu.dc, mu.critic.flat, batch['obs0'], batch['acs'],
+                        batch['iws32'] if hp.prioritized_replay else None, mu.targ_q, mean, std,
+                        hp.td_loss_1_scale, hp.wd_scale, mu.ws, losses=mu.critic_losses,
+                        grad=mu.critic_grad, td=mu.td)
+    out = {}
+    for name, fn in (('disc_grad', disc), ('targ_q', targ), ('actor_grad', actor),
+                     ('critic_grad', critic)):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters * 1e-3  # seconds
+    return out
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    from oracle.cpu_step import CpuReferenceStep
+    torch.set_num_threads(1)
+    ref = CpuReferenceStep(cfg['ob'], cfg['ac'], cfg['h'], cfg['B'], per=cfg['per'],
+                           mem=min(cfg['mem'], 1 << 17))
+    ref.step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref.step(); n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 2000:
+            break
+    return {'value': n / el, 'unit': 'steps/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d update steps of the same workload (CPU restatement of the reference in its '
+                      'own call structure: 3 D passes + 8 agent passes per step, fp32 torch, 1 thread, '
+                      'Python replay loops), %.1f s' % (n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--config', default='C2', choices=sorted(CONFIGS))
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the update step has no CPU path')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node N for --gpus N'
+
+    from sam_tf_amd.comm import TorchComm
+    comm = TorchComm(device)
+    cfg = CONFIGS[args.config]
+    mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
+    drv.prepare()
+    for _ in range(args.warmup):
+        drv.step()
+    comm.Barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step()
+    torch.cuda.synchronize(); comm.Barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    finite = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
+
+    roles = time_roles(drv, cfg)
+    rf = role_flops(cfg)
+    dom = max(roles, key=lambda k: roles[k])
+    achieved = rf[dom] / roles[dom] / 1e12
+    result = {
+        'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'],
+        'value': world * args.steps / el, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s %s: obs %d, act %d, %dx%d MLPs, batch %d per GPU, %s replay (%d rows '
+                               'resident), D gradient penalty, rmsify_obs' %
+                               (args.config, cfg['name'], cfg['ob'], cfg['ac'], cfg['h'][0], cfg['h'][1],
+                                cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
+                                mu.replay_buffer.num_entries),
+                   'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
+                   'finite_params': finite},
+        'roofline': {'bound': 'mfma', 'kernel': dom + ' (layer-wise MFMA f32 pass)',
+                     'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
+                     'pass_us': {k: v * 1e6 for k, v in roles.items()},
+                     'step_flops': flops_per_step(cfg)},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            result['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

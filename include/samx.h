@@ -117,11 +117,15 @@ int samx_rms_commit(double* sums, const double* addvec, int dim, float* mean_out
  * mean of line 27), then clip_by_global_norm (lines 31-33; clip_norm <= 0 disables), then TF1 Adam
  * with epsilon outside the square root; `step` is the 1-based update count.  If targ != NULL the
  * Polyak update of sam_agent.py:31-34 (targ = (1-tau) targ + tau param) is applied to the fresh
- * parameters in the same pass.  partials: float[samx_adam_partials()] scratch. */
+ * parameters in the same pass.  partials: float[samx_adam_partials()] scratch.
+ * step_dev (may be NULL): an int64 update counter in device memory.  When given, the library
+ * increments it and derives the bias correction from it on the device, and `step` is ignored — a
+ * captured HIP graph can then be replayed without a per-step host argument. */
 int samx_adam_partials(void);
 int samx_clip_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
                    float beta1, float beta2, float eps, int64_t step, float clip_norm,
-                   float grad_scale, float* targ, float tau, float* partials, void* stream);
+                   float grad_scale, float* targ, float tau, float* partials, int64_t* step_dev,
+                   void* stream);
 
 /* get_target_updates (sam_agent.py:20-37): tau = 1 is the hard copy. */
 int samx_polyak(float* targ, const float* param, int64_t n, float tau, void* stream);

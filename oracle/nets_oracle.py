@@ -201,7 +201,7 @@ def clip_by_global_norm(g, clip_norm):
 
 
 def critic_loss_grad(pc, dc, obs0, acs, iws, tc1s, mean, std, wd_scale, td_scale=1.0,
-                     dtype=torch.float64, rmsify=True):
+                     dtype=torch.float64, rmsify=True, need_grad=True):
     """sam_agent.py:457-520.  iws None <=> uniform replay.  Returns losses
     [td_loss_1, wd, total], flat grad (unclipped), td_errors [B,1]."""
     f, Pc = _params(pc, dc, dtype, grad=True)
@@ -214,9 +214,8 @@ def critic_loss_grad(pc, dc, obs0, acs, iws, tc1s, mean, std, wd_scale, td_scale
     td_loss = h.mean() * td_scale
     wd = wd_scale * 0.5 * ((Pc['W1'] ** 2).sum() + (Pc['W2'] ** 2).sum())
     loss = td_loss + wd
-    g, = torch.autograd.grad(loss, f)
-    return (np.array([td_loss.item(), wd.item(), loss.item()]), g.numpy(),
-            td.detach().numpy())
+    g = torch.autograd.grad(loss, f)[0].numpy() if need_grad else None
+    return (np.array([td_loss.item(), wd.item(), loss.item()]), g, td.detach().numpy())
 
 
 def td_errors(pc, dc, obs0, acs, tc1s, mean, std, dtype=torch.float64, rmsify=True):
@@ -226,7 +225,7 @@ def td_errors(pc, dc, obs0, acs, tc1s, mean, std, dtype=torch.float64, rmsify=Tr
 
 
 def actor_loss_grad(pa, da, pc, dc, pd, dd, obs0, mean, std, high, q_scale, d_scale,
-                    dtype=torch.float64, rmsify=True):
+                    dtype=torch.float64, rmsify=True, need_grad=True):
     """sam_agent.py:406-433.  pd/dd: the reward net the agent graph evaluates (may be None when
     d_scale == 0).  Returns losses [q_loss, d_loss, total], flat grad wrt actor (unclipped)."""
     f, Pa = _params(pa, da, dtype, grad=True)
@@ -240,8 +239,8 @@ def actor_loss_grad(pa, da, pc, dc, pd, dd, obs0, mean, std, high, q_scale, d_sc
     else:
         d_loss = torch.zeros((), dtype=dtype)
     loss = q_loss + d_loss
-    g, = torch.autograd.grad(loss, f)
-    return np.array([q_loss.item(), d_loss.item(), loss.item()]), g.numpy()
+    g = torch.autograd.grad(loss, f)[0].numpy() if need_grad else None
+    return np.array([q_loss.item(), d_loss.item(), loss.item()]), g
 
 
 def act_q(pa, da, pc, dc, obs, mean, std, high, dtype=torch.float64, rmsify=True):
@@ -262,7 +261,7 @@ D_LOSS_NAMES = ['d_policy_loss', 'd_expert_loss', 'd_ent_mean', 'd_ent_loss', 'd
 
 
 def disc_loss_grad(pd, dd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real_labels, fake_labels,
-                   mean, std, ent_reg_scale=0.0, dtype=torch.float64, rmsify=True):
+                   mean, std, ent_reg_scale=0.0, dtype=torch.float64, rmsify=True, need_grad=True):
     """discriminator.py:77-161 with the TF-random tensors (GP eps, smoothed labels) injected.
     Returns the 8 losses in the reference's order and the flat grad (unclipped)."""
     f, Pd = _params(pd, dd, dtype, grad=True)
@@ -281,14 +280,14 @@ def disc_loss_grad(pd, dd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real_labe
     oi = (eo * pz + (1.0 - eo) * ez).detach().requires_grad_(True)
     ai = (ea * pa_ + (1.0 - ea) * ea_).detach().requires_grad_(True)
     si = critic_q(Pd, oi, ai, dd)
-    go, ga = torch.autograd.grad(si.sum(), [oi, ai], create_graph=True)
+    go, ga = torch.autograd.grad(si.sum(), [oi, ai], create_graph=need_grad)
     gnorm = torch.sqrt((go ** 2).mean() + (ga ** 2).mean())
     gp = (gnorm - 1.0) ** 2
     loss = p_loss + e_loss + ent_loss + GP_COEFF * gp
-    g, = torch.autograd.grad(loss, f)
+    g = torch.autograd.grad(loss, f)[0].numpy() if need_grad else None
     losses = np.array([x.item() for x in
                        (p_loss, e_loss, ent_mean, ent_loss, p_acc, e_acc, gp, loss)])
-    return losses, g.numpy()
+    return losses, g
 
 
 def reward(pd, dd, obs, acs, mean, std, non_satur_grad=False, dtype=torch.float64, rmsify=True):

@@ -42,7 +42,7 @@ SIGNATURES = {
     'samx_rms_commit': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     'samx_adam_partials': (C.c_int, []),
     'samx_clip_adam': (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _F, _P, _F, _P,
-                                 _P]),
+                                 _P, _P]),
     'samx_polyak': (C.c_int, [_P, _P, _I64, _F, _P]),
     'samx_clip_copy': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
     'samx_count_mismatch': (C.c_int, [_P, _P, _I64, _P, _P]),
@@ -71,6 +71,10 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise SamxError('libsamx.so not found at %s: build it with `python -m sam_tf_amd.build` '
                             '(there is no CPU fallback)' % SO_PATH)
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be resident BEFORE
+        # libsamx.so is opened so that both bind to the same runtime instance: streams and device
+        # pointers are only meaningful inside the runtime that created them.
+        import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so is stale

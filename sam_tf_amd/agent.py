@@ -1,0 +1,261 @@
+"""SAMAgent with the reference's surface (imitation_algorithms/sam_agent.py:61-749) on libsamx.
+
+State in HBM (float32 unless noted):
+  params  = [actor | critic]            one flat vector -> ONE all-reduce bucket per update
+  targets = [targ_actor | targ_critic]  same layout, Polyak-tracked in one launch
+  grads, Adam m/v with the same layout; obs running sums (float64); replay storage (memory.py)
+`train()` keeps the reference's return value (numpy, sam_agent.py:706-711); `train_device()` is the
+same update with everything left on the GPU.
+
+Not built (SURVEY.md §8f "next"): return normalisation/PopArt, n-step returns, parameter noise.
+"""
+import numpy as np
+import torch
+
+from . import memory as XP
+from . import ops
+from .hps import check_supported
+from .mpi_adam import MpiAdam
+from .networks import FlatNet, init_flat
+from .running_mean_std import DeviceRunningMeanStd
+
+
+class NormalAcNoise(object):
+    """imitation_algorithms/ac_noise.py:15-28."""
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = mu, sigma
+
+    def generate(self):
+        return np.random.normal(self.mu, self.sigma)
+
+    def reset(self):
+        pass
+
+
+class OUAcNoise(object):
+    """imitation_algorithms/ac_noise.py:30-59 (Ornstein-Uhlenbeck)."""
+
+    def __init__(self, mu, sigma, theta=0.15, dt=1e-2, noise_0=None):
+        self.mu, self.sigma, self.theta, self.dt, self.noise_0 = mu, sigma, theta, dt, noise_0
+        self.reset()
+
+    def generate(self):
+        noise = (self.prev_noise + self.theta * (self.mu - self.prev_noise) * self.dt +
+                 self.sigma * np.sqrt(self.dt) * np.random.normal(size=self.mu.shape))
+        self.prev_noise = noise
+        return noise
+
+    def reset(self):
+        self.prev_noise = self.noise_0 if self.noise_0 is not None else np.zeros_like(self.mu)
+
+
+class SAMAgent(object):
+
+    def __init__(self, name, comm, env, hps, d, device='cuda'):
+        check_supported(hps)
+        self.name, self.scope, self.comm, self.env, self.hps = name, name, comm, env, hps
+        self.device = torch.device(device)
+        self.ob_shape = env.observation_space.shape
+        self.ac_space = env.action_space
+        self.ac_shape = self.ac_space.shape
+        self.ob_dim, self.ac_dim = int(self.ob_shape[0]), int(self.ac_shape[0])
+        assert all(self.ac_space.low == -self.ac_space.high), "non-admissible ac space bounds"
+        self.ac_high = float(self.ac_space.high[0])
+        assert all(c == self.ac_high for c in self.ac_space.high)
+        assert hps.n > 1 or not hps.n_step_returns
+        self.param_noise, self.ac_noise = self.parse_noise_type(hps.noise_type)
+
+        h1, h2 = hps.hid_widths
+        self.da = ops.mlp_desc(self.ob_dim, h1, h2, self.ac_dim, hps.with_layernorm)
+        self.dc = ops.mlp_desc(self.ob_dim + self.ac_dim, h1, h2, 1, hps.with_layernorm)
+        self.Pa, self.Pc = ops.param_count(self.da), ops.param_count(self.dc)
+        rs = np.random.RandomState(hps.seed + 104729)
+        init = np.concatenate([init_flat(self.da, rs, 'actor', hps.hid_w_init),
+                               init_flat(self.dc, rs, 'critic', hps.hid_w_init)])
+        self.params = torch.as_tensor(init).to(self.device)
+        self.targets = torch.zeros_like(self.params)
+        self.grads = torch.zeros_like(self.params)
+        self.clipped = torch.zeros_like(self.params)
+        a, c = slice(0, self.Pa), slice(self.Pa, self.Pa + self.Pc)
+        self.actor = FlatNet(self.scope, 'online_actor', self.da, self.params[a])
+        self.critic = FlatNet(self.scope, 'online_critic', self.dc, self.params[c])
+        self.targ_actor = FlatNet(self.scope, 'targ_actor', self.da, self.targets[a])
+        self.targ_critic = FlatNet(self.scope, 'targ_critic', self.dc, self.targets[c])
+        self.actor_grad, self.critic_grad = self.grads[a], self.grads[c]
+
+        # the reward net the actor loss differentiates through (sam_agent.py:88,192): see
+        # hps.tie_actor_reward_net
+        self.d_desc = d.desc
+        if hps.d_actor_loss_scale != 0:
+            if hps.tie_actor_reward_net:
+                self.d_params = d.params
+            else:
+                rs2 = np.random.RandomState(hps.seed + 15485863)
+                self.d_params = torch.as_tensor(
+                    init_flat(self.d_desc, rs2, 'reward', hps.hid_w_init)).to(self.device)
+        else:
+            self.d_params = None
+
+        if hps.rmsify_obs:
+            self.obs_rms = DeviceRunningMeanStd(shape=self.ob_shape, device=self.device)
+
+        self.setup_replay_buffer()
+        actor_opt = MpiAdam(comm, self.actor.flat, hps.clip_norm, hps.actor_lr, name='actor_adam')
+        critic_opt = MpiAdam(comm, self.critic.flat, hps.clip_norm, hps.critic_lr, name='critic_adam')
+        self.actor_ops = {'names': ['actor_q_loss', 'actor_d_loss', 'actor_total_loss'],
+                          'optimizer': actor_opt}
+        names = ['critic_td_loss_1', 'critic_wd', 'critic_total_loss']
+        self.critic_ops = {'names': names, 'optimizer': critic_opt}
+        self.actor_losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.critic_losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        B = hps.batch_size
+        self.ws = ops.nets_ws(self.da, self.dc, self.d_desc, B, self.device)
+        self.ws1 = ops.nets_ws(self.da, self.dc, self.d_desc, 1, self.device)
+        self.targ_q = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.td = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
+        self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
+        self._idx_dev = torch.empty(B, dtype=torch.int64, device=self.device)
+
+    # ---- set-up pieces -------------------------------------------------------------------------
+    def parse_noise_type(self, noise_type):
+        """sam_agent.py:238-288 (action-space noise only; param noise is a "next" row)."""
+        ac_noise = None
+        for cur in noise_type.split(','):
+            cur = cur.strip()
+            if cur == 'none':
+                pass
+            elif 'normal' in cur:
+                _, std = cur.split('_')
+                ac_noise = NormalAcNoise(mu=np.zeros(self.ac_dim), sigma=float(std) * np.ones(self.ac_dim))
+            elif 'ou' in cur:
+                _, std = cur.split('_')
+                ac_noise = OUAcNoise(mu=np.zeros(self.ac_dim), sigma=float(std) * np.ones(self.ac_dim))
+            else:
+                raise RuntimeError("unknown specified noise type: '{}'".format(cur))
+        return None, ac_noise
+
+    def setup_replay_buffer(self):
+        """sam_agent.py:310-335."""
+        kw = dict(limit=self.hps.mem_size, ob_shape=self.ob_shape, ac_shape=self.ac_shape,
+                  device=self.device)
+        if self.hps.prioritized_replay:
+            self.replay_buffer = XP.PrioritizedRB(alpha=self.hps.alpha, beta=self.hps.beta,
+                                                  ranked=self.hps.ranked, **kw)
+        else:
+            self.replay_buffer = XP.RB(**kw)
+
+    def _mean_std(self):
+        return (self.obs_rms.mean, self.obs_rms.std) if self.hps.rmsify_obs else (None, None)
+
+    # ---- acting --------------------------------------------------------------------------------
+    def predict(self, obs, apply_noise, compute_q):
+        """sam_agent.py:592-619."""
+        o = torch.as_tensor(np.asarray(obs, dtype=np.float32)[None]).to(self.device)
+        mean, std = self._mean_std()
+        ac, q = ops.act_q(self.da, self.actor.flat, self.dc, self.critic.flat, o, mean, std,
+                          self.ac_high, self.ws1, want_q=compute_q)
+        ac = ac.cpu().numpy().flatten()
+        if apply_noise and self.ac_noise is not None:
+            noise = self.ac_noise.generate()
+            assert noise.shape == ac.shape
+            ac += noise
+        return ac, (float(q.item()) if compute_q else None)
+
+    def store_transition(self, ob0, ac, rew, ob1, done1):
+        """sam_agent.py:621-629."""
+        rew *= self.hps.reward_scale
+        self.replay_buffer.append(ob0, ac, rew, ob1, done1)
+        if self.hps.rmsify_obs:
+            self.obs_rms.update(np.array([ob0]), self.comm)
+
+    # ---- the update ----------------------------------------------------------------------------
+    def sample_device(self):
+        """Replay batch in HBM.  Uniform: indices from np.random.randint (memory.py:90), one H2D
+        copy, gather kernel.  PER: uniforms from random.random() (memory.py:278), tree kernels."""
+        B, rb = self.hps.batch_size, self.replay_buffer
+        if self.hps.prioritized_replay:
+            return rb.sample_device(B)
+        idxs = np.random.randint(low=0, high=rb.num_entries, size=B)
+        self._idx_dev.copy_(torch.from_numpy(idxs))  # pageable, synchronous: safe to redraw at once
+        batch = rb.batchify_device(self._idx_dev)
+        batch['idxs'] = self._idx_dev
+        return batch
+
+    def grads_device(self, batch):
+        """TD target on the target nets, then actor and critic losses + unclipped flat gradients on
+        the pre-update parameters (sam_agent.py:651-687 without the four repeated sess.runs)."""
+        mean, std = self._mean_std()
+        hp = self.hps
+        ops.targ_q(self.da, self.targ_actor.flat, self.dc, self.targ_critic.flat, batch['obs1'],
+                   batch['rews'], batch['dones1'], None, mean, std, hp.gamma, self.ac_high, self.ws,
+                   out=self.targ_q)
+        ops.actor_grad(self.da, self.actor.flat, self.dc, self.critic.flat, self.d_desc, self.d_params,
+                       batch['obs0'], mean, std, self.ac_high, hp.q_actor_loss_scale,
+                       hp.d_actor_loss_scale, self.ws, losses=self.actor_losses, grad=self.actor_grad)
+        ops.critic_grad(self.dc, self.critic.flat, batch['obs0'], batch['acs'],
+                        batch.get('iws32') if hp.prioritized_replay else None, self.targ_q, mean, std,
+                        hp.td_loss_1_scale, hp.wd_scale, self.ws, losses=self.critic_losses,
+                        grad=self.critic_grad, td=self.td)
+
+    def apply_device(self, fuse_polyak=False):
+        """MpiAdam on both nets: ONE all-reduce over the [actor|critic] bucket (mpi_adam.py:27),
+        then per-net clip + Adam (sam_agent.py:690-691)."""
+        self.comm.allreduce_(self.grads)
+        tau = self.hps.polyak
+        self.actor_ops['optimizer'].update(self.actor_grad, reduce=False,
+                                           targ=self.targ_actor.flat if fuse_polyak else None, tau=tau)
+        self.critic_ops['optimizer'].update(self.critic_grad, reduce=False,
+                                            targ=self.targ_critic.flat if fuse_polyak else None, tau=tau)
+
+    def refresh_priorities(self, batch):
+        """sam_agent.py:693-703: |td| + 1e-6 with the POST-update critic, then the tree update.
+        The float32 sum matches numpy's (float32 array + python float stays float32)."""
+        mean, std = self._mean_std()
+        ops.td_errors(self.dc, self.critic.flat, batch['obs0'], batch['acs'], self.targ_q, mean, std,
+                      self.ws, out=self.td)
+        self._td_host.copy_(self.td, non_blocking=True)
+        self._idx_host.copy_(batch['idxs'], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
+        self.replay_buffer.update_priorities(self._idx_host.numpy(), new_priorities)
+
+    def train_device(self, fuse_polyak=False, want_clipped=True):
+        batch = self.sample_device()
+        self.grads_device(batch)
+        if want_clipped:  # flatgrad(loss, vars, clip_norm): the logged, locally clipped gradients
+            a = slice(0, self.Pa); c = slice(self.Pa, self.Pa + self.Pc)
+            ops.clip_copy(self.actor_grad, self.hps.clip_norm, self.actor_ops['optimizer'].partials,
+                          out=self.clipped[a])
+            ops.clip_copy(self.critic_grad, self.hps.clip_norm, self.critic_ops['optimizer'].partials,
+                          out=self.clipped[c])
+        self.apply_device(fuse_polyak)
+        if self.hps.prioritized_replay:
+            self.refresh_priorities(batch)
+        return batch
+
+    def train(self):
+        """sam_agent.py:631-711."""
+        self.train_device()
+        cl = self.clipped.cpu().numpy()
+        return {'actor_grads': cl[:self.Pa].copy(),
+                'actor_losses': [float(x) for x in self.actor_losses.cpu().numpy()],
+                'critic_grads': cl[self.Pa:].copy(),
+                'critic_losses': [float(x) for x in self.critic_losses.cpu().numpy()]}
+
+    # ---- housekeeping --------------------------------------------------------------------------
+    def sync_from_root(self):
+        """sam_agent.py:713-717 (one broadcast of the [actor|critic] bucket)."""
+        self.comm.Barrier()
+        self.comm.bcast_(self.params, root=0)
+
+    def initialize_target_nets(self):
+        ops.polyak(self.targets, self.params, 1.0)
+
+    def update_target_net(self):
+        ops.polyak(self.targets, self.params, self.hps.polyak)
+
+    def reset_noise(self):
+        if self.ac_noise is not None:
+            self.ac_noise.reset()

@@ -1,0 +1,68 @@
+"""The `comm` object the reference threads through SAMAgent / Discriminator / MpiAdam is an mpi4py
+communicator (run_sam.py:20-21).  This is the same surface — Get_rank / Get_size / Barrier /
+Allreduce / Bcast — over torch.distributed: backend "nccl" (= RCCL over xGMI) for device tensors,
+"gloo" on CPU for tests.  One process per GPU; with a single process every call is local.
+
+Replaces helpers/mpi_moments.py:6-22 (mpi_mean_like) and the Allreduce/Bcast calls of
+helpers/mpi_adam.py:27,49-52,65-70 and helpers/mpi_running_mean_std.py:55.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SUM = 'sum'
+
+
+class TorchComm(object):
+
+    def __init__(self, device=None):
+        self.active = dist.is_available() and dist.is_initialized()
+        self.device = device
+
+    def Get_rank(self):
+        return dist.get_rank() if self.active else 0
+
+    def Get_size(self):
+        return dist.get_world_size() if self.active else 1
+
+    def Barrier(self):
+        if self.active:
+            dist.barrier()
+
+    # ---- device / tensor forms used on the hot path
+    def allreduce_(self, t):
+        """In-place SUM over ranks of a torch tensor (CUDA -> RCCL, CPU -> gloo)."""
+        if self.active and self.Get_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def bcast_(self, t, root=0):
+        if self.active and self.Get_size() > 1:
+            dist.broadcast(t, src=root)
+        return t
+
+    # ---- mpi4py-shaped numpy forms (drop-in for host callers)
+    def _staging(self, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if self.active and dist.get_backend() == 'nccl':
+            t = t.to(self.device if self.device is not None else 'cuda')
+        return t
+
+    def Allreduce(self, sendbuf, recvbuf, op=SUM):
+        assert op == SUM, "only MPI.SUM is used by the reference on this path"
+        t = self._staging(sendbuf).clone()
+        self.allreduce_(t)
+        recvbuf[...] = t.cpu().numpy().reshape(recvbuf.shape)
+
+    def Bcast(self, buf, root=0):
+        t = self._staging(buf).clone()
+        self.bcast_(t, root)
+        buf[...] = t.cpu().numpy().reshape(buf.shape)
+
+
+def mpi_mean_like(x, comm):
+    """helpers/mpi_moments.py:6-22: Allreduce(SUM) / size, any array shape."""
+    x = np.asarray(x)
+    out = np.zeros_like(x)
+    comm.Allreduce(x, out, op=SUM)
+    return out / comm.Get_size()

@@ -24,8 +24,11 @@ __device__ __forceinline__ double block_sum(double x, double* sh) {
 }
 
 __global__ __launch_bounds__(kThreads) void sumsq_kernel(const float* __restrict__ g, int64_t n,
-                                                         float* __restrict__ partials) {
+                                                         float* __restrict__ partials,
+                                                         int64_t* __restrict__ step_dev) {
     __shared__ double sh[kThreads / 64];
+    // the device-side update counter ticks here, one launch ahead of the kernel that reads it
+    if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) step_dev[0] += 1;
     double acc = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * kThreads) {
@@ -49,9 +52,21 @@ __device__ __forceinline__ float norm_from_partials(const float* __restrict__ pa
 __global__ __launch_bounds__(kThreads) void adam_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     int64_t n, float lr_t, float beta1, float beta2, float eps, float clip_norm, float grad_scale,
-    float* __restrict__ targ, float tau, const float* __restrict__ partials, int np) {
+    float* __restrict__ targ, float tau, const float* __restrict__ partials, int np,
+    const int64_t* __restrict__ step_dev, float lr) {
     __shared__ double sh[kThreads / 64];
     __shared__ float shn;
+    __shared__ float sh_lr;
+    if (step_dev) {
+        // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t read from HBM so that a captured graph
+        // needs no per-step host argument
+        if (threadIdx.x == 0) {
+            const double t = (double)step_dev[0];
+            sh_lr = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+        }
+        __syncthreads();
+        lr_t = sh_lr;
+    }
     float scale = grad_scale;
     if (clip_norm > 0.f) {
         // partials hold |sum-over-workers grad|^2 ; the mean gradient's norm is grad_scale * that
@@ -122,20 +137,22 @@ int samx_adam_partials(void) { return kPartials; }
 
 int samx_clip_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
                    float beta1, float beta2, float eps, int64_t step, float clip_norm,
-                   float grad_scale, float* targ, float tau, float* partials, void* stream) {
+                   float grad_scale, float* targ, float tau, float* partials, int64_t* step_dev,
+                   void* stream) {
     SAMX_REQUIRE(param && grad && m && v, "samx_clip_adam: null pointer");
-    SAMX_REQUIRE(n > 0 && step >= 1, "samx_clip_adam: n and step must be positive");
-    SAMX_REQUIRE(clip_norm <= 0.f || partials, "samx_clip_adam: clipping needs the partials scratch");
+    SAMX_REQUIRE(n > 0 && (step_dev || step >= 1), "samx_clip_adam: n and step must be positive");
+    SAMX_REQUIRE((clip_norm <= 0.f && !step_dev) || partials,
+                 "samx_clip_adam: clipping / device step counter need the partials scratch");
     const int g = grid_for(n);
-    if (clip_norm > 0.f) {
-        sumsq_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(grad, n, partials);
+    if (clip_norm > 0.f || step_dev) {
+        sumsq_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(grad, n, partials, step_dev);
         SAMX_LAUNCH_CHECK();
     }
-    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) /
-                        (1.0 - pow((double)beta1, (double)step));
+    const double st = step_dev ? 1.0 : (double)step;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, st)) / (1.0 - pow((double)beta1, st));
     adam_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(param, grad, m, v, n, (float)lr_t, beta1,
                                                         beta2, eps, clip_norm, grad_scale, targ, tau,
-                                                        partials, g);
+                                                        partials, g, step_dev, lr);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -153,7 +170,7 @@ int samx_clip_copy(const float* grad, int64_t n, float clip_norm, float* out, fl
     SAMX_REQUIRE(clip_norm <= 0.f || partials, "samx_clip_copy: clipping needs the partials scratch");
     const int g = grid_for(n);
     if (clip_norm > 0.f) {
-        sumsq_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(grad, n, partials);
+        sumsq_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(grad, n, partials, nullptr);
         SAMX_LAUNCH_CHECK();
     }
     clip_copy_kernel<<<g, kThreads, 0, (hipStream_t)stream>>>(grad, n, clip_norm, out, partials, g);

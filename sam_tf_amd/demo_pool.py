@@ -1,0 +1,41 @@
+"""Expert (state, action) pairs resident in HBM with the batching rule of
+imitation_algorithms/demo_dataset.py:6-41 (PairDataset): shuffle, hand out consecutive slices,
+reshuffle when fewer than batch_size pairs remain.  Batches are views — no copy, no gather.
+Loading the reference's .npz archives (demo_dataset.py:44-116) is a "next" row.
+"""
+import numpy as np
+import torch
+
+
+class DevicePairPool(object):
+
+    def __init__(self, obs0, acs, randomize=True, device='cuda'):
+        self.device = torch.device(device)
+        self.obs0 = torch.as_tensor(np.asarray(obs0, dtype=np.float32)).to(self.device).contiguous()
+        self.acs = torch.as_tensor(np.asarray(acs, dtype=np.float32)).to(self.device).contiguous()
+        self.num_entries = self.obs0.shape[0]
+        assert self.acs.shape[0] == self.num_entries
+        self.randomize = randomize
+        self.init_pointer()
+
+    def init_pointer(self):
+        self.pointer = 0
+        if self.randomize:
+            indices = np.arange(self.num_entries)
+            np.random.shuffle(indices)  # same generator as the reference
+            idx = torch.as_tensor(indices).to(self.device)
+            # permute in place: the storage address stays fixed (captured HIP graphs read it)
+            self.obs0.copy_(self.obs0.index_select(0, idx))
+            self.acs.copy_(self.acs.index_select(0, idx))
+
+    def get_next_pair_batch_device(self, batch_size):
+        if self.pointer + batch_size >= self.num_entries:
+            self.init_pointer()
+        end = self.pointer + batch_size
+        o, a = self.obs0[self.pointer:end], self.acs[self.pointer:end]
+        self.pointer = end
+        return o, a
+
+    def get_next_pair_batch(self, batch_size):
+        o, a = self.get_next_pair_batch_device(batch_size)
+        return o.cpu().numpy(), a.cpu().numpy()

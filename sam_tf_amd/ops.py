@@ -165,7 +165,7 @@ def adam_partials(device='cuda'):
 
 
 def clip_adam(param, grad, m, v, lr, step, clip_norm, partials, grad_scale=1.0, targ=None, tau=0.0,
-              beta1=0.9, beta2=0.999, eps=1e-8):
+              beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None):
     n = param.numel()
     for t, nm in ((param, 'param'), (grad, 'grad'), (m, 'm'), (v, 'v')):
         _chk(t, F32, (n,), nm)
@@ -174,7 +174,8 @@ def clip_adam(param, grad, m, v, lr, step, clip_norm, partials, grad_scale=1.0, 
     check(_L().samx_clip_adam(ptr(param), ptr(grad), ptr(m), ptr(v), n, float(lr), float(beta1),
                               float(beta2), float(eps), int(step),
                               float(clip_norm) if clip_norm else 0.0, float(grad_scale), ptr(targ),
-                              float(tau), ptr(partials), stream_ptr()))
+                              float(tau), ptr(partials), ptr(_opt(step_dev, I64, (1,), 'step_dev')),
+                              stream_ptr()))
 
 
 def polyak(targ, param, tau):

@@ -1,0 +1,186 @@
+"""End-to-end parity of the update-step driver: K consecutive steps on the GPU (eager and
+graph-captured) vs the same K steps replayed on the CPU oracle with the identical host draws and the
+identical device-drawn D randoms.  Bar: post-update weights, Adam state, running-mean sums and
+losses within 1e-5 relative (max-norm); PER indices bit-exact."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests.nets_cases import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleLearner(object):
+    """fp64 mirror of sam_tf_amd.driver.UpdateStepDriver.step() built from oracle/ only."""
+
+    def __init__(self, mu, d, pool, per):
+        from oracle import nets_oracle as NO
+        from oracle.replay_oracle import PrioritizedReplayOracle
+        self.NO = NO
+        h1, h2 = mu.hps.hid_widths
+        self.da = NO.MLP(mu.ob_dim, h1, h2, mu.ac_dim, False)
+        self.dc = NO.MLP(mu.ob_dim + mu.ac_dim, h1, h2, 1, False)
+        self.pa = mu.actor.get_flat().astype(np.float64); self.pc = mu.critic.get_flat().astype(np.float64)
+        self.pa_t = mu.targ_actor.get_flat().astype(np.float64)
+        self.pc_t = mu.targ_critic.get_flat().astype(np.float64)
+        self.pd = d.reward_nn.get_flat().astype(np.float64)
+        self.opt = {k: [np.zeros(p.size), np.zeros(p.size), 0] for k, p in
+                    (('a', self.pa), ('c', self.pc), ('d', self.pd))}
+        self.store = {k: v.cpu().numpy() for k, v in mu.replay_buffer.store.items()}
+        self.start = mu.replay_buffer.start
+        self.limit = mu.replay_buffer.limit
+        self.rms_mu = mu.obs_rms.sums.cpu().numpy().copy()
+        self.rms_d = d.obs_rms.sums.cpu().numpy().copy()
+        self.hps = mu.hps
+        self.per = per
+        if per:
+            rb = mu.replay_buffer
+            self.rb = PrioritizedReplayOracle(rb.limit, (mu.ob_dim,), (mu.ac_dim,), rb.alpha, rb.beta)
+            self.rb.sum_tree.v[:] = rb.trees.sum.cpu().numpy()
+            self.rb.min_tree.v[:] = rb.trees.min.cpu().numpy()
+            for r in self.rb.rings.values():
+                r.length = rb.length; r.start = rb.start
+            self.rb.max_priority = rb.max_priority
+
+    def rows(self, idxs):
+        phys = (self.start + idxs) % self.limit
+        return {k: v[phys] for k, v in self.store.items()}
+
+    def adam(self, key, p, g, lr):
+        NO = self.NO
+        m, v, t = self.opt[key]
+        th, m, v = NO.mpi_adam_step(p, m, v, [g], lr, t + 1, self.hps.clip_norm)
+        self.opt[key] = [m, v, t + 1]
+        return th
+
+    def step(self, idx_p, e_obs, e_acs, eps_ob, eps_ac, real, idx_a=None, u=None, gpu_td=None):
+        NO, hp = self.NO, self.hps
+        ob = self.da.in_dim
+        p = self.rows(idx_p)
+        self.rms_d = NO.rms_update(self.rms_d, np.concatenate((p['obs0'], e_obs)), ob)
+        mean, std = NO.rms_mean_std(self.rms_d, ob)
+        dl, g = NO.disc_loss_grad(self.pd, self.dc, p['obs0'], p['acs'], e_obs, e_acs, eps_ob, eps_ac,
+                                  real, np.zeros(len(real)), mean, std)
+        self.pd = self.adam('d', self.pd, g, hp.d_lr)
+        iws = None
+        if self.per:
+            idx_a = self.rb.sample_idxs(len(u), u)
+            iws = self.rb.importance_weights(idx_a).astype(np.float32)[:, None]
+        b = self.rows(idx_a)
+        mean, std = NO.rms_mean_std(self.rms_mu, ob)
+        tq = NO.targ_q(self.pa_t, self.pc_t, self.da, self.dc, b['obs1'], b['rews'], b['dones1'],
+                       np.ones_like(b['rews']), mean, std, hp.gamma, 1.0)
+        al, ga = NO.actor_loss_grad(self.pa, self.da, self.pc, self.dc, None, None, b['obs0'], mean, std,
+                                    1.0, hp.q_actor_loss_scale, 0.0)
+        cl, gc, _ = NO.critic_loss_grad(self.pc, self.dc, b['obs0'], b['acs'], iws, tq, mean, std,
+                                        hp.wd_scale, hp.td_loss_1_scale)
+        self.pa = self.adam('a', self.pa, ga, hp.actor_lr)
+        self.pc = self.adam('c', self.pc, gc, hp.critic_lr)
+        if self.per:
+            td = NO.td_errors(self.pc, self.dc, b['obs0'], b['acs'], tq, mean, std)
+            assert relerr(gpu_td, td.ravel()) < 1e-5
+            # the new priorities are float32 network outputs (1e-5 class); the TREE arithmetic on
+            # them is what must be bit-exact, so both sides get the same float32 priorities
+            pr = np.abs(gpu_td.astype(np.float32)) + np.float32(1e-6)
+            self.rb.update_priorities(idx_a, pr.astype(np.float64))
+        self.pa_t = NO.polyak(self.pa_t, self.pa, hp.polyak)
+        self.pc_t = NO.polyak(self.pc_t, self.pc, hp.polyak)
+        return dict(d_losses=dl, actor_losses=al, critic_losses=cl, idx_a=idx_a)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3'])
+def test_k_steps_match_oracle(cfg_name, graph):
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+    mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
+    drv.prepare()
+    ref = OracleLearner(mu, d, pool, cfg['per'])
+    K = 6
+    worst_td = 0.0
+    for k in range(K):
+        drv.step()
+        torch.cuda.synchronize()
+        h = lambda t: t.cpu().numpy()
+        out = ref.step(h(drv.idx_p), h(drv.eb['obs0']), h(drv.eb['acs']), h(drv.eps_ob), h(drv.eps_ac),
+                       h(drv.real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(mu.td))
+        if cfg['per']:
+            assert np.array_equal(out['idx_a'], h(drv.idx_a)), 'PER indices differ at step %d' % k
+        o = drv.outputs()
+        for name in ('d_losses', 'actor_losses', 'critic_losses'):
+            got, exp = h(o[name]).astype(np.float64), out[name]
+            assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-5, (name, k, got, exp)
+    # post-update weights after K steps
+    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
+    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
+    assert relerr(mu.targ_actor.get_flat(), ref.pa_t) < 1e-5
+    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
+    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
+    for key, opt in (('a', mu.actor_ops['optimizer']), ('c', mu.critic_ops['optimizer']),
+                     ('d', d.optimizer)):
+        assert opt.t == K and int(opt.t_dev.item()) == K
+        assert relerr(opt.m.cpu().numpy(), ref.opt[key][0]) < 1e-5
+        assert relerr(opt.v.cpu().numpy(), ref.opt[key][1]) < 2e-5
+    if cfg['per']:
+        assert mu.replay_buffer.max_priority == ref.rb.max_priority
+        assert np.array_equal(mu.replay_buffer.tree_values('sum'), ref.rb.sum_tree.v)
+        assert np.array_equal(mu.replay_buffer.tree_values('min'), ref.rb.min_tree.v)
+
+
+def test_drop_in_surface():
+    """The reference-shaped calls sam.py makes (predict / store_transition / train / get_reward /
+    feed-dict D calls / update_target_net / check_synced) all work and agree with the fused path."""
+    from sam_tf_amd.hps import make_hps, SyntheticEnv
+    from sam_tf_amd.discriminator import Discriminator
+    from sam_tf_amd.agent import SAMAgent
+    from sam_tf_amd.comm import TorchComm
+    from oracle import nets_oracle as NO
+    np.random.seed(0); random.seed(0)
+    comm = TorchComm('cuda')
+    env = SyntheticEnv(5, 2, 0.4)
+    hps = make_hps(batch_size=16, mem_size=200, prioritized_replay=True, noise_type='ou_0.2',
+                   d_actor_loss_scale=0.5)
+    d = Discriminator('d', env, hps, comm)
+    mu = SAMAgent('mu', comm, env, hps, d)
+    mu.initialize_target_nets(); mu.sync_from_root(); d.sync_from_root()
+    rs = np.random.RandomState(1)
+    ob = rs.randn(5).astype(np.float32)
+    for t in range(60):
+        ac, q = mu.predict(ob, apply_noise=True, compute_q=True)
+        assert ac.shape == (2,) and isinstance(q, float)
+        rew = d.get_reward(ob, ac)
+        assert isinstance(rew, float) and np.isfinite(rew)
+        ob1 = rs.randn(5).astype(np.float32)
+        mu.store_transition(ob, ac, rew, ob1, float(t % 20 == 19))
+        ob = ob1
+    assert mu.replay_buffer.num_entries == 60
+    # reward parity for one pair
+    m, s = mu.obs_rms.mean.cpu().numpy(), mu.obs_rms.std.cpu().numpy()
+    dm, ds = d.obs_rms.mean.cpu().numpy(), d.obs_rms.std.cpu().numpy()
+    er = NO.reward(d.reward_nn.get_flat(), NO.MLP(7, 64, 64, 1, False), ob[None], ac[None], dm, ds)
+    assert abs(d.get_reward(ob, ac) - float(er)) < 1e-5 * max(1.0, abs(float(er)))
+    xp = mu.replay_buffer.sample_uniform(16)
+    feeds = {d.p_obs: xp['obs0'], d.p_acs: xp['acs'], d.e_obs: rs.randn(16, 5), d.e_acs: rs.rand(16, 2)}
+    d.obs_rms.update(np.concatenate((feeds[d.p_obs], feeds[d.e_obs])), comm)
+    g = d.get_grads(feeds); l = d.get_losses(feeds); d.optimize(feeds)
+    assert g.shape == (d.params.numel(),) and len(l) == 8 and len(d.names) == 8
+    assert np.linalg.norm(g) <= hps.clip_norm * (1 + 1e-5)
+    out = mu.train()
+    assert set(out) == {'actor_grads', 'actor_losses', 'critic_grads', 'critic_losses'}
+    assert out['actor_grads'].shape == (mu.Pa,) and out['critic_grads'].shape == (mu.Pc,)
+    assert len(out['actor_losses']) == 3 and len(out['critic_losses']) == 3
+    assert out['actor_losses'][1] != 0.0  # the d-term is live with d_actor_loss_scale = 0.5
+    before = mu.targets.clone()
+    mu.update_target_net()
+    assert not torch.equal(before, mu.targets)
+    mu.actor_ops['optimizer'].check_synced(mu.actor.trainable_vars)
+    mu.critic_ops['optimizer'].check_synced(mu.critic.trainable_vars)
+    d.optimizer.check_synced(d.trainable_vars)
+    assert [v.name for v in mu.actor.trainable_vars][:2] == ['mu/online_actor/fc1/kernel:0',
+                                                            'mu/online_actor/fc1/bias:0']
+    mu.reset_noise()

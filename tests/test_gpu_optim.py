@@ -17,6 +17,7 @@ def test_clip_adam_polyak(n, clip, world):
     th_d, tg_d = torch.as_tensor(theta).cuda(), torch.as_tensor(targ).cuda()
     m_d, v_d = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
     part = ops.adam_partials()
+    t_dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     th, tg = theta.astype(np.float64), targ.astype(np.float64)
     for t in range(1, 6):
         gs = [rs.randn(n).astype(np.float32) * (3.0 if t % 2 else 0.01) for _ in range(world)]
