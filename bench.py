@@ -49,7 +49,7 @@ def flops_per_step(cfg):
     return cfg['B'] * (8 * wa + (14 if cfg['per'] else 12) * wc + 22 * wd)
 
 
-def role_flops(cfg):
+def role_flops(cfg):  # per network pass, SURVEY.md §8(d)
     wa, wc, wd = weight_elems(cfg['ob'], cfg['ac'], cfg['h'])
     B = cfg['B']
     return {'disc_grad': 22 * wd * B, 'targ_q': 2 * (wa + wc) * B, 'actor_grad': (6 * wa + 4 * wc) * B,
@@ -98,36 +98,23 @@ def build_learner(cfg, comm, device, seed, use_graph):
     return mu, d, pool, drv
 
 
-def time_roles(drv, cfg, iters=20):
-    """Average device time of each network pass of the step, HIP events on the launch stream."""
+def time_passes(drv, cfg, iters=50):
+    """Average device time of the step's passes, HIP events recorded on the launch stream."""
     from sam_tf_amd import ops
-    mu, d = drv.mu, drv.d
     st = torch.cuda.current_stream()
-    batch = dict(drv.ab); batch['iws32'] = drv.iws32
-    mean, std = mu._mean_std()
-    hp = mu.hps
+    L, B = drv.L, drv.B
+    keep = [t.clone() for t in (L.params, L.targets, L.m, L.v, L.steps)]
 
-    def disc():
-        d.grads_device(drv.pb['obs0'], drv.pb['acs'], drv.eb['obs0'], drv.eb['acs'],
-                       randoms=(drv.eps_ob, drv.eps_ac, drv.real, None))
+    def grads():
+        ops.step_grads(L, drv.batch, drv.out)
 
-    def targ():
-        ops.targ_q(mu.da, mu.targ_actor.flat, mu.dc, mu.targ_critic.flat, batch['obs1'], batch['rews'],
-                   batch['dones1'], None, mean, std, hp.gamma, mu.ac_high, mu.ws, out=mu.targ_q)
+    def apply_():
+        ops.step_apply(L, B, 3, 1.0)
 
-    def actor():
-        ops.actor_grad(mu.da, mu.actor.flat, mu.dc, mu.critic.flat, mu.d_desc, mu.d_params,
-                       batch['obs0'], mean, std, mu.ac_high, hp.q_actor_loss_scale,
-                       hp.d_actor_loss_scale, mu.ws, losses=mu.actor_losses, grad=mu.actor_grad)
-
-    def critic():
-        ops.critic_grad(mu.dc, mu.critic.flat, batch['obs0'], batch['acs'],
-                        batch['iws32'] if hp.prioritized_replay else None, mu.targ_q, mean, std,
-                        hp.td_loss_1_scale, hp.wd_scale, mu.ws, losses=mu.critic_losses,
-                        grad=mu.critic_grad, td=mu.td)
+    def inputs():
+        drv._seg_inputs()
     out = {}
-    for name, fn in (('disc_grad', disc), ('targ_q', targ), ('actor_grad', actor),
-                     ('critic_grad', critic)):
+    for name, fn in (('inputs(gather+rms)', inputs), ('step_grads', grads), ('step_apply', apply_)):
         fn(); fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -136,6 +123,8 @@ def time_roles(drv, cfg, iters=20):
         e1.record(st)
         e1.synchronize()
         out[name] = e0.elapsed_time(e1) / iters * 1e-3  # seconds
+    for t, sv in zip((L.params, L.targets, L.m, L.v, L.steps), keep):
+        t.copy_(sv)
     return out
 
 
@@ -199,10 +188,10 @@ def main():
     el = float(el.item())
     finite = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
 
-    roles = time_roles(drv, cfg)
-    rf = role_flops(cfg)
-    dom = max(roles, key=lambda k: roles[k])
-    achieved = rf[dom] / roles[dom] / 1e12
+    passes = time_passes(drv, cfg)
+    # dominant device pass: samx_step_grads = every network forward/backward of the step
+    # (fused path: disc1 + disc2 + agent + finalize kernels; layer-wise path: the MFMA GEMM chain)
+    achieved = flops_per_step(cfg) / passes['step_grads'] / 1e12
     result = {
         'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'],
         'value': world * args.steps / el, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -215,10 +204,12 @@ def main():
                                 mu.replay_buffer.num_entries),
                    'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                    'finite_params': finite},
-        'roofline': {'bound': 'mfma', 'kernel': dom + ' (layer-wise MFMA f32 pass)',
+        'roofline': {'bound': 'mfma',
+                     'kernel': 'samx_step_grads (%s)' % ('fused whole-network kernels' if drv.fused
+                                                         else 'layer-wise MFMA f32 GEMM chain'),
                      'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
-                     'pass_us': {k: v * 1e6 for k, v in roles.items()},
+                     'pass_us': {k: v * 1e6 for k, v in passes.items()},
                      'step_flops': flops_per_step(cfg)},
     }
     if rank == 0:

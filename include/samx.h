@@ -209,6 +209,65 @@ int samx_reward(const samx_mlp* reward_net, const float* params, const float* ob
                 float* out,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* ---- one update step for the whole learner ------------------------------------------------ */
+/* The body of the reference's training loop (imitation_algorithms/sam.py:369-433, d_steps = g_steps
+ * = 1) as two calls: gradients, then the optimiser pass; the caller's gradient all-reduce
+ * (helpers/mpi_adam.py:27) goes between them.  The learner is described by plain device pointers;
+ * vectors of all three optimisers are laid out [actor | critic | reward-net] so that ONE all-reduce
+ * covers an update.  For 64x64 networks and batches that are a multiple of 16 the whole step runs on
+ * whole-network fused kernels (weights + activations in LDS), otherwise on the layer-wise MFMA path;
+ * results are the same to rounding. */
+typedef struct samx_learner {
+    samx_mlp actor, critic, reward;   /* reward = the discriminator's RewardNN */
+    int32_t ob_dim, ac_dim;
+    float* params;                    /* [Pa + Pc + Pd] online parameters */
+    float* grads;                     /* [Pa + Pc + Pd] out: unclipped flat gradients (all-reduce this) */
+    float* clipped;                   /* [Pa + Pc + Pd] out: locally clipped gradients (logging), or NULL */
+    float *adam_m, *adam_v;           /* [Pa + Pc + Pd] */
+    float* targets;                   /* [Pa + Pc] target actor | target critic */
+    int64_t* steps;                   /* device int64[3]: Adam update counts (actor, critic, reward) */
+    const float* actor_reward_params; /* reward net the actor loss differentiates through
+                                         (sam_agent.py:88,192); NULL when d_actor_loss_scale == 0 */
+    const float *mu_mean, *mu_std;    /* agent obs statistics (sam_agent.py:150-156), NULL = off */
+    const float *d_mean, *d_std;      /* discriminator obs statistics (discriminator.py:67-72) */
+    float ac_high, gamma, polyak, clip_norm, actor_lr, critic_lr, d_lr, beta1, beta2, adam_eps;
+    float td_loss_scale, wd_scale, q_actor_loss_scale, d_actor_loss_scale, ent_reg_scale;
+} samx_learner;
+
+typedef struct samx_batch {  /* device inputs of one step; B rows each */
+    int64_t B;
+    /* discriminator update (sam.py:372-395): policy pairs, expert pairs, injected TF randoms */
+    const float *p_obs, *p_acs, *e_obs, *e_acs, *eps_ob, *eps_ac, *real_labels, *fake_labels;
+    /* agent update (sam_agent.py:634-660): replayed transitions; iws NULL = uniform, td_len NULL = 1 */
+    const float *obs0, *acs, *rews, *dones1, *obs1, *iws, *td_len;
+} samx_batch;
+
+typedef struct samx_step_out {
+    float* d_losses;      /* [8]  discriminator.py:145-158 */
+    float* actor_losses;  /* [3]  sam_agent.py:418-430 */
+    float* critic_losses; /* [3]  sam_agent.py:479-517 */
+    float* targ_q;        /* [B]  sam_agent.py:651-654 */
+    float* td;            /* [B]  pre-update TD errors, or NULL */
+} samx_step_out;
+
+int samx_fused_supported(const samx_learner* L, int64_t B);
+size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
+
+/* d.get_grads/get_losses + mu's get_targ_q / actor & critic losses and grads (sam.py:398-399,
+ * sam_agent.py:651-687): fills learner.grads and the outputs, advances the three device step
+ * counters, leaves the per-optimiser gradient norms in the workspace. */
+int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_step_out* out, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* d.optimize + actor/critic optimize + update_target_net (sam.py:402,433; sam_agent.py:690-691):
+ * mode bit 0: write learner.clipped = grads clipped by their own norm (tf_util.py:137-151);
+ * mode bit 1: grads * grad_scale -> clip_by_global_norm -> Adam -> Polyak on the agent's targets;
+ * mode bit 2: recompute the norms first (set it when grads changed after samx_step_grads, i.e. after
+ * the all-reduce).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
+ * grad_scale = 1/N.  `ws` must be the workspace samx_step_grads used, B the same batch size. */
+int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale, void* ws,
+                    size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

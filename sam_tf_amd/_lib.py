@@ -24,6 +24,34 @@ class MlpDesc(C.Structure):
 _P, _I64, _I32, _F, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_size_t
 _MP = C.POINTER(MlpDesc)
 
+
+class Learner(C.Structure):
+    """Mirror of `struct samx_learner`."""
+    _fields_ = ([('actor', MlpDesc), ('critic', MlpDesc), ('reward', MlpDesc),
+                 ('ob_dim', C.c_int32), ('ac_dim', C.c_int32)] +
+                [(k, C.c_void_p) for k in ('params', 'grads', 'clipped', 'adam_m', 'adam_v', 'targets',
+                                           'steps', 'actor_reward_params', 'mu_mean', 'mu_std', 'd_mean',
+                                           'd_std')] +
+                [(k, C.c_float) for k in ('ac_high', 'gamma', 'polyak', 'clip_norm', 'actor_lr',
+                                          'critic_lr', 'd_lr', 'beta1', 'beta2', 'adam_eps',
+                                          'td_loss_scale', 'wd_scale', 'q_actor_loss_scale',
+                                          'd_actor_loss_scale', 'ent_reg_scale')])
+
+
+class Batch(C.Structure):
+    """Mirror of `struct samx_batch`."""
+    _fields_ = [('B', C.c_int64)] + [(k, C.c_void_p) for k in (
+        'p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
+        'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')]
+
+
+class StepOut(C.Structure):
+    """Mirror of `struct samx_step_out`."""
+    _fields_ = [(k, C.c_void_p) for k in ('d_losses', 'actor_losses', 'critic_losses', 'targ_q', 'td')]
+
+
+_LP, _BP, _OP = C.POINTER(Learner), C.POINTER(Batch), C.POINTER(StepOut)
+
 # name -> (restype, argtypes); must list every symbol include/samx.h declares
 SIGNATURES = {
     'samx_last_error': (C.c_char_p, []),
@@ -59,6 +87,10 @@ SIGNATURES = {
     'samx_disc_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int,
                                  _F, _P, _P, _P, _SZ, _P]),
     'samx_reward': (C.c_int, [_MP, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P, _P, _SZ, _P]),
+    'samx_fused_supported': (C.c_int, [_LP, _I64]),
+    'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
+    'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),
+    'samx_step_apply': (C.c_int, [_LP, _I64, C.c_int, _F, _P, _SZ, _P]),
 }
 
 _lib = None

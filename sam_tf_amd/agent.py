@@ -73,10 +73,21 @@ class SAMAgent(object):
         rs = np.random.RandomState(hps.seed + 104729)
         init = np.concatenate([init_flat(self.da, rs, 'actor', hps.hid_w_init),
                                init_flat(self.dc, rs, 'critic', hps.hid_w_init)])
-        self.params = torch.as_tensor(init).to(self.device)
-        self.targets = torch.zeros_like(self.params)
-        self.grads = torch.zeros_like(self.params)
-        self.clipped = torch.zeros_like(self.params)
+        # learner-wide flat state [actor | critic | reward-net]: the discriminator's vectors are
+        # re-homed into it so that ONE all-reduce / ONE optimiser launch serve the whole step
+        self.L = ops.LearnerState(self.da, self.dc, d.desc, self.ob_dim, self.ac_dim, dict(
+            ac_high=self.ac_high, gamma=hps.gamma, polyak=hps.polyak,
+            clip_norm=hps.clip_norm if hps.clip_norm else 0.0, actor_lr=hps.actor_lr,
+            critic_lr=hps.critic_lr, d_lr=hps.d_lr, beta1=0.9, beta2=0.999, adam_eps=1e-8,
+            td_loss_scale=hps.td_loss_1_scale, wd_scale=hps.wd_scale,
+            q_actor_loss_scale=hps.q_actor_loss_scale, d_actor_loss_scale=hps.d_actor_loss_scale,
+            ent_reg_scale=hps.ent_reg_scale), device=self.device)
+        L = self.L
+        Pac = self.Pa + self.Pc
+        self.params, self.targets = L.params[:Pac], L.targets
+        self.grads, self.clipped = L.grads[:Pac], L.clipped[:Pac]
+        self.params.copy_(torch.as_tensor(init).to(self.device))
+        d.rebind(L.seg(L.params, 2), L.seg(L.grads, 2), L.seg(L.m, 2), L.seg(L.v, 2), L.steps[2:3])
         a, c = slice(0, self.Pa), slice(self.Pa, self.Pa + self.Pc)
         self.actor = FlatNet(self.scope, 'online_actor', self.da, self.params[a])
         self.critic = FlatNet(self.scope, 'online_critic', self.dc, self.params[c])
@@ -97,12 +108,17 @@ class SAMAgent(object):
         else:
             self.d_params = None
 
+        L.set_ptr('actor_reward_params', self.d_params)
         if hps.rmsify_obs:
             self.obs_rms = DeviceRunningMeanStd(shape=self.ob_shape, device=self.device)
+            L.set_ptr('mu_mean', self.obs_rms.mean); L.set_ptr('mu_std', self.obs_rms.std)
+            L.set_ptr('d_mean', d.obs_rms.mean); L.set_ptr('d_std', d.obs_rms.std)
 
         self.setup_replay_buffer()
-        actor_opt = MpiAdam(comm, self.actor.flat, hps.clip_norm, hps.actor_lr, name='actor_adam')
-        critic_opt = MpiAdam(comm, self.critic.flat, hps.clip_norm, hps.critic_lr, name='critic_adam')
+        actor_opt = MpiAdam(comm, self.actor.flat, hps.clip_norm, hps.actor_lr, name='actor_adam',
+                            m=L.seg(L.m, 0), v=L.seg(L.v, 0), t_dev=L.steps[0:1])
+        critic_opt = MpiAdam(comm, self.critic.flat, hps.clip_norm, hps.critic_lr, name='critic_adam',
+                             m=L.seg(L.m, 1), v=L.seg(L.v, 1), t_dev=L.steps[1:2])
         self.actor_ops = {'names': ['actor_q_loss', 'actor_d_loss', 'actor_total_loss'],
                           'optimizer': actor_opt}
         names = ['critic_td_loss_1', 'critic_wd', 'critic_total_loss']

@@ -10,7 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libsamx.so')
-SOURCES = ['core.hip', 'tree.hip', 'replay.hip', 'optim.hip', 'gemm.hip', 'nets.hip']
+SOURCES = ['core.hip', 'tree.hip', 'replay.hip', 'optim.hip', 'gemm.hip', 'nets.hip',
+           'fused_small.hip', 'step.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,105 @@
+// Internal interface of the whole-network fused kernels (fused_small.hip) used by step.hip.
+#pragma once
+#include "samx_common.h"
+#include "../../include/samx.h"
+
+namespace samx {
+namespace fused {
+
+constexpr int kRows = 16;          // batch rows per workgroup
+constexpr int kMaxSegBlocks = 64;  // blocks (and sum-of-squares partials) per optimiser segment
+
+struct AgentArgs {
+    // inputs (device): batch rows
+    const float *obs0, *acs, *rews, *dones1, *obs1, *iws, *td_len, *mean, *stdv;
+    // parameters (device, flat)
+    const float *actor, *critic, *targ_actor, *targ_critic, *reward;
+    int ob, ac;
+    int64_t B;
+    float high, gamma, td_scale, q_scale, d_scale;
+    // outputs
+    float *targ_q_out, *td_out;
+    float* partials;  // [B/16][P] slots, P = Pa + Pc
+    int64_t P, Pa;
+    float* loss_part;  // [B/16][4]: sum huber*iw, sum Q, sum D, (block 0) sum W1^2 + W2^2 of the critic
+};
+
+struct DiscArgs {
+    const float *p_obs, *p_acs, *e_obs, *e_acs, *eps_ob, *eps_ac, *real, *fake, *mean, *stdv;
+    const float* params;
+    int ob, ac;
+    int64_t B;
+    float ent_scale, gp_coeff;
+    float* partials;   // [3B/16][P] slots
+    int64_t P;
+    float* loss_part;  // [2B/16][4]: sum ce, sum entropy-CE, sum sigmoid
+    double* gp_part;   // [B/16][2]: sum g_ob^2, sum g_ac^2
+    float* gp_out;     // [1]: (N-1)^2
+};
+
+struct Segment {
+    const float* partials;  // first slot, already offset to this segment
+    int64_t slot_stride;
+    int nslots;
+    int64_t n;
+    float* grad;
+    float* sumsq;  // [nblocks]
+    int nblocks;
+    // weight decay: grad += wd * param on two index ranges (critic hidden kernels)
+    float wd;
+    const float* param;
+    int64_t wd0_lo, wd0_hi, wd1_lo, wd1_hi;
+    int64_t* step_dev;  // ticked once per finalize
+};
+
+struct FinalizeArgs {
+    Segment seg[3];
+    int nseg;
+    int64_t B;
+    // agent losses
+    const float* agent_loss_part;
+    int agent_tiles;
+    float q_scale, d_scale, td_scale, wd_scale;
+    float *actor_losses, *critic_losses;
+    // discriminator losses
+    const float* disc_loss_part;
+    int disc_tiles_b;
+    float ent_scale, gp_coeff;
+    const float* gp;
+    float* disc_losses;
+};
+
+struct ApplySeg {
+    float *param, *m, *v, *targ, *clipped;
+    const float* grad;
+    float* sumsq;
+    int nsumsq;
+    int64_t n;
+    int nblocks;
+    float lr, clip;
+    const int64_t* step_dev;
+};
+
+struct ApplyArgs {
+    ApplySeg seg[3];
+    int nseg;
+    int mode;  // bit 0: write clipped gradient, bit 1: Adam (+Polyak)
+    float grad_scale, beta1, beta2, eps, tau;
+};
+
+bool supported(const samx_mlp* d, int64_t B);
+int seg_blocks(int64_t n);
+struct StepArgs {
+    AgentArgs a;
+    DiscArgs d;
+    int n_a, n_tc, n_disc;  // workgroups per role: actor tiles, target+critic tiles, D tiles (3B/16)
+};
+// agent roles + discriminator first kernel in ONE launch, then the discriminator's second kernel
+int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
+int launch_finalize(const FinalizeArgs& f, hipStream_t st);
+int launch_apply(const ApplyArgs& f, hipStream_t st);
+int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st);
+int launch_tick(int64_t* a, int64_t* b, int64_t* c, hipStream_t st);
+
+}  // namespace fused
+}  // namespace samx

@@ -1,0 +1,908 @@
+// Whole-network fused kernels for the small configurations (64x64 MLPs, inputs <= 64 wide).
+//
+// One workgroup (4 waves) owns R = 16 batch rows and runs the ENTIRE pass for them — observation
+// normalisation, every layer forward, losses, backward to the inputs, and the per-row-block weight
+// gradients — with all weights and activations staged in LDS and every matmul on
+// v_mfma_f32_16x16x4_f32 (exact f32).  Each workgroup writes its weight-gradient contribution to its
+// own slot of a partials buffer; `finalize` adds the slots in a fixed order (deterministic, no float
+// atomics), `apply` clips and runs Adam/Polyak for up to three optimisers in one launch.
+//
+// A 64-wide SAM step is launch/latency bound (54 MFLOP, <1 MB touched): the point of this file is
+// to do it in ~6 launches instead of ~57.
+//
+// LDS layout rule: every matrix (activations [16][*], weights [K][64]) uses a row pitch == 17 mod 32
+// floats.  With that pitch all three MFMA operand access patterns used here (row-major A, row-major
+// B, transposed B) touch 31-32 distinct banks per 32-lane half.
+//
+// Reference semantics: sam_agent.py:145-205,406-520 ; discriminator.py:61-161 ;
+// networks.py:45-72,222-404 ; mpi_adam.py:18-36 ; tf_util.py:137-151.
+#include "samx_common.h"
+#include "fused_small.h"
+#include <math.h>
+
+namespace samx {
+namespace fused {
+namespace {
+
+constexpr int H = 64;     // hidden width (both layers)
+constexpr int LD = 81;    // LDS pitch of 64-wide matrices (== 17 mod 32)
+constexpr int LD3 = 17;   // pitch of the head matrix W3[64][out<=16]
+constexpr int R = 16;     // batch rows per workgroup
+constexpr int NT = 256;   // threads per workgroup
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lrelu(float z) { return fmaxf(z, 0.2f * z); }
+__device__ __forceinline__ float dlrelu(float a) { return a >= 0.f ? 1.f : 0.2f; }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// accumulator element j of lane l  <->  C[row = (l>>4)*4 + j][col = l & 15]
+
+// C = A[16 x K4] * W[K4 x 16 cols from col0]   (A row-major pitch lda, W row-major pitch ldw)
+__device__ __forceinline__ f32x4 tile_nn(const float* A, int lda, const float* W, int ldw, int K4,
+                                         int col0, int lane) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+    int k = 0;
+    for (; k + 8 <= K4; k += 8) {
+        a0 = mfma4(A[r * lda + k + kq], W[(k + kq) * ldw + col0 + r], a0);
+        a1 = mfma4(A[r * lda + k + 4 + kq], W[(k + 4 + kq) * ldw + col0 + r], a1);
+    }
+    for (; k < K4; k += 4) a0 = mfma4(A[r * lda + k + kq], W[(k + kq) * ldw + col0 + r], a0);
+    return a0 + a1;
+}
+
+// C = A[16 x K4] * W^T, W rows row0..row0+15 (pitch ldw): C[r][c] = sum_k A[r][k] W[row0 + c][k]
+__device__ __forceinline__ f32x4 tile_nt(const float* A, int lda, const float* W, int ldw, int K4,
+                                         int row0, int lane) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+    int k = 0;
+    for (; k + 8 <= K4; k += 8) {
+        a0 = mfma4(A[r * lda + k + kq], W[(row0 + r) * ldw + k + kq], a0);
+        a1 = mfma4(A[r * lda + k + 4 + kq], W[(row0 + r) * ldw + k + 4 + kq], a1);
+    }
+    for (; k < K4; k += 4) a0 = mfma4(A[r * lda + k + kq], W[(row0 + r) * ldw + k + kq], a0);
+    return a0 + a1;
+}
+
+// K = 64 forms, fully unrolled: all 32 LDS reads are issued ahead of the 16 MFMAs
+__device__ __forceinline__ f32x4 tile_nn64(const float* A, const float* W, int col0, int lane) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const float* pa = A + (lane & 15) * LD + (lane >> 4);
+    const float* pw = W + (lane >> 4) * LD + col0 + (lane & 15);
+#pragma unroll
+    for (int k = 0; k < H; k += 8) {
+        a0 = mfma4(pa[k], pw[k * LD], a0);
+        a1 = mfma4(pa[k + 4], pw[(k + 4) * LD], a1);
+    }
+    return a0 + a1;
+}
+__device__ __forceinline__ f32x4 tile_nt64(const float* A, const float* W, int row0, int lane) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const float* pa = A + (lane & 15) * LD + (lane >> 4);
+    const float* pw = W + (row0 + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < H; k += 8) {
+        a0 = mfma4(pa[k], pw[k], a0);
+        a1 = mfma4(pa[k + 4], pw[k + 4], a1);
+    }
+    return a0 + a1;
+}
+
+// C[i][j] = sum_{r<16} X[r][i0 + i] * D[r][j0 + j]   (weight gradient of one 16x16 block)
+__device__ __forceinline__ f32x4 tile_tn(const float* X, int ldx, int i0, const float* D, int ldd, int j0,
+                                         int lane) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+    const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < R; k += 4) a0 = mfma4(X[(k + kq) * ldx + i0 + c], D[(k + kq) * ldd + j0 + c], a0);
+    return a0;
+}
+
+struct NetL {  // one network's parameters in LDS
+    float *W1, *b1, *W2, *b2, *W3, *b3;
+    int in, k4, out;
+};
+
+__host__ __device__ inline int net_lds_floats(int in, int out) {
+    const int k4 = (in + 3) / 4 * 4;
+    return k4 * LD + H + H * LD + H + H * LD3 + 16 + (out > 0 ? 0 : 0);
+}
+
+__device__ inline NetL carve_net(float*& p, int in, int out) {
+    NetL n;
+    n.in = in; n.k4 = (in + 3) / 4 * 4; n.out = out;
+    n.W1 = p; p += n.k4 * LD;
+    n.b1 = p; p += H;
+    n.W2 = p; p += H * LD;
+    n.b2 = p; p += H;
+    n.W3 = p; p += H * LD3;
+    n.b3 = p; p += 16;
+    return n;
+}
+
+// global flat [W1 b1 W2 b2 W3 b3] -> padded LDS image (all threads; caller syncs)
+__device__ inline void load_net(const NetL& n, const float* __restrict__ g) {
+    const int tid = threadIdx.x;
+    const float* gW1 = g;
+    const float* gb1 = gW1 + n.in * H;
+    const float* gW2 = gb1 + H;
+    const float* gb2 = gW2 + H * H;
+    const float* gW3 = gb2 + H;
+    const float* gb3 = gW3 + H * n.out;
+    for (int t = tid; t < n.k4 * H; t += NT) {
+        const int k = t >> 6, c = t & 63;
+        n.W1[k * LD + c] = k < n.in ? gW1[t] : 0.f;
+    }
+    for (int t = tid; t < H * H; t += NT) n.W2[(t >> 6) * LD + (t & 63)] = gW2[t];
+    for (int t = tid; t < H * 16; t += NT) {
+        const int k = t >> 4, c = t & 15;
+        n.W3[k * LD3 + c] = c < n.out ? gW3[k * n.out + c] : 0.f;
+    }
+    if (tid < H) { n.b1[tid] = gb1[tid]; n.b2[tid] = gb2[tid]; }
+    if (tid < 16) n.b3[tid] = tid < n.out ? gb3[tid] : 0.f;
+}
+
+// out[16][64] = lrelu(in[16][K4] * W + b)          (all 4 waves, one 16-col tile each)
+__device__ inline void layer_fwd(const float* in, int K4, const float* W, const float* b, float* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 acc = K4 == H ? tile_nn64(in, W, 16 * w, lane) : tile_nn(in, LD, W, LD, K4, 16 * w, lane);
+    const int c = 16 * w + (lane & 15), r0 = (lane >> 4) * 4;
+    const float bb = b[c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(r0 + j) * LD + c] = lrelu(acc[j] + bb);
+}
+
+// tangent / masked linear map: out = (in * W) .* lrelu'(mask_src)   (no bias); out may alias mask_src
+__device__ inline void layer_tan(const float* in, int K4, const float* W, const float* mask_src, float* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 acc = K4 == H ? tile_nn64(in, W, 16 * w, lane) : tile_nn(in, LD, W, LD, K4, 16 * w, lane);
+    const int c = 16 * w + (lane & 15), r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(r0 + j) * LD + c] = acc[j] * dlrelu(mask_src[(r0 + j) * LD + c]);
+}
+
+// dZ1[16][64] = (dZ2[16][64] * W2^T) .* lrelu'(A1)
+__device__ inline void layer_bwd(const float* dZ2, const float* W2, const float* A1, float* dZ1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 acc = tile_nt64(dZ2, W2, 16 * w, lane);
+    const int c = 16 * w + (lane & 15), r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dZ1[(r0 + j) * LD + c] = acc[j] * dlrelu(A1[(r0 + j) * LD + c]);
+}
+
+// s[r] = <A2[r], W3[:,0]> + b3[0] for the 16 rows; every thread gets nothing back, result in sh_s[16]
+__device__ inline void head_dot(const float* A2, const NetL& n, float* sh_s) {
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, q = tid & 15;  // 16 threads per row
+    float acc = 0.f;
+#pragma unroll
+    for (int c = q; c < H; c += 16) acc = fmaf(A2[r * LD + c], n.W3[c * LD3], acc);
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if (q == 0) sh_s[r] = acc + n.b3[0];
+}
+
+// dZ2[r][c] = dq[r] * w3[c] * lrelu'(A2[r][c])
+__device__ inline void head_bwd(const float* dq, const NetL& n, const float* A2, float* dZ2) {
+    for (int t = threadIdx.x; t < R * H; t += NT) {
+        const int r = t >> 6, c = t & 63;
+        dZ2[r * LD + c] = dq[r] * n.W3[c * LD3] * dlrelu(A2[r * LD + c]);
+    }
+}
+
+// partial weight gradient of a [nI x 64] matrix + its bias: dst[i*64 + j], dst_b[j]
+__device__ inline void wgrad64(const float* X, int nI, const float* dZ, float* __restrict__ dstW,
+                               float* __restrict__ dstb, int ones_rows) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ti = (nI + 15) / 16;
+    for (int t = w; t < ti * 4; t += 4) {
+        const int i0 = (t >> 2) * 16, j0 = (t & 3) * 16;
+        f32x4 acc = tile_tn(X, LD, i0, dZ, LD, j0, lane);
+        const int c = j0 + (lane & 15), r0 = i0 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + j < nI) dstW[(r0 + j) * H + c] = acc[j];
+    }
+    if (dstb && threadIdx.x < H) {
+        float s = 0.f;
+        for (int r = 0; r < ones_rows; ++r) s += dZ[r * LD + threadIdx.x];
+        dstb[threadIdx.x] = s;
+    }
+}
+
+// head of a 1-output net: dW3[c] = sum_r A2[r][c] * dq[r], db3 = sum_{r < ones_rows} dq[r]
+__device__ inline void wgrad_head1(const float* A2, const float* dq, float* __restrict__ dstW,
+                                   float* __restrict__ dstb, int ones_rows) {
+    const int tid = threadIdx.x;
+    if (tid < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s = fmaf(A2[r * LD + tid], dq[r], s);
+        dstW[tid] = s;
+    }
+    if (tid == H) {
+        float s = 0.f;
+        for (int r = 0; r < ones_rows; ++r) s += dq[r];
+        dstb[0] = s;
+    }
+}
+
+// normalised observation rows (+ optional action columns) into XC[16][LD]; columns beyond are zero
+__device__ inline void load_rows(float* XC, const float* __restrict__ obs, const float* __restrict__ acs,
+                                 const float* __restrict__ mean, const float* __restrict__ stdv, int ob,
+                                 int ac, int64_t row0) {
+    for (int t = threadIdx.x; t < R * LD; t += NT) {
+        const int r = t / LD, c = t % LD;
+        float v = 0.f;
+        if (c < ob) {
+            v = obs[(row0 + r) * ob + c];
+            if (mean) v = fminf(fmaxf((v - mean[c]) / stdv[c], -5.f), 5.f);
+        } else if (acs && c < ob + ac) {
+            v = acs[(row0 + r) * ac + (c - ob)];
+        }
+        XC[t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Agent roles, 16 rows per workgroup.  Two independent roles run side by side in the step kernel:
+//   TC : TD target on the target nets (obs1), then critic loss + gradient (obs0, batch actions)
+//   A  : actor loss + gradient through the critic (and the reward net when d_scale != 0)
+// ------------------------------------------------------------------------------------------------
+struct AgentLds {
+    NetL nA, nC, nD;
+    float *XC, *A1a, *A2a, *A1c, *A2c, *DZa, *DZb, *PRE, *s_, *tq, *dq, *red;
+};
+
+__device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d) {
+    AgentLds L;
+    L.nA = carve_net(p, ob, ac);
+    L.nC = carve_net(p, ob + ac, 1);
+    L.nD = L.nC;
+    if (use_d) L.nD = carve_net(p, ob + ac, 1);
+    L.XC = p; p += R * LD;
+    L.A1a = p; p += R * LD;
+    L.A2a = p; p += R * LD;
+    L.A1c = p; p += R * LD;
+    L.A2c = p; p += R * LD;
+    L.DZa = p; p += R * LD;
+    L.DZb = p; p += R * LD;
+    L.PRE = p; p += R * LD3;
+    L.s_ = p; L.tq = p + 16; L.dq = p + 32; L.red = p + 48;
+    return L;
+}
+
+// actor head: 16 x ac tile, tanh * high, clipped (sam_agent.py:177), into the action columns of XC
+__device__ inline void actor_head(const AgentLds& L, int ob, int ac, float high) {
+    const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) == 0) {
+        f32x4 acc = tile_nn(L.A2a, LD, L.nA.W3, LD3, H, 0, lane);
+        const int c = lane & 15, r0 = (lane >> 4) * 4;
+        if (c < ac) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = high * tanhf(acc[j] + L.nA.b3[c]);
+                L.XC[(r0 + j) * LD + ob + c] = fminf(fmaxf(v, -high), high);
+            }
+        }
+    }
+}
+
+__device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac, in_c = ob + ac;
+    AgentLds L = carve_agent_lds(lds, ob, ac, false);
+    float* gC = a.partials + (int64_t)wg * a.P + a.Pa;  // critic part of this tile's gradient slot
+    const int64_t cW1 = 0, cb1 = cW1 + (int64_t)in_c * H, cW2 = cb1 + H, cb2 = cW2 + H * H, cW3 = cb2 + H,
+                  cb3 = cW3 + H;
+    // ---- TD target: rews + gamma^len (1 - done) Q'(obz1, mu'(obz1))   (sam_agent.py:196-205)
+    load_net(L.nA, a.targ_actor);
+    load_net(L.nC, a.targ_critic);
+    load_rows(L.XC, a.obs1, nullptr, a.mean, a.stdv, ob, 0, row0);
+    __syncthreads();
+    layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
+    __syncthreads();
+    layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
+    __syncthreads();
+    actor_head(L, ob, ac, a.high);
+    __syncthreads();
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
+    __syncthreads();
+    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    __syncthreads();
+    head_dot(L.A2c, L.nC, L.s_);
+    __syncthreads();
+    if (tid < R) {
+        const int64_t g = row0 + tid;
+        const float gam = a.td_len ? powf(a.gamma, a.td_len[g]) : a.gamma;
+        const float t = a.rews[g] + gam * ((1.f - a.dones1[g]) * L.s_[tid]);
+        L.tq[tid] = t;
+        a.targ_q_out[g] = t;
+    }
+    // ---- critic loss + gradient (sam_agent.py:457-520)
+    load_net(L.nC, a.critic);  // every read of the target critic finished before the last barrier
+    load_rows(L.XC, a.obs0, a.acs, a.mean, a.stdv, ob, ac, row0);
+    __syncthreads();
+    if (wg == 0) {
+        // sum of squares of the decayed critic kernels for the weight-decay loss term
+        // (network_util.py:43-56); padded LDS rows are zero
+        double acc = 0.0;
+        for (int t = tid; t < L.nC.k4 * H; t += NT) { const float w = L.nC.W1[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int t = tid; t < H * H; t += NT) { const float w = L.nC.W2[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) L.red[wv] = (float)acc;
+    }
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
+    __syncthreads();
+    if (wg == 0 && tid == 0) a.loss_part[3] = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    __syncthreads();
+    head_dot(L.A2c, L.nC, L.s_);
+    __syncthreads();
+    if (tid < R) {
+        const int64_t g = row0 + tid;
+        const float td = L.s_[tid] - L.tq[tid];
+        const float iw = a.iws ? a.iws[g] : 1.f;
+        const float ad = fabsf(td);
+        const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;         // math_util.py:22-29
+        const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
+        L.dq[tid] = (a.td_scale / (float)a.B) * dh * iw;
+        L.red[tid] = hub * iw;
+        if (a.td_out) a.td_out[g] = td;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += L.red[r];
+        a.loss_part[wg * 4 + 0] = s;  // sum of huber*iw over this tile's rows
+    }
+    head_bwd(L.dq, L.nC, L.A2c, L.DZa);
+    wgrad_head1(L.A2c, L.dq, gC + cW3, gC + cb3, R);
+    __syncthreads();
+    wgrad64(L.A1c, H, L.DZa, gC + cW2, gC + cb2, R);
+    layer_bwd(L.DZa, L.nC.W2, L.A1c, L.DZb);
+    __syncthreads();
+    wgrad64(L.XC, in_c, L.DZb, gC + cW1, gC + cb1, R);
+}
+
+__device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac;
+    const bool use_d = a.d_scale != 0.f;
+    AgentLds L = carve_agent_lds(lds, ob, ac, use_d);
+    float* gA = a.partials + (int64_t)wg * a.P;  // actor part of this tile's gradient slot
+    const int64_t aW1 = 0, ab1 = aW1 + (int64_t)ob * H, aW2 = ab1 + H, ab2 = aW2 + H * H, aW3 = ab2 + H,
+                  ab3 = aW3 + (int64_t)H * ac;
+    load_net(L.nA, a.actor);
+    load_net(L.nC, a.critic);
+    if (use_d) load_net(L.nD, a.reward);
+    load_rows(L.XC, a.obs0, nullptr, a.mean, a.stdv, ob, 0, row0);
+    __syncthreads();
+    layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
+    __syncthreads();
+    layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
+    __syncthreads();
+    actor_head(L, ob, ac, a.high);
+    __syncthreads();
+    // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
+    __syncthreads();
+    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    __syncthreads();
+    head_dot(L.A2c, L.nC, L.s_);
+    if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += L.s_[r];
+        a.loss_part[wg * 4 + 1] = s;  // sum of Q(s, mu(s))
+    }
+    head_bwd(L.dq, L.nC, L.A2c, L.DZa);
+    __syncthreads();
+    layer_bwd(L.DZa, L.nC.W2, L.A1c, L.DZb);
+    __syncthreads();
+    // dQ/da = dZ1c * W1c[ob:ob+ac, :]^T   (wave 0, one tile)
+    f32x4 dA = {0.f, 0.f, 0.f, 0.f};
+    if (wv == 0) dA = tile_nt64(L.DZb, L.nC.W1, ob, lane);
+    __syncthreads();
+    if (use_d) {  // D branch: -d_scale * mean D(obz0, mu(obz0))   (sam_agent.py:421-422)
+        layer_fwd(L.XC, L.nD.k4, L.nD.W1, L.nD.b1, L.A1c);
+        __syncthreads();
+        layer_fwd(L.A1c, H, L.nD.W2, L.nD.b2, L.A2c);
+        __syncthreads();
+        head_dot(L.A2c, L.nD, L.s_);
+        if (tid < R) L.dq[tid] = -a.d_scale / (float)a.B;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += L.s_[r];
+            a.loss_part[wg * 4 + 2] = s;
+        }
+        head_bwd(L.dq, L.nD, L.A2c, L.DZa);
+        __syncthreads();
+        layer_bwd(L.DZa, L.nD.W2, L.A1c, L.DZb);
+        __syncthreads();
+        if (wv == 0) dA += tile_nt64(L.DZb, L.nD.W1, ob, lane);
+        __syncthreads();
+    } else if (tid == 0) {
+        a.loss_part[wg * 4 + 2] = 0.f;
+    }
+    if (wv == 0) {  // through clip (identity inside the range) and tanh
+        const int c = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.f;
+            if (c < ac) {
+                const float t = L.XC[(r0 + j) * LD + ob + c] / a.high;
+                v = dA[j] * (a.high * (1.f - t * t));
+            }
+            L.PRE[(r0 + j) * LD3 + c] = v;
+        }
+    }
+    __syncthreads();
+    {   // actor head gradient: dW3a[i][c] = sum_r A2a[r][i] * PRE[r][c]
+        f32x4 acc = tile_tn(L.A2a, LD, 16 * wv, L.PRE, LD3, 0, lane);
+        const int c = lane & 15, r0 = 16 * wv + (lane >> 4) * 4;
+        if (c < ac) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gA[aW3 + (int64_t)(r0 + j) * ac + c] = acc[j];
+        }
+        if (tid < ac) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += L.PRE[r * LD3 + tid];
+            gA[ab3 + tid] = s;
+        }
+    }
+    {   // dZ2a = (PRE * W3a^T) .* lrelu'(A2a) : reduction over the (zero-padded) action index
+        f32x4 acc = tile_nt(L.PRE, LD3, L.nA.W3, LD3, 16, 16 * wv, lane);
+        const int c = 16 * wv + (lane & 15), r0 = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L.DZa[(r0 + j) * LD + c] = acc[j] * dlrelu(L.A2a[(r0 + j) * LD + c]);
+    }
+    __syncthreads();
+    wgrad64(L.A1a, H, L.DZa, gA + aW2, gA + ab2, R);
+    layer_bwd(L.DZa, L.nA.W2, L.A1a, L.DZb);
+    __syncthreads();
+    wgrad64(L.XC, ob, L.DZb, gA + aW1, gA + ab1, R);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Discriminator, first kernel.  Row tiles [0, 2B/16): policy / expert pairs — forward, BCE(+entropy)
+// terms, full backward, weight-gradient slot.  Tiles [2B/16, 3B/16): interpolates — forward, the
+// input gradient g = d score / d input, and this tile's share of sum g_ob^2, sum g_ac^2.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int sect) {
+    // sect 0: policy rows, 1: expert rows, 2: eps*policy + (1-eps)*expert
+    const int ob = a.ob, ac = a.ac;
+    for (int t = threadIdx.x; t < R * LD; t += NT) {
+        const int r = t / LD, c = t % LD;
+        float v = 0.f;
+        const int64_t g = row0 + r;
+        if (c < ob + ac) {
+            float pv = 0.f, ev = 0.f;
+            if (c < ob) {
+                if (sect != 1) pv = a.p_obs[g * ob + c];
+                if (sect != 0) ev = a.e_obs[g * ob + c];
+                if (a.mean) {
+                    pv = fminf(fmaxf((pv - a.mean[c]) / a.stdv[c], -5.f), 5.f);
+                    ev = fminf(fmaxf((ev - a.mean[c]) / a.stdv[c], -5.f), 5.f);
+                }
+            } else {
+                if (sect != 1) pv = a.p_acs[g * ac + (c - ob)];
+                if (sect != 0) ev = a.e_acs[g * ac + (c - ob)];
+            }
+            if (sect == 0) v = pv;
+            else if (sect == 1) v = ev;
+            else {
+                const float e = c < ob ? a.eps_ob[g * ob + c] : a.eps_ac[g * ac + (c - ob)];
+                v = e * pv + (1.f - e) * ev;
+            }
+        }
+        XC[t] = v;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sig_ce(float x, float z) {
+    return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+// interpolate-row chain shared by both D kernels: forward, then g = ((w3.*m2) W2^T .* m1) W1^T
+// leaves A1/A2 (activations), DZa (= gz2), DZb (= gz1), G[16][LD] (input gradient)
+__device__ inline void disc_interp_chain(const NetL& n, float* XC, float* A1, float* A2, float* DZa,
+                                         float* DZb, float* G, float* ones) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    layer_fwd(XC, n.k4, n.W1, n.b1, A1);
+    __syncthreads();
+    layer_fwd(A1, H, n.W2, n.b2, A2);
+    if (threadIdx.x < R) ones[threadIdx.x] = 1.f;
+    __syncthreads();
+    head_bwd(ones, n, A2, DZa);
+    __syncthreads();
+    layer_bwd(DZa, n.W2, A1, DZb);
+    __syncthreads();
+    const int ti = (n.in + 15) / 16;
+    for (int t = wv; t < ti; t += 4) {
+        f32x4 acc = tile_nt(DZb, LD, n.W1, LD, H, 16 * t, lane);
+        const int c = 16 * t + (lane & 15), r0 = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) G[(r0 + j) * LD + c] = c < n.in ? acc[j] : 0.f;
+    }
+    __syncthreads();
+}
+
+__device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x;
+    const int tiles_b = (int)(a.B / R);
+    const int sect = wg / tiles_b;  // 0 policy, 1 expert, 2 interpolate
+    const int64_t row0 = (int64_t)(wg % tiles_b) * R;
+    const int in = a.ob + a.ac;
+    float* p = lds;
+    NetL n = carve_net(p, in, 1);
+    float* XC = p; p += R * LD;
+    float* A1 = p; p += R * LD;
+    float* A2 = p; p += R * LD;
+    float* DZa = p; p += R * LD;
+    float* DZb = p; p += R * LD;
+    float* sh = p; p += 96;
+    float* s_ = sh; float* dq = sh + 16; float* r0_ = sh + 32; float* r1_ = sh + 48; float* r2_ = sh + 64;
+    load_net(n, a.params);
+    disc_rows(XC, a, row0, sect);
+    __syncthreads();
+    if (sect == 2) {
+        float* Gbuf = p;  // sixth tile: the input gradient g
+        disc_interp_chain(n, XC, A1, A2, DZa, DZb, Gbuf, dq);
+        // this tile's sums of squares, observation and action columns separately (fixed order)
+        float so = 0.f, sa = 0.f;
+        if (tid < R) {
+            for (int c = 0; c < a.ob; ++c) so = fmaf(Gbuf[tid * LD + c], Gbuf[tid * LD + c], so);
+            for (int c = a.ob; c < in; ++c) sa = fmaf(Gbuf[tid * LD + c], Gbuf[tid * LD + c], sa);
+            r0_[tid] = so; r1_[tid] = sa;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double o = 0.0, c = 0.0;
+            for (int r = 0; r < R; ++r) { o += (double)r0_[r]; c += (double)r1_[r]; }
+            a.gp_part[2 * (wg - 2 * tiles_b)] = o;
+            a.gp_part[2 * (wg - 2 * tiles_b) + 1] = c;
+        }
+        return;
+    }
+    // ---- policy / expert rows
+    float* part = a.partials + (int64_t)wg * a.P;
+    const int64_t oW1 = 0, ob1 = (int64_t)in * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + H;
+    layer_fwd(XC, n.k4, n.W1, n.b1, A1);
+    __syncthreads();
+    layer_fwd(A1, H, n.W2, n.b2, A2);
+    __syncthreads();
+    head_dot(A2, n, s_);
+    __syncthreads();
+    if (tid < R) {
+        const int64_t g = row0 + tid;
+        const float s = s_[tid];
+        const float z = sect == 0 ? (a.fake ? a.fake[g] : 0.f) : (a.real ? a.real[g] : 1.f);
+        const float sg = sigmoidf_(s);
+        dq[tid] = (sg - z) / (float)a.B + a.ent_scale * s * sg * (1.f - sg) / (float)(2 * a.B);
+        r0_[tid] = sig_ce(s, z);
+        r1_[tid] = sig_ce(s, sg);
+        r2_[tid] = sg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float c = 0.f, e = 0.f, g = 0.f;
+        for (int r = 0; r < R; ++r) { c += r0_[r]; e += r1_[r]; g += r2_[r]; }
+        a.loss_part[wg * 4 + 0] = c;
+        a.loss_part[wg * 4 + 1] = e;
+        a.loss_part[wg * 4 + 2] = g;
+    }
+    head_bwd(dq, n, A2, DZa);
+    wgrad_head1(A2, dq, part + oW3, part + ob3, R);
+    __syncthreads();
+    wgrad64(A1, H, DZa, part + oW2, part + ob2, R);
+    layer_bwd(DZa, n.W2, A1, DZb);
+    __syncthreads();
+    wgrad64(XC, in, DZb, part + oW1, part + ob1, R);
+}
+
+// Discriminator, second kernel (interpolate tiles only): with the batch-wide norm N known, the
+// cotangent V = 10 * 2(N-1)/N * g / (B*dim) is pushed forward through the masks (tangent pass) and
+// the gradient-penalty part of the weight gradient is written to this tile's slot:
+//   dW1 += V^T gz1,  dW2 += a1dot^T gz2,  dw3 += sum_r a2dot     (no bias terms)
+__global__ __launch_bounds__(NT) void disc2_kernel(DiscArgs a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x;
+    const int tiles_b = (int)(a.B / R);
+    const int64_t row0 = (int64_t)wg * R;
+    const int in = a.ob + a.ac;
+    float* p = lds;
+    NetL n = carve_net(p, in, 1);
+    float* XC = p; p += R * LD;
+    float* A1 = p; p += R * LD;
+    float* A2 = p; p += R * LD;
+    float* DZa = p; p += R * LD;
+    float* DZb = p; p += R * LD;
+    float* sh = p; p += 96;
+    float* G = p; p += R * LD;
+    float* ones = sh + 16;
+    float* coef = sh + 32;
+    load_net(n, a.params);
+    disc_rows(XC, a, row0, 2);
+    if (tid == 0) {
+        double so = 0.0, sa = 0.0;
+        for (int i = 0; i < tiles_b; ++i) { so += a.gp_part[2 * i]; sa += a.gp_part[2 * i + 1]; }
+        const double mo = so / ((double)a.B * a.ob), ma = sa / ((double)a.B * a.ac);
+        const double N = sqrt(mo + ma);
+        const double k = (double)a.gp_coeff * 2.0 * (N - 1.0) / N;
+        coef[0] = (float)(k / ((double)a.B * a.ob));
+        coef[1] = (float)(k / ((double)a.B * a.ac));
+        if (wg == 0) a.gp_out[0] = (float)((N - 1.0) * (N - 1.0));
+    }
+    __syncthreads();
+    disc_interp_chain(n, XC, A1, A2, DZa, DZb, G, ones);
+    // V = coef .* g, in place over G (columns beyond `in` are already zero)
+    for (int t = tid; t < R * LD; t += NT) {
+        const int c = t % LD;
+        G[t] = G[t] * (c < a.ob ? coef[0] : coef[1]);
+    }
+    __syncthreads();
+    float* part = a.partials + (int64_t)(2 * tiles_b + wg) * a.P;
+    const int64_t oW1 = 0, ob1 = (int64_t)in * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + H;
+    wgrad64(G, in, DZb, part + oW1, nullptr, 0);                 // V^T gz1
+    layer_tan(G, n.k4, n.W1, A1, A1);                            // a1dot = (V W1) .* m1  (in place)
+    if (tid < H) { part[ob1 + tid] = 0.f; part[ob2 + tid] = 0.f; }
+    if (tid == 0) part[ob3] = 0.f;
+    __syncthreads();
+    wgrad64(A1, H, DZa, part + oW2, nullptr, 0);                 // a1dot^T gz2
+    layer_tan(A1, H, n.W2, A2, A2);                              // a2dot = (a1dot W2) .* m2
+    __syncthreads();
+    if (tid < H) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += A2[r * LD + tid];
+        part[oW3 + tid] = s;
+    }
+}
+
+// One launch for every gradient pass of the step that needs no grid-wide value: the two agent roles
+// and the discriminator's first kernel are independent, so their workgroups share the chip.
+// Longest role first.
+__global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
+    extern __shared__ float lds[];
+    int b = blockIdx.x;
+    if (b < s.n_a) { agent_a_body(s.a, b, lds); return; }
+    b -= s.n_a;
+    if (b < s.n_tc) { agent_tc_body(s.a, b, lds); return; }
+    b -= s.n_tc;
+    disc1_body(s.d, b, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: grad[i] = sum over slots (fixed order) [+ wd * W for decayed kernels], per-block sums of
+// squares for the clip norm, and the scalar losses.  One launch covers up to three optimiser segments.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
+    __shared__ double shd[4];
+    const int tid = threadIdx.x;
+    // which segment does this block belong to?
+    int seg = 0, b = blockIdx.x;
+    while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
+    const Segment& s = f.seg[seg];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)b * 256 + tid; i < s.n; i += (int64_t)s.nblocks * 256) {
+        // slots are added in increasing order (fixed association); the loads of 8 slots are
+        // independent and issued together
+        float g = 0.f;
+        const float* src = s.partials + i;
+        int k = 0;
+        for (; k + 8 <= s.nslots; k += 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(k + q) * s.slot_stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g += t[q];
+        }
+        for (; k < s.nslots; ++k) g += src[(int64_t)k * s.slot_stride];
+        if (s.wd > 0.f && ((i >= s.wd0_lo && i < s.wd0_hi) || (i >= s.wd1_lo && i < s.wd1_hi)))
+            g += s.wd * s.param[i];
+        s.grad[i] = g;
+        acc += (double)g * (double)g;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
+    // scalar losses: last block of the grid, thread 0 of each wave handles one family
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        if (f.agent_loss_part) {
+            double h = 0.0, q = 0.0, dd = 0.0;
+            for (int k = 0; k < f.agent_tiles; ++k) {
+                h += (double)f.agent_loss_part[4 * k];
+                q += (double)f.agent_loss_part[4 * k + 1];
+                dd += (double)f.agent_loss_part[4 * k + 2];
+            }
+            const double B = (double)f.B;
+            const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
+            f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl; f.actor_losses[2] = (float)(ql + dl);
+            const double tl = h / B * f.td_scale;
+            const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
+            f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl; f.critic_losses[2] = (float)(tl + wl);
+        }
+        for (int k = 0; k < f.nseg; ++k)
+            if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
+        if (f.disc_loss_part) {
+            double pc = 0, ec = 0, pe = 0, ee = 0, pg = 0, eg = 0;
+            const int tb = f.disc_tiles_b;
+            for (int k = 0; k < tb; ++k) {
+                pc += (double)f.disc_loss_part[4 * k]; pe += (double)f.disc_loss_part[4 * k + 1];
+                pg += (double)f.disc_loss_part[4 * k + 2];
+                ec += (double)f.disc_loss_part[4 * (tb + k)]; ee += (double)f.disc_loss_part[4 * (tb + k) + 1];
+                eg += (double)f.disc_loss_part[4 * (tb + k) + 2];
+            }
+            const double B = (double)f.B;
+            const double pl = pc / B, el = ec / B, em = (pe + ee) / (2.0 * B), eloss = -(double)f.ent_scale * em;
+            f.disc_losses[0] = (float)pl; f.disc_losses[1] = (float)el; f.disc_losses[2] = (float)em;
+            f.disc_losses[3] = (float)eloss; f.disc_losses[4] = (float)(pg / B); f.disc_losses[5] = (float)(eg / B);
+            f.disc_losses[6] = f.gp[0];
+            f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * (double)f.gp[0]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply: for each segment, norm from the per-block sums of squares, then (a) the locally clipped
+// copy that the reference logs, (b) Adam (+Polyak).  mode bit 0: write clipped, bit 1: Adam.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
+    __shared__ double shd[4];
+    __shared__ float sh_scale, sh_lr;
+    const int tid = threadIdx.x;
+    int seg = 0, b = blockIdx.x;
+    while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
+    const ApplySeg& s = f.seg[seg];
+    double acc = 0.0;
+    for (int i = tid; i < s.nsumsq; i += 256) acc += (double)s.sumsq[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const float nrm = (float)sqrt(shd[0] + shd[1] + shd[2] + shd[3]) * f.grad_scale;
+        sh_scale = s.clip > 0.f ? s.clip / fmaxf(nrm, s.clip) : 1.f;
+        // step counter: block 0 of the segment ticks it AFTER every block has read it? no — blocks of
+        // one launch may run in any order, so the counter is advanced by the host-enqueued tick
+        // kernel; here it is only read.
+        const double t = (double)s.step_dev[0];
+        sh_lr = (float)((double)s.lr * sqrt(1.0 - pow((double)f.beta2, t)) / (1.0 - pow((double)f.beta1, t)));
+    }
+    __syncthreads();
+    const float scale = sh_scale * f.grad_scale, lr_t = sh_lr;
+    for (int64_t i = (int64_t)b * 256 + tid; i < s.n; i += (int64_t)s.nblocks * 256) {
+        const float gi = s.grad[i] * scale;
+        if (f.mode & 1) s.clipped[i] = gi;
+        if (f.mode & 2) {
+            float mi = s.m[i], vi = s.v[i];
+            mi = mi + (gi - mi) * (1.f - f.beta1);
+            vi = vi + (gi * gi - vi) * (1.f - f.beta2);
+            const float pi = s.param[i] - (mi * lr_t) / (sqrtf(vi) + f.eps);
+            s.m[i] = mi; s.v[i] = vi; s.param[i] = pi;
+            if (s.targ) s.targ[i] = (1.f - f.tau) * s.targ[i] + f.tau * pi;
+        }
+    }
+}
+
+__global__ void tick_kernel(int64_t* a, int64_t* b, int64_t* c) {
+    if (threadIdx.x == 0) {
+        if (a) a[0] += 1;
+        if (b) b[0] += 1;
+        if (c) c[0] += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_sumsq_kernel(ApplyArgs f) {
+    __shared__ double shd[4];
+    const int tid = threadIdx.x;
+    int seg = 0, b = blockIdx.x;
+    while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
+    const ApplySeg& s = f.seg[seg];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)b * 256 + tid; i < s.n; i += (int64_t)s.nblocks * 256)
+        acc += (double)s.grad[i] * (double)s.grad[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
+}
+
+size_t agent_lds_bytes(int ob, int ac, bool use_d) {
+    size_t f = net_lds_floats(ob, ac) + net_lds_floats(ob + ac, 1) + (use_d ? net_lds_floats(ob + ac, 1) : 0);
+    f += 7 * R * LD + R * LD3 + 64;
+    return f * sizeof(float);
+}
+size_t disc_lds_bytes(int in) {
+    size_t f = net_lds_floats(in, 1) + 6 * R * LD + 96;
+    return f * sizeof(float);
+}
+
+}  // namespace
+
+bool supported(const samx_mlp* d, int64_t B) {
+    return d && !d->layernorm && d->h1 == H && d->h2 == H && d->in_dim <= 64 && d->out_dim <= 16 && B > 0 &&
+           B % R == 0;
+}
+
+int seg_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > kMaxSegBlocks ? kMaxSegBlocks : b));
+}
+
+int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
+    StepArgs s;
+    size_t lds = 0;
+    s.n_a = s.n_tc = s.n_disc = 0;
+    if (a) {
+        s.a = *a;
+        s.n_a = s.n_tc = (int)(a->B / R);
+        lds = agent_lds_bytes(a->ob, a->ac, a->d_scale != 0.f);
+    }
+    if (d) {
+        s.d = *d;
+        s.n_disc = 3 * (int)(d->B / R);
+        const size_t l2 = disc_lds_bytes(d->ob + d->ac);
+        if (l2 > lds) lds = l2;
+    }
+    SAMX_REQUIRE(lds <= 150 * 1024, "fused step kernel needs %zu bytes of LDS", lds);
+    static size_t attr_set = 0;  // largest dynamic-LDS size already granted
+    if (lds > attr_set) {
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)step_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)disc2_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+    }
+    step_kernel<<<(unsigned)(s.n_a + s.n_tc + s.n_disc), NT, lds, st>>>(s);
+    SAMX_LAUNCH_CHECK();
+    if (d) {
+        disc2_kernel<<<(unsigned)(d->B / R), NT, disc_lds_bytes(d->ob + d->ac), st>>>(*d);
+        SAMX_LAUNCH_CHECK();
+    }
+    return SAMX_OK;
+}
+
+int launch_finalize(const FinalizeArgs& f, hipStream_t st) {
+    int blocks = 0;
+    for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
+    finalize_kernel<<<blocks, 256, 0, st>>>(f);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_apply(const ApplyArgs& f, hipStream_t st) {
+    int blocks = 0;
+    for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
+    apply_kernel<<<blocks, 256, 0, st>>>(f);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_tick(int64_t* a, int64_t* b, int64_t* c, hipStream_t st) {
+    tick_kernel<<<1, 64, 0, st>>>(a, b, c);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st) {
+    int blocks = 0;
+    for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
+    seg_sumsq_kernel<<<blocks, 256, 0, st>>>(f);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+}  // namespace fused
+}  // namespace samx

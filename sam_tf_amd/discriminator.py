@@ -42,6 +42,17 @@ class Discriminator(object):
         self.gen.manual_seed(int(hps.seed) + 104729 * (comm.Get_rank() + 1))
         self._ws = {}
 
+    def rebind(self, flat, grad, m, v, t_dev):
+        """Move parameters / gradient / Adam state into views of a learner-wide flat state
+        (ops.LearnerState, layout [actor | critic | reward-net]) so one all-reduce and one optimiser
+        launch cover the whole step.  Values are carried over."""
+        flat.copy_(self.reward_nn.flat); m.copy_(self.optimizer.m); v.copy_(self.optimizer.v)
+        t_dev.copy_(self.optimizer.t_dev)
+        self.reward_nn = FlatNet(self.scope, 'sr', self.desc, flat)
+        self.grad = grad
+        self.optimizer = MpiAdam(self.comm, flat, self.hps.clip_norm, self.hps.d_lr, name='d_adam', m=m,
+                                 v=v, t_dev=t_dev)
+
     # ---- helpers
     @property
     def params(self):

@@ -10,21 +10,24 @@ from . import ops
 
 class MpiAdam(object):
 
-    def __init__(self, comm, param, clip_norm, learning_rate, name='adam'):
+    def __init__(self, comm, param, clip_norm, learning_rate, name='adam', m=None, v=None, t_dev=None):
         self.comm, self.param, self.name = comm, param, name
         self.clip_norm, self.lr = clip_norm, float(learning_rate)
-        self.m = torch.zeros_like(param)
-        self.v = torch.zeros_like(param)
-        self.t = 0
-        # the same count in HBM: the kernels of a captured graph read it instead of a host argument
-        self.t_dev = torch.zeros(1, dtype=torch.int64, device=param.device)
+        # m / v / t_dev may be views into a learner-wide flat state (ops.LearnerState)
+        self.m = torch.zeros_like(param) if m is None else m
+        self.v = torch.zeros_like(param) if v is None else v
+        # the update count lives in HBM: the kernels of a captured graph read it, not a host argument
+        self.t_dev = torch.zeros(1, dtype=torch.int64, device=param.device) if t_dev is None else t_dev
         self.partials = ops.adam_partials(param.device)
         self._mism = torch.zeros(1, dtype=torch.int32, device=param.device)
+
+    @property
+    def t(self):
+        return int(self.t_dev.item())
 
     def update(self, grad, targ=None, tau=0.0, reduce=True):
         if reduce:
             self.comm.allreduce_(grad)
-        self.t += 1
         self.enqueue(grad, targ, tau)
 
     def enqueue(self, grad, targ=None, tau=0.0):

@@ -329,3 +329,87 @@ def reward(dd, pd, obs, acs, mean, std, non_satur_grad, ws, out=None):
     check(_L().samx_reward(C.byref(dd), ptr(pd), ptr(obs), ptr(acs), ptr(mean), ptr(std), B, ob,
                            int(bool(non_satur_grad)), ptr(out), ptr(ws), ws.numel(), stream_ptr()))
     return out
+
+
+# ------------------------------------------------------------------ whole-learner step
+
+class LearnerState(object):
+    """Owns the flat device vectors of the three optimisers ([actor | critic | reward-net]) and the
+    `samx_learner` struct that points at them."""
+
+    def __init__(self, da, dc, dd, ob_dim, ac_dim, hp, device='cuda'):
+        self.da, self.dc, self.dd = da, dc, dd
+        self.Pa, self.Pc, self.Pd = param_count(da), param_count(dc), param_count(dd)
+        P = self.Pa + self.Pc + self.Pd
+        z = lambda n: torch.zeros(n, dtype=F32, device=device)
+        self.params, self.grads, self.clipped, self.m, self.v = z(P), z(P), z(P), z(P), z(P)
+        self.targets = z(self.Pa + self.Pc)
+        self.steps = torch.zeros(3, dtype=I64, device=device)
+        self.device = torch.device(device)
+        self.hp = dict(hp)
+        self.c = _lib.Learner()
+        self.c.actor, self.c.critic, self.c.reward = da, dc, dd
+        self.c.ob_dim, self.c.ac_dim = int(ob_dim), int(ac_dim)
+        for k, t in (('params', self.params), ('grads', self.grads), ('clipped', self.clipped),
+                     ('adam_m', self.m), ('adam_v', self.v), ('targets', self.targets),
+                     ('steps', self.steps)):
+            setattr(self.c, k, t.data_ptr())
+        for k, v in self.hp.items():
+            setattr(self.c, k, float(v))
+        self._keep = {}
+        self._ws = {}
+
+    def set_ptr(self, field, tensor):
+        """Optional pointers: actor_reward_params, mu_mean, mu_std, d_mean, d_std."""
+        self._keep[field] = tensor
+        setattr(self.c, field, None if tensor is None else tensor.data_ptr())
+
+    def seg(self, t, k):
+        o = (0, self.Pa, self.Pa + self.Pc)[k]
+        n = (self.Pa, self.Pc, self.Pd)[k]
+        return t[o:o + n]
+
+    def fused(self, B):
+        return bool(_L().samx_fused_supported(C.byref(self.c), int(B)))
+
+    def ws(self, B):
+        if B not in self._ws:
+            n = _L().samx_step_ws_bytes(C.byref(self.c), int(B))
+            self._ws[B] = torch.zeros(int(n), dtype=torch.uint8, device=self.device)
+        return self._ws[B]
+
+
+def make_batch(B, **tensors):
+    b = _lib.Batch()
+    b.B = int(B)
+    keep = []
+    for k, t in tensors.items():
+        if t is not None:
+            assert t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.shape[0] == B, k
+            keep.append(t)
+            setattr(b, k, t.data_ptr())
+    b._keep = keep
+    return b
+
+
+def make_step_out(B, device='cuda'):
+    o = _lib.StepOut()
+    o.t = dict(d_losses=torch.zeros(8, dtype=F32, device=device),
+               actor_losses=torch.zeros(3, dtype=F32, device=device),
+               critic_losses=torch.zeros(3, dtype=F32, device=device),
+               targ_q=torch.zeros(B, dtype=F32, device=device), td=torch.zeros(B, dtype=F32, device=device))
+    for k, t in o.t.items():
+        setattr(o, k, t.data_ptr())
+    return o
+
+
+def step_grads(L, batch, out):
+    ws = L.ws(batch.B)
+    check(_L().samx_step_grads(C.byref(L.c), C.byref(batch), C.byref(out), ptr(ws), ws.numel(),
+                               stream_ptr()))
+
+
+def step_apply(L, B, mode, grad_scale=1.0):
+    ws = L.ws(B)
+    check(_L().samx_step_apply(C.byref(L.c), int(B), int(mode), float(grad_scale), ptr(ws), ws.numel(),
+                               stream_ptr()))

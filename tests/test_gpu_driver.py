@@ -107,7 +107,7 @@ def test_k_steps_match_oracle(cfg_name, graph):
         torch.cuda.synchronize()
         h = lambda t: t.cpu().numpy()
         out = ref.step(h(drv.idx_p), h(drv.eb['obs0']), h(drv.eb['acs']), h(drv.eps_ob), h(drv.eps_ac),
-                       h(drv.real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(mu.td))
+                       h(drv.real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
         if cfg['per']:
             assert np.array_equal(out['idx_a'], h(drv.idx_a)), 'PER indices differ at step %d' % k
         o = drv.outputs()

@@ -1,0 +1,134 @@
+"""samx_step_grads / samx_step_apply (whole learner, fused whole-network kernels for 64x64 nets) vs
+the fp64 oracle, and the fused path vs the layer-wise path.  Bar: 1e-5 relative (max-norm)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.nets_cases import make_case, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+HP = dict(ac_high=0.4, gamma=0.99, polyak=0.01, clip_norm=5.0, actor_lr=1e-4, critic_lr=1e-3, d_lr=3e-4,
+          beta1=0.9, beta2=0.999, adam_eps=1e-8, td_loss_scale=1.0, wd_scale=1e-3,
+          q_actor_loss_scale=1.0, d_actor_loss_scale=0.0, ent_reg_scale=0.0)
+
+
+def _dev(x):
+    return None if x is None else torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def _setup(name, d_scale, ent, per, rms=True):
+    from sam_tf_amd import ops
+    c = make_case(name); P, D = c['P'], c['D']
+    mk = lambda d: ops.mlp_desc(d.in_dim, d.h1, d.h2, d.out_dim, d.layernorm)
+    hp = dict(HP, d_actor_loss_scale=d_scale, ent_reg_scale=ent)
+    L = ops.LearnerState(mk(c['da']), mk(c['dc']), mk(c['dd']), c['ob'], c['ac'], hp)
+    L.params.copy_(_dev(np.concatenate([P['pa'], P['pc'], P['pd']])))
+    L.targets.copy_(_dev(np.concatenate([P['pa_t'], P['pc_t']])))
+    if rms:
+        for k in ('mu_mean', 'd_mean'):
+            L.set_ptr(k, _dev(c['mean']))
+        for k in ('mu_std', 'd_std'):
+            L.set_ptr(k, _dev(c['std']))
+    if d_scale:
+        L.set_ptr('actor_reward_params', _dev(P['pd'][::-1].copy()))  # a DIFFERENT (frozen) reward net
+    B = c['B']
+    batch = ops.make_batch(B, p_obs=_dev(D['obs0']), p_acs=_dev(D['acs']), e_obs=_dev(D['e_obs']),
+                           e_acs=_dev(D['e_acs']), eps_ob=_dev(D['eps_ob']), eps_ac=_dev(D['eps_ac']),
+                           real_labels=_dev(D['real']), fake_labels=_dev(D['fake']), obs0=_dev(D['obs0']),
+                           acs=_dev(D['acs']), rews=_dev(D['rews']), dones1=_dev(D['dones1']),
+                           obs1=_dev(D['obs1']), iws=_dev(D['iws']) if per else None)
+    return c, L, batch, ops.make_step_out(B)
+
+
+def _oracle(c, d_scale, ent, per, rms=True):
+    from oracle import nets_oracle as NO
+    P, D = c['P'], c['D']
+    mean, std = (c['mean'], c['std']) if rms else (0.0, 1.0)
+    B = c['B']
+    dl, dg = NO.disc_loss_grad(P['pd'], c['dd'], D['obs0'], D['acs'], D['e_obs'], D['e_acs'], D['eps_ob'],
+                               D['eps_ac'], D['real'], D['fake'], mean, std, ent_reg_scale=ent, rmsify=rms)
+    tq = NO.targ_q(P['pa_t'], P['pc_t'], c['da'], c['dc'], D['obs1'], D['rews'][:, None],
+                   D['dones1'][:, None], np.ones((B, 1)), mean, std, 0.99, 0.4, rmsify=rms)
+    al, ag = NO.actor_loss_grad(P['pa'], c['da'], P['pc'], c['dc'], P['pd'][::-1].copy() if d_scale else None,
+                                c['dd'], D['obs0'], mean, std, 0.4, 1.0, d_scale, rmsify=rms)
+    cl, cg, td = NO.critic_loss_grad(P['pc'], c['dc'], D['obs0'], D['acs'],
+                                     D['iws'][:, None] if per else None, tq, mean, std, 1e-3, rmsify=rms)
+    return dict(d_losses=dl, actor_losses=al, critic_losses=cl, targ_q=tq.ravel(), td=td.ravel(),
+                grads=np.concatenate([ag, cg, dg]))
+
+
+@pytest.mark.parametrize('name,d_scale,ent,per,rms', [
+    ('C1', 0.0, 0.0, False, True), ('C2', 0.0, 0.0, False, True), ('C3', 0.0, 0.0, True, True),
+    ('C3', 0.5, 1e-3, True, True), ('C2', 0.5, 0.0, False, False),
+    ('ragged', 0.5, 0.0, True, True),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
+    ('C4', 0.0, 0.0, False, True)])
+def test_step_grads_vs_oracle(name, d_scale, ent, per, rms):
+    from sam_tf_amd import ops
+    c, L, batch, out = _setup(name, d_scale, ent, per, rms)
+    assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3'))
+    exp = _oracle(c, d_scale, ent, per, rms)
+    ops.step_grads(L, batch, out)
+    torch.cuda.synchronize()
+    for k in ('d_losses', 'actor_losses', 'critic_losses'):
+        got = out.t[k].cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(got - exp[k]) / np.maximum(np.abs(exp[k]), 1e-3)) < TOL, (k, got, exp[k])
+    assert relerr(out.t['targ_q'].cpu().numpy(), exp['targ_q']) < TOL
+    assert relerr(out.t['td'].cpu().numpy(), exp['td']) < TOL
+    g = L.grads.cpu().numpy()
+    for k in range(3):
+        assert relerr(L.seg(torch.as_tensor(g), k).numpy(), L.seg(torch.as_tensor(exp['grads']), k).numpy()) < TOL, k
+    assert L.steps.tolist() == [1, 1, 1]
+
+
+@pytest.mark.parametrize('world', [1, 4])
+def test_step_apply_vs_oracle(world):
+    """Optimiser pass for the three segments: clipped copies (local norm), all-reduce emulated by
+    scaling, Adam + Polyak — against oracle mpi_adam_step / polyak; fused and unfused modes agree."""
+    from sam_tf_amd import ops
+    from oracle import nets_oracle as NO
+    c, L, batch, out = _setup('C2', 0.0, 0.0, False)
+    ops.step_grads(L, batch, out)
+    g_local = L.grads.cpu().numpy().astype(np.float64)
+    th0 = L.params.cpu().numpy().astype(np.float64)
+    tg0 = L.targets.cpu().numpy().astype(np.float64)
+    if world == 1:
+        ops.step_apply(L, c['B'], 3, 1.0)
+        g_mean = g_local
+    else:
+        ops.step_apply(L, c['B'], 1, 1.0)            # logging copy with the LOCAL norm
+        other = np.random.RandomState(0).randn(g_local.size) * 0.3
+        L.grads.copy_(torch.as_tensor((g_local * 1.0 + other).astype(np.float32)).cuda())  # "all-reduce"
+        g_mean = L.grads.cpu().numpy().astype(np.float64) / world
+        ops.step_apply(L, c['B'], 6, 1.0 / world)
+    lrs = (1e-4, 1e-3, 3e-4)
+    for k in range(3):
+        sl = lambda a: L.seg(torch.as_tensor(a), k).numpy()
+        clipped, _ = NO.clip_by_global_norm(sl(g_local), 5.0)
+        assert relerr(sl(L.clipped.cpu().numpy()), clipped) < TOL
+        th, m, v = NO.mpi_adam_step(sl(th0), np.zeros(sl(th0).size), np.zeros(sl(th0).size), [sl(g_mean)],
+                                    lrs[k], 1, 5.0)
+        assert relerr(sl(L.params.cpu().numpy()), th) < TOL
+        assert relerr(sl(L.m.cpu().numpy()), m) < TOL and relerr(sl(L.v.cpu().numpy()), v) < 2e-5
+        if k < 2:
+            o = (0, L.Pa)[k]
+            tg = NO.polyak(tg0[o:o + th.size], th, 0.01)
+            assert relerr(L.targets.cpu().numpy()[o:o + th.size], tg) < TOL
+
+
+def test_fused_matches_layerwise():
+    """The two implementations of the same step agree far inside the parity bar."""
+    from sam_tf_amd import ops
+    c, L, batch, out = _setup('C3', 0.5, 1e-3, True)
+    ops.step_grads(L, batch, out)
+    g_f = L.grads.clone()
+    ws = ops.nets_ws(L.da, L.dc, L.dd, c['B'])
+    P, D = c['P'], c['D']
+    _, gd = ops.disc_grad(L.dd, _dev(P['pd']), _dev(D['obs0']), _dev(D['acs']), _dev(D['e_obs']),
+                          _dev(D['e_acs']), _dev(D['eps_ob']), _dev(D['eps_ac']), _dev(D['real']),
+                          _dev(D['fake']), _dev(c['mean']), _dev(c['std']), 1e-3, ops.disc_ws(L.dd, c['B']))
+    assert relerr(L.seg(g_f, 2).cpu().numpy(), gd.cpu().numpy()) < 2e-6
+    _, ga = ops.actor_grad(L.da, _dev(P['pa']), L.dc, _dev(P['pc']), L.dd, _dev(P['pd'][::-1].copy()),
+                           _dev(D['obs0']), _dev(c['mean']), _dev(c['std']), 0.4, 1.0, 0.5, ws)
+    assert relerr(L.seg(g_f, 0).cpu().numpy(), ga.cpu().numpy()) < 2e-6
