@@ -240,6 +240,19 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
     const float *p_obs, *p_acs, *e_obs, *e_acs, *eps_ob, *eps_ac, *real_labels, *fake_labels;
     /* agent update (sam_agent.py:634-660): replayed transitions; iws NULL = uniform, td_len NULL = 1 */
     const float *obs0, *acs, *rews, *dones1, *obs1, *iws, *td_len;
+    /* Optional row indirection (all NULL/0 = the pointers above address B gathered rows).
+     * p_idx: p_obs/p_acs address the replay storage and row r of the batch is storage row
+     *        (ring_start + p_idx[r]) % ring_len — RingBuffer.get_batch, memory.py:33-34;
+     * a_idx: the same for obs0/acs/rews/dones1/obs1;
+     * e_start: device scalar; e_obs/e_acs address the expert pool and row r is pool row
+     *        e_start[0] + r — PairDataset.get_next_batch, demo_dataset.py:37-40. */
+    const int64_t *p_idx, *a_idx, *e_start;
+    int64_t ring_start, ring_len;
+    /* eps_ob == NULL: the library draws eps_ob/eps_ac and the smoothed labels itself (Philox keyed by
+     * rng_seed and the reward-net update count).  label_smoothing: 0 = labels 1/0, 1 = one-sided
+     * (real ~ 1.2 - 0.5u, discriminator.py:104-109), 2 = also fake ~ 0.3 - 0.3u (lines 97-103). */
+    uint64_t rng_seed;
+    int32_t label_smoothing;
 } samx_batch;
 
 typedef struct samx_step_out {
@@ -251,6 +264,21 @@ typedef struct samx_step_out {
 } samx_step_out;
 
 int samx_fused_supported(const samx_learner* L, int64_t B);
+
+/* The numbers samx_step_grads draws for update number `step` (0-based reward-net update count) when
+ * batch.eps_ob is NULL, written out so a checker can replay the same update.  real/fake may be NULL. */
+int samx_disc_randoms(uint64_t rng_seed, int64_t step, int64_t B, int ob_dim, int ac_dim,
+                      float* eps_ob, float* eps_ac, float* real_labels, float* fake_labels, void* stream);
+
+/* d.obs_rms.update on the discriminator's input rows WITHOUT gathering them first
+ * (sam.py:389-390 + helpers/mpi_running_mean_std.py:47-59): float64 column sums over the policy rows
+ * (replay storage via p_idx) and the expert rows (pool rows e_start[0]..+B).  With commit != 0 the sums
+ * are also folded into `sums` and mean/std refreshed (single process); otherwise call samx_rms_commit
+ * after the all-reduce of addvec. */
+int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                       const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
+                       int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
+                       float* std_out, void* stream);
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
 
 /* d.get_grads/get_losses + mu's get_targ_q / actor & critic losses and grads (sam.py:398-399,

@@ -40,9 +40,11 @@ class Learner(C.Structure):
 
 class Batch(C.Structure):
     """Mirror of `struct samx_batch`."""
-    _fields_ = [('B', C.c_int64)] + [(k, C.c_void_p) for k in (
+    _fields_ = ([('B', C.c_int64)] + [(k, C.c_void_p) for k in (
         'p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
-        'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')]
+        'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'p_idx', 'a_idx', 'e_start')] +
+                [('ring_start', C.c_int64), ('ring_len', C.c_int64), ('rng_seed', C.c_uint64),
+                 ('label_smoothing', C.c_int32)])
 
 
 class StepOut(C.Structure):
@@ -88,6 +90,9 @@ SIGNATURES = {
                                  _F, _P, _P, _P, _SZ, _P]),
     'samx_reward': (C.c_int, [_MP, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P, _P, _SZ, _P]),
     'samx_fused_supported': (C.c_int, [_LP, _I64]),
+    'samx_disc_randoms': (C.c_int, [C.c_uint64, _I64, _I64, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    'samx_d_input_stats': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
+                                     _P]),
     'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
     'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),
     'samx_step_apply': (C.c_int, [_LP, _I64, C.c_int, _F, _P, _SZ, _P]),

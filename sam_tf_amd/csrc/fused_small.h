@@ -7,7 +7,7 @@ namespace samx {
 namespace fused {
 
 constexpr int kRows = 16;          // batch rows per workgroup
-constexpr int kMaxSegBlocks = 64;  // blocks (and sum-of-squares partials) per optimiser segment
+constexpr int kMaxSegBlocks = 256;  // blocks (and sum-of-squares partials) per optimiser segment
 
 struct AgentArgs {
     // inputs (device): batch rows
@@ -22,6 +22,9 @@ struct AgentArgs {
     float* partials;  // [B/16][P] slots, P = Pa + Pc
     int64_t P, Pa;
     float* loss_part;  // [B/16][4]: sum huber*iw, sum Q, sum D, (block 0) sum W1^2 + W2^2 of the critic
+    // optional row indirection into ring storage (memory.py:33-34); idx == nullptr: direct rows
+    const int64_t* idx;
+    int64_t ring_start, ring_len;
 };
 
 struct DiscArgs {
@@ -35,12 +38,19 @@ struct DiscArgs {
     float* loss_part;  // [2B/16][4]: sum ce, sum entropy-CE, sum sigmoid
     double* gp_part;   // [B/16][2]: sum g_ob^2, sum g_ac^2
     float* gp_out;     // [1]: (N-1)^2
+    const int64_t *p_idx, *e_start;  // optional indirection: replay ring rows / expert pool slice
+    int64_t ring_start, ring_len;
+    // in-kernel randoms (used when eps_ob == nullptr)
+    uint64_t rng_seed;
+    const int64_t* rng_step;  // device: reward-net update count
+    int label_smoothing;
 };
 
 struct Segment {
     const float* partials;  // first slot, already offset to this segment
     int64_t slot_stride;
     int nslots;
+    int scaled_from;  // slots [scaled_from, nslots) are multiplied by the gradient-penalty scalar k
     int64_t n;
     float* grad;
     float* sumsq;  // [nblocks]
@@ -65,7 +75,9 @@ struct FinalizeArgs {
     const float* disc_loss_part;
     int disc_tiles_b;
     float ent_scale, gp_coeff;
-    const float* gp;
+    float* gp;               // [1] out: (N-1)^2
+    const double* gp_part;   // [gp_tiles][2] sums of squares of the input gradient (NULL: no D segment)
+    int gp_tiles, ob, ac;
     float* disc_losses;
 };
 

@@ -18,7 +18,9 @@
 // networks.py:45-72,222-404 ; mpi_adam.py:18-36 ; tf_util.py:137-151.
 #include "samx_common.h"
 #include "fused_small.h"
+#include "rng.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace samx {
 namespace fused {
@@ -123,26 +125,41 @@ __device__ inline NetL carve_net(float*& p, int in, int out) {
     return n;
 }
 
-// global flat [W1 b1 W2 b2 W3 b3] -> padded LDS image (all threads; caller syncs)
+typedef __attribute__((address_space(3))) float lds_float;
+typedef const __attribute__((address_space(1))) float glb_float;
+
+// one wave copies 64 consecutive floats global -> LDS with the LDS-DMA path (no VGPR round trip;
+// the copy stays in flight until the next s_waitcnt vmcnt(0))
+__device__ __forceinline__ void dma_row64(const float* g, float* l, int lane) {
+    __builtin_amdgcn_global_load_lds((glb_float*)(g + lane), (lds_float*)l, 4, 0, 0);
+}
+
+// global flat [W1 b1 W2 b2 W3 b3] -> padded LDS image.  All copies of all networks are issued
+// back to back; the caller drains them ONCE (stage_wait) before the first barrier.
 __device__ inline void load_net(const NetL& n, const float* __restrict__ g) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* gW1 = g;
     const float* gb1 = gW1 + n.in * H;
     const float* gW2 = gb1 + H;
     const float* gb2 = gW2 + H * H;
     const float* gW3 = gb2 + H;
     const float* gb3 = gW3 + H * n.out;
-    for (int t = tid; t < n.k4 * H; t += NT) {
-        const int k = t >> 6, c = t & 63;
-        n.W1[k * LD + c] = k < n.in ? gW1[t] : 0.f;
-    }
-    for (int t = tid; t < H * H; t += NT) n.W2[(t >> 6) * LD + (t & 63)] = gW2[t];
-    for (int t = tid; t < H * 16; t += NT) {
-        const int k = t >> 4, c = t & 15;
-        n.W3[k * LD3 + c] = c < n.out ? gW3[k * n.out + c] : 0.f;
-    }
-    if (tid < H) { n.b1[tid] = gb1[tid]; n.b2[tid] = gb2[tid]; }
+    for (int k = w; k < n.in; k += 4) dma_row64(gW1 + k * H, n.W1 + k * LD, lane);
+    for (int k = w; k < H; k += 4) dma_row64(gW2 + k * H, n.W2 + k * LD, lane);
+    if (w == 0) dma_row64(gb1, n.b1, lane);
+    if (w == 1) dma_row64(gb2, n.b2, lane);
+    for (int t = tid; t < (n.k4 - n.in) * H; t += NT) n.W1[(n.in + (t >> 6)) * LD + (t & 63)] = 0.f;
+    // head matrix: only the `out` real columns are read from memory (one load per thread per pass);
+    // the zero padding up to 16 columns is written by different threads to different words
+    for (int t = tid; t < H * n.out; t += NT) n.W3[(t / n.out) * LD3 + (t % n.out)] = gW3[t];
+    for (int t = tid; t < H * 16; t += NT)
+        if ((t & 15) >= n.out) n.W3[(t >> 4) * LD3 + (t & 15)] = 0.f;
     if (tid < 16) n.b3[tid] = tid < n.out ? gb3[tid] : 0.f;
+}
+
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // out[16][64] = lrelu(in[16][K4] * W + b)          (all 4 waves, one 16-col tile each)
@@ -232,20 +249,31 @@ __device__ inline void wgrad_head1(const float* A2, const float* dq, float* __re
     }
 }
 
-// normalised observation rows (+ optional action columns) into XC[16][LD]; columns beyond are zero
+__device__ __forceinline__ int64_t ring_row(const int64_t* idx, int64_t start, int64_t len, int64_t g) {
+    if (!idx) return g;
+    int64_t s = start + idx[g];  // 0 <= idx < len and 0 <= start < len (host-checked)
+    return s >= len ? s - len : s;
+}
+
+// normalised observation rows (+ optional action columns) into XC[16][LD]; columns beyond are zero.
+// The loads form ONE batch per thread (index, then data; no load sits behind another load's use).
 __device__ inline void load_rows(float* XC, const float* __restrict__ obs, const float* __restrict__ acs,
                                  const float* __restrict__ mean, const float* __restrict__ stdv, int ob,
-                                 int ac, int64_t row0) {
-    for (int t = threadIdx.x; t < R * LD; t += NT) {
-        const int r = t / LD, c = t % LD;
-        float v = 0.f;
+                                 int ac, int64_t row0, const int64_t* idx, int64_t start, int64_t len) {
+    const int w = ob + (acs ? ac : 0);
+    for (int t = threadIdx.x; t < R * LD; t += NT)
+        if (t % LD >= w) XC[t] = 0.f;
+    for (int t = threadIdx.x; t < R * w; t += NT) {
+        const int r = t / w, c = t % w;
+        const int64_t pr = ring_row(idx, start, len, row0 + r);
+        float v;
         if (c < ob) {
-            v = obs[(row0 + r) * ob + c];
+            v = obs[pr * ob + c];
             if (mean) v = fminf(fmaxf((v - mean[c]) / stdv[c], -5.f), 5.f);
-        } else if (acs && c < ob + ac) {
-            v = acs[(row0 + r) * ac + (c - ob)];
+        } else {
+            v = acs[pr * ac + (c - ob)];
         }
-        XC[t] = v;
+        XC[r * LD + c] = v;
     }
 }
 
@@ -256,7 +284,7 @@ __device__ inline void load_rows(float* XC, const float* __restrict__ obs, const
 // ------------------------------------------------------------------------------------------------
 struct AgentLds {
     NetL nA, nC, nD;
-    float *XC, *A1a, *A2a, *A1c, *A2c, *DZa, *DZb, *PRE, *s_, *tq, *dq, *red;
+    float *XC, *XC0, *A1a, *A2a, *A1c, *A2c, *DZa, *DZb, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl;
 };
 
 __device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d) {
@@ -266,6 +294,7 @@ __device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d)
     L.nD = L.nC;
     if (use_d) L.nD = carve_net(p, ob + ac, 1);
     L.XC = p; p += R * LD;
+    L.XC0 = p; p += R * LD;
     L.A1a = p; p += R * LD;
     L.A2a = p; p += R * LD;
     L.A1c = p; p += R * LD;
@@ -274,6 +303,7 @@ __device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d)
     L.DZb = p; p += R * LD;
     L.PRE = p; p += R * LD3;
     L.s_ = p; L.tq = p + 16; L.dq = p + 32; L.red = p + 48;
+    L.rw = p + 64; L.dn = p + 80; L.iw = p + 96; L.tl = p + 112;
     return L;
 }
 
@@ -297,15 +327,24 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
-    AgentLds L = carve_agent_lds(lds, ob, ac, false);
+    AgentLds L = carve_agent_lds(lds, ob, ac, true);   // third slot: the online critic, staged early
     float* gC = a.partials + (int64_t)wg * a.P + a.Pa;  // critic part of this tile's gradient slot
     const int64_t cW1 = 0, cb1 = cW1 + (int64_t)in_c * H, cW2 = cb1 + H, cb2 = cW2 + H * H, cW3 = cb2 + H,
                   cb3 = cW3 + H;
     // ---- TD target: rews + gamma^len (1 - done) Q'(obz1, mu'(obz1))   (sam_agent.py:196-205)
     load_net(L.nA, a.targ_actor);
     load_net(L.nC, a.targ_critic);
-    load_rows(L.XC, a.obs1, nullptr, a.mean, a.stdv, ob, 0, row0);
-    __syncthreads();
+    load_net(L.nD, a.critic);
+    load_rows(L.XC, a.obs1, nullptr, a.mean, a.stdv, ob, 0, row0, a.idx, a.ring_start, a.ring_len);
+    load_rows(L.XC0, a.obs0, a.acs, a.mean, a.stdv, ob, ac, row0, a.idx, a.ring_start, a.ring_len);
+    if (tid < R) {
+        const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + tid);
+        L.rw[tid] = a.rews[pr];
+        L.dn[tid] = a.dones1[pr];
+        L.iw[tid] = a.iws ? a.iws[row0 + tid] : 1.f;     // importance weights are per BATCH row
+        L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
+    }
+    stage_wait();
     layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
     __syncthreads();
     layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
@@ -320,14 +359,14 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds) {
     __syncthreads();
     if (tid < R) {
         const int64_t g = row0 + tid;
-        const float gam = a.td_len ? powf(a.gamma, a.td_len[g]) : a.gamma;
-        const float t = a.rews[g] + gam * ((1.f - a.dones1[g]) * L.s_[tid]);
+        const float gam = a.td_len ? powf(a.gamma, L.tl[tid]) : a.gamma;
+        const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * L.s_[tid]);
         L.tq[tid] = t;
         a.targ_q_out[g] = t;
     }
     // ---- critic loss + gradient (sam_agent.py:457-520)
-    load_net(L.nC, a.critic);  // every read of the target critic finished before the last barrier
-    load_rows(L.XC, a.obs0, a.acs, a.mean, a.stdv, ob, ac, row0);
+    L.nC = L.nD;    // switch to the online critic staged at kernel start
+    L.XC = L.XC0;   // ... and to the [obz0 | acs] rows fetched at kernel start
     __syncthreads();
     if (wg == 0) {
         // sum of squares of the decayed critic kernels for the weight-decay loss term
@@ -348,7 +387,7 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds) {
     if (tid < R) {
         const int64_t g = row0 + tid;
         const float td = L.s_[tid] - L.tq[tid];
-        const float iw = a.iws ? a.iws[g] : 1.f;
+        const float iw = L.iw[tid];
         const float ad = fabsf(td);
         const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;         // math_util.py:22-29
         const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
@@ -383,8 +422,8 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     load_net(L.nA, a.actor);
     load_net(L.nC, a.critic);
     if (use_d) load_net(L.nD, a.reward);
-    load_rows(L.XC, a.obs0, nullptr, a.mean, a.stdv, ob, 0, row0);
-    __syncthreads();
+    load_rows(L.XC, a.obs0, nullptr, a.mean, a.stdv, ob, 0, row0, a.idx, a.ring_start, a.ring_len);
+    stage_wait();
     layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
     __syncthreads();
     layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
@@ -479,33 +518,36 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
 // input gradient g = d score / d input, and this tile's share of sum g_ob^2, sum g_ac^2.
 // ------------------------------------------------------------------------------------------------
 __device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int sect) {
-    // sect 0: policy rows, 1: expert rows, 2: eps*policy + (1-eps)*expert
-    const int ob = a.ob, ac = a.ac;
-    for (int t = threadIdx.x; t < R * LD; t += NT) {
-        const int r = t / LD, c = t % LD;
-        float v = 0.f;
+    // sect 0: policy rows, 1: expert rows, 2: eps*policy + (1-eps)*expert  (discriminator.py:129-134)
+    const int ob = a.ob, ac = a.ac, w = ob + ac;
+    const int64_t e0 = a.e_start ? a.e_start[0] : 0;
+    const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
+    for (int t = threadIdx.x; t < R * LD; t += NT)
+        if (t % LD >= w) XC[t] = 0.f;
+    for (int t = threadIdx.x; t < R * w; t += NT) {
+        const int r = t / w, c = t % w;
         const int64_t g = row0 + r;
-        if (c < ob + ac) {
-            float pv = 0.f, ev = 0.f;
-            if (c < ob) {
-                if (sect != 1) pv = a.p_obs[g * ob + c];
-                if (sect != 0) ev = a.e_obs[g * ob + c];
-                if (a.mean) {
-                    pv = fminf(fmaxf((pv - a.mean[c]) / a.stdv[c], -5.f), 5.f);
-                    ev = fminf(fmaxf((ev - a.mean[c]) / a.stdv[c], -5.f), 5.f);
-                }
-            } else {
-                if (sect != 1) pv = a.p_acs[g * ac + (c - ob)];
-                if (sect != 0) ev = a.e_acs[g * ac + (c - ob)];
+        const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g), eg = e0 + g;
+        float pv = 0.f, ev = 0.f, e = 0.f;
+        if (c < ob) {
+            if (sect != 1) pv = a.p_obs[pg * ob + c];
+            if (sect != 0) ev = a.e_obs[eg * ob + c];
+            if (sect == 2)
+                e = a.eps_ob ? a.eps_ob[g * ob + c]
+                             : philox_uniform(a.rng_seed, step, RNG_EPS_OB, (uint64_t)(g * ob + c));
+            if (a.mean) {
+                const float m = a.mean[c], sd = a.stdv[c];
+                pv = fminf(fmaxf((pv - m) / sd, -5.f), 5.f);
+                ev = fminf(fmaxf((ev - m) / sd, -5.f), 5.f);
             }
-            if (sect == 0) v = pv;
-            else if (sect == 1) v = ev;
-            else {
-                const float e = c < ob ? a.eps_ob[g * ob + c] : a.eps_ac[g * ac + (c - ob)];
-                v = e * pv + (1.f - e) * ev;
-            }
+        } else {
+            if (sect != 1) pv = a.p_acs[pg * ac + (c - ob)];
+            if (sect != 0) ev = a.e_acs[eg * ac + (c - ob)];
+            if (sect == 2)
+                e = a.eps_ob ? a.eps_ac[g * ac + (c - ob)]
+                             : philox_uniform(a.rng_seed, step, RNG_EPS_AC, (uint64_t)(g * ac + (c - ob)));
         }
-        XC[t] = v;
+        XC[r * LD + c] = sect == 0 ? pv : (sect == 1 ? ev : e * pv + (1.f - e) * ev);
     }
 }
 
@@ -555,15 +597,17 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     float* s_ = sh; float* dq = sh + 16; float* r0_ = sh + 32; float* r1_ = sh + 48; float* r2_ = sh + 64;
     load_net(n, a.params);
     disc_rows(XC, a, row0, sect);
-    __syncthreads();
+    stage_wait();
     if (sect == 2) {
-        float* Gbuf = p;  // sixth tile: the input gradient g
-        disc_interp_chain(n, XC, A1, A2, DZa, DZb, Gbuf, dq);
-        // this tile's sums of squares, observation and action columns separately (fixed order)
-        float so = 0.f, sa = 0.f;
-        if (tid < R) {
-            for (int c = 0; c < a.ob; ++c) so = fmaf(Gbuf[tid * LD + c], Gbuf[tid * LD + c], so);
-            for (int c = a.ob; c < in; ++c) sa = fmaf(Gbuf[tid * LD + c], Gbuf[tid * LD + c], sa);
+        // Interpolate rows.  d(10*GP)/d(theta) = k * sum_rows <V, dg/dtheta> with V = g/(B*dim) and the
+        // scalar k = 10*2(N-1)/N known only once every tile has contributed to N.  The slot gets the
+        // sum WITHOUT k; finalize multiplies these slots by k (discriminator.py:136-140,154).
+        float* G = p;  // sixth tile: the input gradient g, then V
+        disc_interp_chain(n, XC, A1, A2, DZa, DZb, G, dq);
+        if (tid < R) {  // this tile's sums of squares, observation / action columns (fixed order)
+            float so = 0.f, sa = 0.f;
+            for (int c = 0; c < a.ob; ++c) so = fmaf(G[tid * LD + c], G[tid * LD + c], so);
+            for (int c = a.ob; c < in; ++c) sa = fmaf(G[tid * LD + c], G[tid * LD + c], sa);
             r0_[tid] = so; r1_[tid] = sa;
         }
         __syncthreads();
@@ -572,6 +616,28 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
             for (int r = 0; r < R; ++r) { o += (double)r0_[r]; c += (double)r1_[r]; }
             a.gp_part[2 * (wg - 2 * tiles_b)] = o;
             a.gp_part[2 * (wg - 2 * tiles_b) + 1] = c;
+        }
+        const float co = 1.f / ((float)a.B * (float)a.ob), ca = 1.f / ((float)a.B * (float)a.ac);
+        for (int t = tid; t < R * LD; t += NT) {
+            const int c = t % LD;
+            G[t] = c < in ? G[t] * (c < a.ob ? co : ca) : 0.f;
+        }
+        __syncthreads();
+        float* part = a.partials + (int64_t)wg * a.P;
+        const int64_t oW1 = 0, ob1 = (int64_t)in * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H,
+                      ob3 = oW3 + H;
+        wgrad64(G, in, DZb, part + oW1, nullptr, 0);      // V^T gz1
+        layer_tan(G, n.k4, n.W1, A1, A1);                 // a1dot = (V W1) .* m1   (in place)
+        if (tid < H) { part[ob1 + tid] = 0.f; part[ob2 + tid] = 0.f; }
+        if (tid == 0) part[ob3] = 0.f;
+        __syncthreads();
+        wgrad64(A1, H, DZa, part + oW2, nullptr, 0);      // a1dot^T gz2
+        layer_tan(A1, H, n.W2, A2, A2);                   // a2dot = (a1dot W2) .* m2
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+            for (int r = 0; r < R; ++r) s2 += A2[r * LD + tid];
+            part[oW3 + tid] = s2;                         // sum_r a2dot
         }
         return;
     }
@@ -587,7 +653,18 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     if (tid < R) {
         const int64_t g = row0 + tid;
         const float s = s_[tid];
-        const float z = sect == 0 ? (a.fake ? a.fake[g] : 0.f) : (a.real ? a.real[g] : 1.f);
+        float z;
+        if (a.eps_ob) {  // injected tensors
+            z = sect == 0 ? (a.fake ? a.fake[g] : 0.f) : (a.real ? a.real[g] : 1.f);
+        } else {         // drawn here (discriminator.py:89-109)
+            const uint64_t step = (uint64_t)a.rng_step[0];
+            if (sect == 0)
+                z = a.label_smoothing == 2 ? fake_label(philox_uniform(a.rng_seed, step, RNG_FAKE, (uint64_t)g))
+                                           : 0.f;
+            else
+                z = a.label_smoothing >= 1 ? real_label(philox_uniform(a.rng_seed, step, RNG_REAL, (uint64_t)g))
+                                           : 1.f;
+        }
         const float sg = sigmoidf_(s);
         dq[tid] = (sg - z) / (float)a.B + a.ent_scale * s * sg * (1.f - sg) / (float)(2 * a.B);
         r0_[tid] = sig_ce(s, z);
@@ -611,65 +688,6 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     wgrad64(XC, in, DZb, part + oW1, part + ob1, R);
 }
 
-// Discriminator, second kernel (interpolate tiles only): with the batch-wide norm N known, the
-// cotangent V = 10 * 2(N-1)/N * g / (B*dim) is pushed forward through the masks (tangent pass) and
-// the gradient-penalty part of the weight gradient is written to this tile's slot:
-//   dW1 += V^T gz1,  dW2 += a1dot^T gz2,  dw3 += sum_r a2dot     (no bias terms)
-__global__ __launch_bounds__(NT) void disc2_kernel(DiscArgs a) {
-    extern __shared__ float lds[];
-    const int tid = threadIdx.x;
-    const int wg = blockIdx.x;
-    const int tiles_b = (int)(a.B / R);
-    const int64_t row0 = (int64_t)wg * R;
-    const int in = a.ob + a.ac;
-    float* p = lds;
-    NetL n = carve_net(p, in, 1);
-    float* XC = p; p += R * LD;
-    float* A1 = p; p += R * LD;
-    float* A2 = p; p += R * LD;
-    float* DZa = p; p += R * LD;
-    float* DZb = p; p += R * LD;
-    float* sh = p; p += 96;
-    float* G = p; p += R * LD;
-    float* ones = sh + 16;
-    float* coef = sh + 32;
-    load_net(n, a.params);
-    disc_rows(XC, a, row0, 2);
-    if (tid == 0) {
-        double so = 0.0, sa = 0.0;
-        for (int i = 0; i < tiles_b; ++i) { so += a.gp_part[2 * i]; sa += a.gp_part[2 * i + 1]; }
-        const double mo = so / ((double)a.B * a.ob), ma = sa / ((double)a.B * a.ac);
-        const double N = sqrt(mo + ma);
-        const double k = (double)a.gp_coeff * 2.0 * (N - 1.0) / N;
-        coef[0] = (float)(k / ((double)a.B * a.ob));
-        coef[1] = (float)(k / ((double)a.B * a.ac));
-        if (wg == 0) a.gp_out[0] = (float)((N - 1.0) * (N - 1.0));
-    }
-    __syncthreads();
-    disc_interp_chain(n, XC, A1, A2, DZa, DZb, G, ones);
-    // V = coef .* g, in place over G (columns beyond `in` are already zero)
-    for (int t = tid; t < R * LD; t += NT) {
-        const int c = t % LD;
-        G[t] = G[t] * (c < a.ob ? coef[0] : coef[1]);
-    }
-    __syncthreads();
-    float* part = a.partials + (int64_t)(2 * tiles_b + wg) * a.P;
-    const int64_t oW1 = 0, ob1 = (int64_t)in * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + H;
-    wgrad64(G, in, DZb, part + oW1, nullptr, 0);                 // V^T gz1
-    layer_tan(G, n.k4, n.W1, A1, A1);                            // a1dot = (V W1) .* m1  (in place)
-    if (tid < H) { part[ob1 + tid] = 0.f; part[ob2 + tid] = 0.f; }
-    if (tid == 0) part[ob3] = 0.f;
-    __syncthreads();
-    wgrad64(A1, H, DZa, part + oW2, nullptr, 0);                 // a1dot^T gz2
-    layer_tan(A1, H, n.W2, A2, A2);                              // a2dot = (a1dot W2) .* m2
-    __syncthreads();
-    if (tid < H) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += A2[r * LD + tid];
-        part[oW3 + tid] = s;
-    }
-}
-
 // One launch for every gradient pass of the step that needs no grid-wide value: the two agent roles
 // and the discriminator's first kernel are independent, so their workgroups share the chip.
 // Longest role first.
@@ -689,69 +707,115 @@ __global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
     __shared__ double shd[4];
+    __shared__ float sh_k;
     const int tid = threadIdx.x;
     // which segment does this block belong to?
     int seg = 0, b = blockIdx.x;
     while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
     const Segment& s = f.seg[seg];
-    double acc = 0.0;
-    for (int64_t i = (int64_t)b * 256 + tid; i < s.n; i += (int64_t)s.nblocks * 256) {
-        // slots are added in increasing order (fixed association); the loads of 8 slots are
-        // independent and issued together
-        float g = 0.f;
-        const float* src = s.partials + i;
-        int k = 0;
-        for (; k + 8 <= s.nslots; k += 8) {
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(k + q) * s.slot_stride];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) g += t[q];
+    if (tid < 64) {
+        // gradient-penalty scalars from the tiles' sums of squares: one wave, one batch of loads,
+        // fixed shuffle tree (identical in every block)
+        double so = 0.0, sa = 0.0;
+        if (f.gp_part)
+            for (int i = tid; i < f.gp_tiles; i += 64) { so += f.gp_part[2 * i]; sa += f.gp_part[2 * i + 1]; }
+        for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o, 64); sa += __shfl_xor(sa, o, 64); }
+        if (tid == 0) {
+            float k = 0.f;
+            if (f.gp_part) {
+                const double N = sqrt(so / ((double)f.B * f.ob) + sa / ((double)f.B * f.ac));
+                k = (float)((double)f.gp_coeff * 2.0 * (N - 1.0) / N);
+                shd[0] = (N - 1.0) * (N - 1.0);
+            }
+            sh_k = k;
         }
-        for (; k < s.nslots; ++k) g += src[(int64_t)k * s.slot_stride];
+    }
+    __syncthreads();
+    const double gp_loss = shd[0];
+    __syncthreads();
+    const float kgp = sh_k;
+    // 4 lanes per element: lane q adds slots q, q+4, ... in increasing order, then a fixed 2-level tree
+    const int q = tid & 3;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)b * 64 + (tid >> 2); i < s.n; i += (int64_t)s.nblocks * 64) {
+        const float* src = s.partials + i;
+        float g0 = 0.f, g1 = 0.f;  // plain slots, gp-scaled slots
+        int k = q;
+        for (; k + 12 < s.scaled_from; k += 16) {
+            const float t0 = src[(int64_t)k * s.slot_stride], t1 = src[(int64_t)(k + 4) * s.slot_stride],
+                        t2 = src[(int64_t)(k + 8) * s.slot_stride], t3 = src[(int64_t)(k + 12) * s.slot_stride];
+            g0 += t0; g0 += t1; g0 += t2; g0 += t3;
+        }
+        for (; k < s.scaled_from; k += 4) g0 += src[(int64_t)k * s.slot_stride];
+        for (; k + 12 < s.nslots; k += 16) {
+            const float t0 = src[(int64_t)k * s.slot_stride], t1 = src[(int64_t)(k + 4) * s.slot_stride],
+                        t2 = src[(int64_t)(k + 8) * s.slot_stride], t3 = src[(int64_t)(k + 12) * s.slot_stride];
+            g1 += t0; g1 += t1; g1 += t2; g1 += t3;
+        }
+        for (; k < s.nslots; k += 4) g1 += src[(int64_t)k * s.slot_stride];
+        g0 += __shfl_xor(g0, 1, 64); g0 += __shfl_xor(g0, 2, 64);
+        g1 += __shfl_xor(g1, 1, 64); g1 += __shfl_xor(g1, 2, 64);
+        float g = g0 + kgp * g1;
         if (s.wd > 0.f && ((i >= s.wd0_lo && i < s.wd0_hi) || (i >= s.wd1_lo && i < s.wd1_hi)))
             g += s.wd * s.param[i];
-        s.grad[i] = g;
-        acc += (double)g * (double)g;
+        if (q == 0) {
+            s.grad[i] = g;
+            acc += (double)g * (double)g;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) shd[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
-    // scalar losses: last block of the grid, thread 0 of each wave handles one family
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    // scalar losses: the last block's first wave; every lane loads one tile's partial sums
+    if (blockIdx.x == gridDim.x - 1 && tid < 64) {
+        auto wsum = [](double x) {
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            return x;
+        };
         if (f.agent_loss_part) {
             double h = 0.0, q = 0.0, dd = 0.0;
-            for (int k = 0; k < f.agent_tiles; ++k) {
+            for (int k = tid; k < f.agent_tiles; k += 64) {
                 h += (double)f.agent_loss_part[4 * k];
                 q += (double)f.agent_loss_part[4 * k + 1];
                 dd += (double)f.agent_loss_part[4 * k + 2];
             }
-            const double B = (double)f.B;
-            const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
-            f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl; f.actor_losses[2] = (float)(ql + dl);
-            const double tl = h / B * f.td_scale;
-            const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
-            f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl; f.critic_losses[2] = (float)(tl + wl);
+            h = wsum(h); q = wsum(q); dd = wsum(dd);
+            if (tid == 0) {
+                const double B = (double)f.B;
+                const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
+                f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl;
+                f.actor_losses[2] = (float)(ql + dl);
+                const double tl = h / B * f.td_scale;
+                const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
+                f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl;
+                f.critic_losses[2] = (float)(tl + wl);
+            }
         }
-        for (int k = 0; k < f.nseg; ++k)
-            if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
         if (f.disc_loss_part) {
             double pc = 0, ec = 0, pe = 0, ee = 0, pg = 0, eg = 0;
             const int tb = f.disc_tiles_b;
-            for (int k = 0; k < tb; ++k) {
+            for (int k = tid; k < tb; k += 64) {
                 pc += (double)f.disc_loss_part[4 * k]; pe += (double)f.disc_loss_part[4 * k + 1];
                 pg += (double)f.disc_loss_part[4 * k + 2];
                 ec += (double)f.disc_loss_part[4 * (tb + k)]; ee += (double)f.disc_loss_part[4 * (tb + k) + 1];
                 eg += (double)f.disc_loss_part[4 * (tb + k) + 2];
             }
-            const double B = (double)f.B;
-            const double pl = pc / B, el = ec / B, em = (pe + ee) / (2.0 * B), eloss = -(double)f.ent_scale * em;
-            f.disc_losses[0] = (float)pl; f.disc_losses[1] = (float)el; f.disc_losses[2] = (float)em;
-            f.disc_losses[3] = (float)eloss; f.disc_losses[4] = (float)(pg / B); f.disc_losses[5] = (float)(eg / B);
-            f.disc_losses[6] = f.gp[0];
-            f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * (double)f.gp[0]);
+            pc = wsum(pc); ec = wsum(ec); pe = wsum(pe); ee = wsum(ee); pg = wsum(pg); eg = wsum(eg);
+            if (tid == 0) {
+                const double B = (double)f.B;
+                const double pl = pc / B, el = ec / B, em = (pe + ee) / (2.0 * B),
+                             eloss = -(double)f.ent_scale * em;
+                f.disc_losses[0] = (float)pl; f.disc_losses[1] = (float)el; f.disc_losses[2] = (float)em;
+                f.disc_losses[3] = (float)eloss; f.disc_losses[4] = (float)(pg / B);
+                f.disc_losses[5] = (float)(eg / B);
+                f.disc_losses[6] = (float)gp_loss;
+                f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * gp_loss);
+            }
         }
+        if (tid == 0)
+            for (int k = 0; k < f.nseg; ++k)
+                if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
     }
 }
 
@@ -820,8 +884,9 @@ __global__ __launch_bounds__(256) void seg_sumsq_kernel(ApplyArgs f) {
 }
 
 size_t agent_lds_bytes(int ob, int ac, bool use_d) {
-    size_t f = net_lds_floats(ob, ac) + net_lds_floats(ob + ac, 1) + (use_d ? net_lds_floats(ob + ac, 1) : 0);
-    f += 7 * R * LD + R * LD3 + 64;
+    (void)use_d;  // the target+critic role always keeps three networks resident
+    size_t f = net_lds_floats(ob, ac) + 2 * net_lds_floats(ob + ac, 1);
+    f += 8 * R * LD + R * LD3 + 128;
     return f * sizeof(float);
 }
 size_t disc_lds_bytes(int in) {
@@ -837,7 +902,7 @@ bool supported(const samx_mlp* d, int64_t B) {
 }
 
 int seg_blocks(int64_t n) {
-    int64_t b = (n + 255) / 256;
+    int64_t b = (n + 63) / 64;
     return (int)(b < 1 ? 1 : (b > kMaxSegBlocks ? kMaxSegBlocks : b));
 }
 
@@ -857,20 +922,25 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
         if (l2 > lds) lds = l2;
     }
     SAMX_REQUIRE(lds <= 150 * 1024, "fused step kernel needs %zu bytes of LDS", lds);
+    // profiling aid: SAMX_FUSED_ROLES=<bitmask> (1 actor role, 2 target+critic role, 4 discriminator)
+    // launches a subset of the roles; results are then incomplete — never set it in production
+    static int roles = -1;
+    if (roles < 0) {
+        const char* e = getenv("SAMX_FUSED_ROLES");
+        roles = e ? atoi(e) : 7;
+    }
+    if (!(roles & 1)) s.n_a = 0;
+    if (!(roles & 2)) s.n_tc = 0;
+    if (!(roles & 4)) s.n_disc = 0;
+    if (s.n_a + s.n_tc + s.n_disc == 0) return SAMX_OK;
     static size_t attr_set = 0;  // largest dynamic-LDS size already granted
     if (lds > attr_set) {
         SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)step_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)disc2_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
     step_kernel<<<(unsigned)(s.n_a + s.n_tc + s.n_disc), NT, lds, st>>>(s);
     SAMX_LAUNCH_CHECK();
-    if (d) {
-        disc2_kernel<<<(unsigned)(d->B / R), NT, disc_lds_bytes(d->ob + d->ac), st>>>(*d);
-        SAMX_LAUNCH_CHECK();
-    }
     return SAMX_OK;
 }
 

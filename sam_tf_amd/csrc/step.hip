@@ -4,6 +4,7 @@
 //   reference sequence: sam.py:369-433 (D update, then mu.train(), then update_target_net())
 #include "samx_common.h"
 #include "fused_small.h"
+#include "rng.h"
 #include "../../include/samx.h"
 
 using namespace samx;
@@ -17,6 +18,9 @@ struct StepWs {
     size_t nets_bytes;
     void* disc_ws;
     size_t disc_bytes;
+    // layer-wise path only: gathered rows and materialised randoms
+    float *g_pobs, *g_pacs, *g_eobs, *g_eacs, *g_obs0, *g_acs, *g_rews, *g_dones, *g_obs1, *r_eob, *r_eac,
+        *r_real, *r_fake;
 };
 
 bool use_fused(const samx_learner* L, int64_t B) {
@@ -42,6 +46,13 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.disc_bytes = f ? 0 : samx_disc_ws_bytes(&L->reward, B);
     w.nets_ws = ar.take<char>(w.nets_bytes);
     w.disc_ws = ar.take<char>(w.disc_bytes);
+    const int64_t ob = L->ob_dim, ac = L->ac_dim, n = f ? 0 : B;
+    w.g_pobs = ar.take<float>(n * ob); w.g_pacs = ar.take<float>(n * ac);
+    w.g_eobs = ar.take<float>(n * ob); w.g_eacs = ar.take<float>(n * ac);
+    w.g_obs0 = ar.take<float>(n * ob); w.g_acs = ar.take<float>(n * ac);
+    w.g_rews = ar.take<float>(n); w.g_dones = ar.take<float>(n); w.g_obs1 = ar.take<float>(n * ob);
+    w.r_eob = ar.take<float>(n * ob); w.r_eac = ar.take<float>(n * ac);
+    w.r_real = ar.take<float>(n); w.r_fake = ar.take<float>(n);
     return w;
 }
 
@@ -91,9 +102,127 @@ fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, fl
     return f;
 }
 
+__global__ __launch_bounds__(256) void randoms_kernel(uint64_t seed, const int64_t* step_dev, int64_t step,
+                                                      int64_t B, int ob, int ac, float* eps_ob, float* eps_ac,
+                                                      float* real, float* fake) {
+    const uint64_t st = step_dev ? (uint64_t)step_dev[0] : (uint64_t)step;
+    const int64_t n_ob = B * ob, n_ac = B * ac;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < n_ob + n_ac + 2 * B;
+         t += (int64_t)gridDim.x * 256) {
+        if (t < n_ob) eps_ob[t] = philox_uniform(seed, st, RNG_EPS_OB, (uint64_t)t);
+        else if (t < n_ob + n_ac) eps_ac[t - n_ob] = philox_uniform(seed, st, RNG_EPS_AC, (uint64_t)(t - n_ob));
+        else if (t < n_ob + n_ac + B) {
+            if (real) real[t - n_ob - n_ac] = real_label(philox_uniform(seed, st, RNG_REAL, (uint64_t)(t - n_ob - n_ac)));
+        } else if (fake) {
+            fake[t - n_ob - n_ac - B] = fake_label(philox_uniform(seed, st, RNG_FAKE, (uint64_t)(t - n_ob - n_ac - B)));
+        }
+    }
+}
+
+// rows e_start[0] .. e_start[0]+B of the expert pool -> dense [B, *] (layer-wise path only)
+__global__ __launch_bounds__(256) void expert_slice_kernel(const float* __restrict__ obs,
+                                                           const float* __restrict__ acs,
+                                                           const int64_t* __restrict__ e_start, int64_t B,
+                                                           int ob, int ac, float* __restrict__ o_obs,
+                                                           float* __restrict__ o_acs) {
+    const int64_t e0 = e_start[0];
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < B * (ob + ac); t += (int64_t)gridDim.x * 256) {
+        if (t < B * ob) o_obs[t] = obs[e0 * ob + t];
+        else o_acs[t - B * ob] = acs[e0 * ac + (t - B * ob)];
+    }
+}
+
+// float64 column sums of the discriminator's 2B input rows read in place, one workgroup.
+// threads = rowlanes x dimpad; every row lane adds its rows in increasing order, lanes are then
+// combined by a fixed binary tree (deterministic).
+__global__ __launch_bounds__(1024) void d_input_stats_kernel(
+    const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
+    const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
+    const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
+    int commit, double* __restrict__ sums, float* __restrict__ mean_out, float* __restrict__ std_out) {
+    extern __shared__ double shd[];  // [2][1024]
+    const int tid = threadIdx.x;
+    const int col = tid % dimpad, lane = tid / dimpad, lanes = 1024 / dimpad;
+    const int64_t e0 = e_start ? e_start[0] : 0;
+    double a = 0.0, q = 0.0;
+    if (col < dim) {
+        for (int64_t r = lane; r < 2 * B; r += lanes) {
+            double v;
+            if (r < B) {
+                int64_t pr = r;
+                if (p_idx) { pr = ring_start + p_idx[r]; if (pr >= ring_len) pr -= ring_len; }
+                v = (double)replay_obs0[pr * dim + col];
+            } else {
+                v = (double)pool_obs0[(e0 + (r - B)) * dim + col];
+            }
+            a = __dadd_rn(a, v);
+            q = __dadd_rn(q, __dmul_rn(v, v));
+        }
+    }
+    shd[tid] = a;
+    shd[1024 + tid] = q;
+    __syncthreads();
+    for (int s = lanes / 2; s > 0; s >>= 1) {
+        if (lane < s) {
+            shd[tid] = __dadd_rn(shd[tid], shd[tid + s * dimpad]);
+            shd[1024 + tid] = __dadd_rn(shd[1024 + tid], shd[1024 + tid + s * dimpad]);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && col < dim) {
+        const double ta = shd[tid], tq = shd[1024 + tid];
+        addvec[col] = ta;
+        addvec[dim + col] = tq;
+        if (commit) {  // helpers/mpi_running_mean_std.py:31-45
+            const double cnt = sums[2 * dim] + (double)(2 * B);
+            const double s1 = __dadd_rn(sums[col], ta), s2 = __dadd_rn(sums[dim + col], tq);
+            sums[col] = s1;
+            sums[dim + col] = s2;
+            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+            mean_out[col] = mean;
+            std_out[col] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        addvec[2 * dim] = (double)(2 * B);
+        if (commit) sums[2 * dim] = sums[2 * dim] + (double)(2 * B);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int samx_disc_randoms(uint64_t rng_seed, int64_t step, int64_t B, int ob_dim, int ac_dim, float* eps_ob,
+                      float* eps_ac, float* real_labels, float* fake_labels, void* stream) {
+    SAMX_REQUIRE(eps_ob && eps_ac && B > 0 && ob_dim > 0 && ac_dim > 0 && step >= 0,
+                 "samx_disc_randoms: bad arguments");
+    const int64_t n = B * (ob_dim + ac_dim + 2);
+    randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0,
+                     (hipStream_t)stream>>>(rng_seed, nullptr, step, B, ob_dim, ac_dim, eps_ob, eps_ac,
+                                            real_labels, fake_labels);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                       const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
+                       int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
+                       float* std_out, void* stream) {
+    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "samx_d_input_stats: bad arguments");
+    SAMX_REQUIRE(ob_dim <= 1024, "samx_d_input_stats: ob_dim %d > 1024", ob_dim);
+    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
+                 "samx_d_input_stats: bad ring geometry");
+    SAMX_REQUIRE(!commit || (sums && mean_out && std_out), "samx_d_input_stats: commit needs sums/mean/std");
+    int dimpad = 1;
+    while (dimpad < ob_dim) dimpad *= 2;
+    d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
+        replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
+        mean_out, std_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
 
 int samx_fused_supported(const samx_learner* L, int64_t B) { return L && use_fused(L, B) ? 1 : 0; }
 
@@ -110,9 +239,14 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(b && o && ws, "samx_step_grads: null argument");
     SAMX_REQUIRE(b->B > 0, "samx_step_grads: empty batch");
-    SAMX_REQUIRE(b->p_obs && b->p_acs && b->e_obs && b->e_acs && b->eps_ob && b->eps_ac && b->obs0 &&
-                     b->acs && b->rews && b->dones1 && b->obs1,
+    SAMX_REQUIRE(b->p_obs && b->p_acs && b->e_obs && b->e_acs && b->obs0 && b->acs && b->rews &&
+                     b->dones1 && b->obs1,
                  "samx_step_grads: missing batch input");
+    SAMX_REQUIRE((b->eps_ob == nullptr) == (b->eps_ac == nullptr), "samx_step_grads: eps_ob/eps_ac go together");
+    SAMX_REQUIRE(b->label_smoothing >= 0 && b->label_smoothing <= 2, "samx_step_grads: label_smoothing");
+    SAMX_REQUIRE((!b->p_idx && !b->a_idx) ||
+                     (b->ring_len > 0 && b->ring_start >= 0 && b->ring_start < b->ring_len),
+                 "samx_step_grads: bad ring geometry");
     SAMX_REQUIRE(o->d_losses && o->actor_losses && o->critic_losses && o->targ_q,
                  "samx_step_grads: missing output buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -129,7 +263,40 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     const float* tc = L->targets + Pa;
 
     if (!use_fused(L, B)) {
-        // layer-wise path, role by role (same order as the reference: D first)
+        // layer-wise path, role by role (same order as the reference: D first).  It works on dense
+        // rows and materialised randoms, so indirection / in-kernel draws are resolved first.
+        samx_batch dense = *b;
+        const int ob = L->ob_dim, ac = L->ac_dim;
+        if (b->p_idx) {
+            rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
+                                    ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
+            if (rc != SAMX_OK) return rc;
+            dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
+        }
+        if (b->e_start) {
+            expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
+            SAMX_LAUNCH_CHECK();
+            dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
+        }
+        if (b->a_idx) {
+            rc = samx_replay_gather(b->obs0, b->acs, b->rews, b->dones1, b->obs1, b->ring_len, b->ring_start,
+                                    ob, ac, b->a_idx, B, w.g_obs0, w.g_acs, w.g_rews, w.g_dones, w.g_obs1,
+                                    stream);
+            if (rc != SAMX_OK) return rc;
+            dense.obs0 = w.g_obs0; dense.acs = w.g_acs; dense.rews = w.g_rews; dense.dones1 = w.g_dones;
+            dense.obs1 = w.g_obs1;
+        }
+        if (!b->eps_ob) {
+            const int64_t n = B * (ob + ac + 2);
+            randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
+                b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
+                b->label_smoothing >= 1 ? w.r_real : nullptr, b->label_smoothing == 2 ? w.r_fake : nullptr);
+            SAMX_LAUNCH_CHECK();
+            dense.eps_ob = w.r_eob; dense.eps_ac = w.r_eac;
+            dense.real_labels = b->label_smoothing >= 1 ? w.r_real : nullptr;
+            dense.fake_labels = b->label_smoothing == 2 ? w.r_fake : nullptr;
+        }
+        b = &dense;
         rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
                             b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,
                             L->ent_reg_scale, o->d_losses, L->grads + Pa + Pc, w.disc_ws, w.disc_bytes,
@@ -162,6 +329,8 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     d.ent_scale = L->ent_reg_scale; d.gp_coeff = 10.f;  // discriminator.py:154
     d.partials = w.disc_part; d.P = Pd; d.loss_part = w.disc_loss; d.gp_part = w.gp_part;
     d.gp_out = w.gp_out;
+    d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
+    d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
 
     fused::AgentArgs a;
     a.obs0 = b->obs0; a.acs = b->acs; a.rews = b->rews; a.dones1 = b->dones1; a.obs1 = b->obs1;
@@ -172,6 +341,7 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     a.q_scale = L->q_actor_loss_scale; a.d_scale = L->d_actor_loss_scale;
     a.targ_q_out = o->targ_q; a.td_out = o->td;
     a.partials = w.agent_part; a.P = Pa + Pc; a.Pa = Pa; a.loss_part = w.agent_loss;
+    a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
     rc = fused::launch_step(&a, &d, st);
     if (rc != SAMX_OK) return rc;
 
@@ -184,6 +354,7 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
         s.partials = k < 2 ? w.agent_part + off[k] : w.disc_part;
         s.slot_stride = k < 2 ? Pa + Pc : Pd;
         s.nslots = k < 2 ? tiles : 3 * tiles;
+        s.scaled_from = k < 2 ? tiles : 2 * tiles;
         s.n = n[k];
         s.grad = L->grads + off[k];
         s.nblocks = fused::seg_blocks(n[k]);
@@ -204,6 +375,7 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     f.actor_losses = o->actor_losses; f.critic_losses = o->critic_losses;
     f.disc_loss_part = w.disc_loss; f.disc_tiles_b = tiles;
     f.ent_scale = L->ent_reg_scale; f.gp_coeff = 10.f; f.gp = w.gp_out; f.disc_losses = o->d_losses;
+    f.gp_part = w.gp_part; f.gp_tiles = tiles; f.ob = L->ob_dim; f.ac = L->ac_dim;
     return fused::launch_finalize(f, st);
 }
 

@@ -12,9 +12,11 @@ around two row gathers and the running-mean kernels; the discriminator's and the
 do not depend on each other's fresh parameters, so they are computed side by side and ONE flat
 [actor | critic | reward-net] all-reduce serves the step (plus the 2*ob+1 doubles of the obs sums).
 With `use_graph` each stretch of kernels between two collectives is captured once into a HIP graph
-(torch.cuda.CUDAGraph on the stream the C ABI is handed) and replayed.  Host work per step: the
-reference's RNG draws (np.random.randint / random.random, same generators, same order), two small
-pinned H2D copies, the graph launches, and for N > 1 the RCCL calls.  Data-parallel ranks each own a
+(torch.cuda.CUDAGraph on the stream the C ABI is handed) and replayed.  Rows are read in place
+from the replay storage / expert pool through index words (no gather pass) and the discriminator's
+random tensors are drawn inside the kernels (Philox keyed by seed and update count).  Host work per
+step: the reference's RNG draws (np.random.randint / random.random, same generators, same order), ONE
+packed pinned H2D copy, the graph launches, and for N > 1 the RCCL calls.  Data-parallel ranks each own a
 replay shard and a minibatch; only gradients and running-mean sums are exchanged.
 """
 import random as _random
@@ -26,13 +28,15 @@ from . import ops
 
 
 class _Slot(object):
-    """Pinned staging for one step's host-drawn numbers; an event guards its reuse."""
+    """Pinned staging for one step's host-drawn numbers (one packed H2D copy); an event guards reuse.
+    Layout (int64 words): [idx_p (B) | idx_a (B) | e_start (1)] then B float64 PER uniforms."""
 
     def __init__(self, B):
-        self.idx_p = torch.empty(B, dtype=torch.int64).pin_memory()
-        self.idx_a = torch.empty(B, dtype=torch.int64).pin_memory()
-        self.idx_e = torch.empty(B, dtype=torch.int64).pin_memory()
-        self.u = torch.empty(B, dtype=torch.float64).pin_memory()
+        self.words = torch.empty(2 * B + 1 + B, dtype=torch.int64).pin_memory()
+        self.idx_p = self.words[:B]
+        self.idx_a = self.words[B:2 * B]
+        self.e_start = self.words[2 * B:2 * B + 1]
+        self.u = self.words[2 * B + 1:].view(torch.float64)
         self.event = None
 
 
@@ -48,62 +52,62 @@ class UpdateStepDriver(object):
         self.dev = dev
         self.per = bool(mu.hps.prioritized_replay)
         self.use_graph = bool(use_graph)
-        ob, ac = mu.ob_dim, mu.ac_dim
         f32 = dict(dtype=torch.float32, device=dev)
+        rb = mu.replay_buffer
+        assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
         # static device buffers (their addresses are baked into the captured graphs)
-        self.idx_p = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.idx_a = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.idx_e = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.u = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.words = torch.zeros(3 * B + 1, dtype=torch.int64, device=dev)
+        self.idx_p = self.words[:B]
+        self.idx_a = self.words[B:2 * B]
+        self.e_start = self.words[2 * B:2 * B + 1]
+        self.u = self.words[2 * B + 1:].view(torch.float64)
         self.iws = torch.zeros(B, dtype=torch.float64, device=dev)
         self.iws32 = torch.zeros(B, **f32)
-        self.pb = dict(obs0=torch.zeros(B, ob, **f32), acs=torch.zeros(B, ac, **f32))
-        self.eb = dict(obs0=torch.zeros(B, ob, **f32), acs=torch.zeros(B, ac, **f32))
-        self.ab = {k: torch.zeros(B, w, **f32) for k, w in
-                   (('obs0', ob), ('acs', ac), ('rews', 1), ('dones1', 1), ('obs1', ob))}
-        self.eps_ob = torch.zeros(B, ob, **f32)
-        self.eps_ac = torch.zeros(B, ac, **f32)
-        self.real = torch.zeros(B, **f32)
-        self.fake = torch.zeros(B, **f32)
         hp = d.hps
-        self.batch = ops.make_batch(
-            B, p_obs=self.pb['obs0'], p_acs=self.pb['acs'], e_obs=self.eb['obs0'], e_acs=self.eb['acs'],
-            eps_ob=self.eps_ob, eps_ac=self.eps_ac,
-            real_labels=self.real if hp.label_smoothing else None,
-            fake_labels=self.fake if (hp.label_smoothing and not hp.one_sided_label_smoothing) else None,
-            obs0=self.ab['obs0'], acs=self.ab['acs'], rews=self.ab['rews'].view(B),
-            dones1=self.ab['dones1'].view(B), obs1=self.ab['obs1'],
-            iws=self.iws32 if self.per else None)
+        st = rb.store
+        self.rng_seed = int(hp.seed) * 1000003 + 7919 * (self.comm.Get_rank() + 1)
+        self.label_mode = 0 if not hp.label_smoothing else (1 if hp.one_sided_label_smoothing else 2)
+        self._batch_start = None
         self.out = ops.make_step_out(B, dev)
         self.td_post = torch.zeros(B, **f32)
+        self.gb = {k: torch.zeros(B, st[k].shape[1], **f32) for k in ('obs0', 'acs')}  # PER refresh rows
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
         self.slots = [_Slot(B) for _ in range(n_slots)]
         self.step_no = 0
         self.plan = None
         self.fused = self.L.fused(B)
+        self._make_batch()
+
+    def _make_batch(self):
+        """(Re)build the samx_batch: every row is read IN PLACE from the replay storage / expert pool
+        through the index words (no gather pass); D randoms are drawn inside the kernels."""
+        rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
+        self._batch_start = rb.start
+        self.batch = ops.make_batch(
+            self.B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
+            obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
+            obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=self.idx_p, a_idx=self.idx_a,
+            e_start=self.e_start, ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
+            label_smoothing=self.label_mode)
 
     # ------------------------------------------------------------------ device segments
     def _seg_inputs(self):
-        mu, d = self.mu, self.d
-        mu.replay_buffer.batchify_device(self.idx_p, want=('obs0', 'acs'), out=self.pb)
-        # expert pairs: consecutive rows of the shuffled pool (demo_dataset.py:28-41)
-        ops.check(ops._L().samx_replay_gather(
-            ops.ptr(self.pool.obs0), ops.ptr(self.pool.acs), None, None, None, self.pool.num_entries, 0,
-            mu.ob_dim, mu.ac_dim, ops.ptr(self.idx_e), self.B, ops.ptr(self.eb['obs0']),
-            ops.ptr(self.eb['acs']), None, None, None, ops.stream_ptr()))
-        if d.hps.rmsify_obs:  # sam.py:389-390
-            ops.rms_batch_sums(self.pb['obs0'], self.eb['obs0'], d.obs_rms.addvec)
+        """d.obs_rms.update on the D batch (sam.py:389-390); single process: sums + commit at once."""
+        d, rb = self.d, self.mu.replay_buffer
+        if d.hps.rmsify_obs:
+            r = d.obs_rms
+            ops.d_input_stats(rb.store['obs0'], self._batch_start, self.idx_p, self.pool.obs0, self.e_start,
+                              self.B, r.addvec, commit=self.world == 1, sums=r.sums, mean=r.mean, std=r.std)
 
     def _seg_grads(self):
         mu, d = self.mu, self.d
-        if d.hps.rmsify_obs:
+        if d.hps.rmsify_obs and self.world > 1:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
         if self.per:  # memory.py:248-309 on the device trees
             mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
-        mu.replay_buffer.batchify_device(self.idx_a, out=self.ab)
         ops.step_grads(self.L, self.batch, self.out)
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
         ops.step_apply(self.L, self.B, 3 if self.world == 1 else 1, 1.0)
@@ -118,7 +122,8 @@ class UpdateStepDriver(object):
         if self.per:  # TD errors with the POST-update critic (sam_agent.py:693-701)
             mu = self.mu
             mean, std = mu._mean_std()
-            ops.td_errors(mu.dc, mu.critic.flat, self.ab['obs0'], self.ab['acs'], self.out.t['targ_q'],
+            mu.replay_buffer.batchify_device(self.idx_a, want=('obs0', 'acs'), out=self.gb)
+            ops.td_errors(mu.dc, mu.critic.flat, self.gb['obs0'], self.gb['acs'], self.out.t['targ_q'],
                           mean, std, mu.ws, out=self.td_post)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
@@ -164,7 +169,7 @@ class UpdateStepDriver(object):
         # expert batch pointer arithmetic (demo_dataset.py:33-40)
         if self.pool.pointer + B >= self.pool.num_entries:
             self.pool.init_pointer()
-        slot.idx_e.copy_(torch.arange(self.pool.pointer, self.pool.pointer + B))
+        slot.e_start[0] = self.pool.pointer
         self.pool.pointer += B
         if self.per:
             slot.u.copy_(torch.from_numpy(rb.draw_uniforms(B)))           # memory.py:278
@@ -172,23 +177,16 @@ class UpdateStepDriver(object):
             slot.idx_a.copy_(torch.from_numpy(np.random.randint(low=0, high=rb.num_entries, size=B)))
 
     def _upload(self, slot):
-        self.idx_p.copy_(slot.idx_p, non_blocking=True)
-        self.idx_e.copy_(slot.idx_e, non_blocking=True)
-        if self.per:
-            self.u.copy_(slot.u, non_blocking=True)
-        else:
-            self.idx_a.copy_(slot.idx_a, non_blocking=True)
+        self.words.copy_(slot.words, non_blocking=True)   # ONE packed H2D copy per step
         ev = torch.cuda.Event()
         ev.record()
         slot.event = ev
-        # TF-random tensors of the D graph (discriminator.py:101-109,130-133), fresh every update
-        d = self.d
-        self.eps_ob.uniform_(0, 1, generator=d.gen)
-        self.eps_ac.uniform_(0, 1, generator=d.gen)
-        if d.hps.label_smoothing:
-            self.real.uniform_(0, 1, generator=d.gen).mul_(-0.5).add_(1.2)
-            if not d.hps.one_sided_label_smoothing:
-                self.fake.uniform_(0, 1, generator=d.gen).mul_(-0.3).add_(0.3)
+
+    def step_randoms(self, step):
+        """The D randoms the kernels drew for reward-net update `step` (for checkers)."""
+        return ops.disc_randoms(self.rng_seed, step, self.B, self.mu.ob_dim, self.mu.ac_dim,
+                                want_real=self.label_mode >= 1, want_fake=self.label_mode == 2,
+                                device=self.dev)
 
     def prepare(self):
         """Build (and, with use_graph, capture) the device plan.  Capturing executes the segments —
@@ -202,7 +200,7 @@ class UpdateStepDriver(object):
             keep += [d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]
         saved = [t.clone() for t in keep]
         rng_np, rng_py = np.random.get_state(), _random.getstate()
-        ptr0, gen_state = self.pool.pointer, d.gen.get_state()
+        ptr0 = self.pool.pointer
         slot = self.slots[0]
         self._draw(slot)
         self._upload(slot)
@@ -214,12 +212,13 @@ class UpdateStepDriver(object):
         np.random.set_state(rng_np)
         _random.setstate(rng_py)
         self.pool.pointer = ptr0
-        d.gen.set_state(gen_state)
         torch.cuda.synchronize()
 
     def step(self):
         if self.plan is None:
             self.prepare()
+        assert self.mu.replay_buffer.start == self._batch_start, \
+            "replay ring moved: call driver.refresh() after appending transitions"
         slot = self.slots[self.step_no % len(self.slots)]
         self._draw(slot)
         self._upload(slot)
@@ -234,6 +233,12 @@ class UpdateStepDriver(object):
             new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
             self.mu.replay_buffer.update_priorities(self._idx_host.numpy(), new_priorities)
         self.step_no += 1
+
+    def refresh(self):
+        """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""
+        self.plan = None
+        self._make_batch()
+        self.prepare()
 
     def outputs(self):
         """What the reference's loop logs per step (sam.py:398-431), still in HBM."""

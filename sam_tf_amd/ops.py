@@ -379,17 +379,61 @@ class LearnerState(object):
         return self._ws[B]
 
 
-def make_batch(B, **tensors):
+_BATCH_F32 = ('p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
+              'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')
+_BATCH_I64 = ('p_idx', 'a_idx', 'e_start')
+_BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing')
+
+
+def make_batch(B, **fields):
+    """Fill a `samx_batch`.  float32 / int64 CUDA tensors for the pointer fields, ints for the rest.
+    Row-count checks apply to dense inputs only (indirect inputs address whole storages)."""
     b = _lib.Batch()
     b.B = int(B)
     keep = []
-    for k, t in tensors.items():
-        if t is not None:
-            assert t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.shape[0] == B, k
-            keep.append(t)
-            setattr(b, k, t.data_ptr())
+    indirect_p = fields.get('p_idx') is not None
+    indirect_a = fields.get('a_idx') is not None
+    indirect_e = fields.get('e_start') is not None
+    for k, t in fields.items():
+        if t is None:
+            continue
+        if k in _BATCH_INT:
+            setattr(b, k, int(t))
+            continue
+        want = F32 if k in _BATCH_F32 else I64
+        assert k in _BATCH_F32 or k in _BATCH_I64, 'unknown batch field %s' % k
+        assert t.is_cuda and t.dtype == want and t.is_contiguous(), k
+        dense = not ((indirect_p and k in ('p_obs', 'p_acs')) or (indirect_e and k in ('e_obs', 'e_acs')) or
+                     (indirect_a and k in ('obs0', 'acs', 'rews', 'dones1', 'obs1')) or k == 'e_start')
+        if dense:
+            assert t.shape[0] == B, '%s must have %d rows' % (k, B)
+        keep.append(t)
+        setattr(b, k, t.data_ptr())
     b._keep = keep
     return b
+
+
+def disc_randoms(seed, step, B, ob, ac, want_real=True, want_fake=False, device='cuda'):
+    """The tensors samx_step_grads draws itself for reward-net update number `step` (0-based)."""
+    eo = torch.empty(B, ob, dtype=F32, device=device); ea = torch.empty(B, ac, dtype=F32, device=device)
+    real = torch.empty(B, dtype=F32, device=device) if want_real else None
+    fake = torch.empty(B, dtype=F32, device=device) if want_fake else None
+    check(_L().samx_disc_randoms(int(seed), int(step), int(B), int(ob), int(ac), ptr(eo), ptr(ea), ptr(real),
+                                 ptr(fake), stream_ptr()))
+    return eo, ea, real, fake
+
+
+def d_input_stats(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec, commit=False, sums=None,
+                  mean=None, std=None):
+    ring_len, ob = replay_obs0.shape
+    _chk(replay_obs0, F32, (ring_len, ob), 'replay_obs0'); _chk(pool_obs0, F32, (pool_obs0.shape[0], ob), 'pool')
+    _opt(p_idx, I64, (B,), 'p_idx'); _opt(e_start, I64, (1,), 'e_start')
+    _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+    if commit:
+        _chk(sums, F64, (2 * ob + 1,), 'sums'); _chk(mean, F32, (ob,), 'mean'); _chk(std, F32, (ob,), 'std')
+    check(_L().samx_d_input_stats(ptr(replay_obs0), int(ring_start), int(ring_len), ptr(p_idx), ptr(pool_obs0),
+                                  ptr(e_start), int(B), int(ob), ptr(addvec), int(bool(commit)), ptr(sums),
+                                  ptr(mean), ptr(std), stream_ptr()))
 
 
 def make_step_out(B, device='cuda'):

@@ -106,8 +106,10 @@ def test_k_steps_match_oracle(cfg_name, graph):
         drv.step()
         torch.cuda.synchronize()
         h = lambda t: t.cpu().numpy()
-        out = ref.step(h(drv.idx_p), h(drv.eb['obs0']), h(drv.eb['acs']), h(drv.eps_ob), h(drv.eps_ac),
-                       h(drv.real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
+        e0 = int(drv.e_start.item())
+        eps_ob, eps_ac, real, _ = drv.step_randoms(k)   # what the kernels drew for update k
+        out = ref.step(h(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
+                       h(eps_ac), h(real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
         if cfg['per']:
             assert np.array_equal(out['idx_a'], h(drv.idx_a)), 'PER indices differ at step %d' % k
         o = drv.outputs()
@@ -184,3 +186,38 @@ def test_drop_in_surface():
     assert [v.name for v in mu.actor.trainable_vars][:2] == ['mu/online_actor/fc1/kernel:0',
                                                             'mu/online_actor/fc1/bias:0']
     mu.reset_noise()
+
+
+def test_d_input_stats_and_randoms():
+    """In-place running-sum kernel == float64 numpy sums over the same rows; Philox draws are in
+    range, reproducible and differ between updates."""
+    from sam_tf_amd import ops
+    from oracle import nets_oracle as NO
+    rs = np.random.RandomState(0)
+    ring, ob, B = 500, 11, 64
+    store = torch.as_tensor(rs.randn(ring, ob).astype(np.float32)).cuda()
+    pool = torch.as_tensor((rs.randn(300, ob) + 0.5).astype(np.float32)).cuda()
+    idx = torch.as_tensor(rs.randint(0, ring, size=B)).cuda()
+    e_start = torch.tensor([37], dtype=torch.int64, device='cuda')
+    start = 123
+    add = torch.zeros(2 * ob + 1, dtype=torch.float64, device='cuda')
+    sums0 = NO.rms_init(ob)
+    sums = torch.as_tensor(sums0).cuda()
+    mean = torch.zeros(ob, device='cuda'); std = torch.zeros(ob, device='cuda')
+    ops.d_input_stats(store, start, idx, pool, e_start, B, add, commit=True, sums=sums, mean=mean, std=std)
+    rows = np.concatenate([store.cpu().numpy()[(start + idx.cpu().numpy()) % ring], pool.cpu().numpy()[37:37 + B]])
+    exp = NO.rms_update(sums0, rows, ob)
+    np.testing.assert_allclose(add.cpu().numpy(), exp - sums0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sums.cpu().numpy(), exp, rtol=1e-12)
+    em, es = NO.rms_mean_std(exp, ob)
+    np.testing.assert_allclose(mean.cpu().numpy(), em, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(std.cpu().numpy(), es, rtol=1e-6)
+    a = ops.disc_randoms(99, 3, 256, 11, 3, want_real=True, want_fake=True)
+    b = ops.disc_randoms(99, 3, 256, 11, 3, want_real=True, want_fake=True)
+    c = ops.disc_randoms(99, 4, 256, 11, 3, want_real=True, want_fake=True)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and not torch.equal(x, z)
+    eo, ea, real, fake = a
+    assert 0.0 <= float(eo.min()) and float(eo.max()) < 1.0 and abs(float(eo.mean()) - 0.5) < 0.02
+    assert 0.7 < float(real.min()) and float(real.max()) <= 1.2
+    assert 0.0 < float(fake.min()) and float(fake.max()) <= 0.3

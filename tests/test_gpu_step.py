@@ -132,3 +132,48 @@ def test_fused_matches_layerwise():
     _, ga = ops.actor_grad(L.da, _dev(P['pa']), L.dc, _dev(P['pc']), L.dd, _dev(P['pd'][::-1].copy()),
                            _dev(D['obs0']), _dev(c['mean']), _dev(c['std']), 0.4, 1.0, 0.5, ws)
     assert relerr(L.seg(g_f, 0).cpu().numpy(), ga.cpu().numpy()) < 2e-6
+
+
+def test_indirect_rows_and_kernel_randoms_match_dense():
+    """samx_step_grads reading rows in place through ring indices / the expert slice and drawing its
+    own D randoms == the same call on gathered rows with the materialised randoms (bit for bit on
+    the fused path, to rounding on the layer-wise path)."""
+    from sam_tf_amd import ops
+    for name in ('C2', 'ragged'):
+        c, L, dense, out = _setup(name, 0.0, 0.0, True)
+        B, ob, ac = c['B'], c['ob'], c['ac']
+        rs = np.random.RandomState(5)
+        ring, start = 4 * B + 3, 2 * B + 1
+        st = {k: torch.as_tensor(rs.randn(ring, w).astype(np.float32)).cuda()
+              for k, w in (('obs0', ob), ('acs', ac), ('rews', 1), ('dones1', 1), ('obs1', ob))}
+        pool_o = torch.as_tensor(rs.randn(3 * B, ob).astype(np.float32)).cuda()
+        pool_a = torch.as_tensor(rs.rand(3 * B, ac).astype(np.float32)).cuda()
+        idx_p = torch.as_tensor(rs.randint(0, ring, size=B)).cuda()
+        idx_a = torch.as_tensor(rs.randint(0, ring, size=B)).cuda()
+        e_start = torch.tensor([B // 2], dtype=torch.int64, device='cuda')
+        iws = _dev(c['D']['iws'])
+        L.steps[2] = 5  # pretend five reward-net updates happened: the randoms depend on it
+        ind = ops.make_batch(B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=pool_o, e_acs=pool_a,
+                             obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1),
+                             dones1=st['dones1'].view(-1), obs1=st['obs1'], iws=iws, p_idx=idx_p, a_idx=idx_a,
+                             e_start=e_start, ring_start=start, ring_len=ring, rng_seed=1234,
+                             label_smoothing=2)
+        ops.step_grads(L, ind, out)
+        g_ind = L.grads.clone(); l_ind = {k: v.clone() for k, v in out.t.items()}
+        rows = lambda t, ix: t[(start + ix) % ring].contiguous()
+        eo, ea, real, fake = ops.disc_randoms(1234, 5, B, ob, ac, want_real=True, want_fake=True)
+        L.steps[2] = 5
+        e0 = B // 2
+        den = ops.make_batch(B, p_obs=rows(st['obs0'], idx_p), p_acs=rows(st['acs'], idx_p),
+                             e_obs=pool_o[e0:e0 + B].contiguous(), e_acs=pool_a[e0:e0 + B].contiguous(),
+                             eps_ob=eo, eps_ac=ea, real_labels=real, fake_labels=fake,
+                             obs0=rows(st['obs0'], idx_a), acs=rows(st['acs'], idx_a),
+                             rews=rows(st['rews'], idx_a).view(-1), dones1=rows(st['dones1'], idx_a).view(-1),
+                             obs1=rows(st['obs1'], idx_a), iws=iws)
+        ops.step_grads(L, den, out)
+        if name == 'C2':
+            assert torch.equal(g_ind, L.grads)
+            for k in l_ind:
+                assert torch.equal(l_ind[k], out.t[k]), k
+        else:
+            assert relerr(g_ind.cpu().numpy(), L.grads.cpu().numpy()) < 1e-6
