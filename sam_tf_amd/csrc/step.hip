@@ -146,17 +146,31 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
     const int64_t e0 = e_start ? e_start[0] : 0;
     double a = 0.0, q = 0.0;
     if (col < dim) {
-        for (int64_t r = lane; r < 2 * B; r += lanes) {
-            double v;
-            if (r < B) {
-                int64_t pr = r;
-                if (p_idx) { pr = ring_start + p_idx[r]; if (pr >= ring_len) pr -= ring_len; }
-                v = (double)replay_obs0[pr * dim + col];
-            } else {
-                v = (double)pool_obs0[(e0 + (r - B)) * dim + col];
+        // rows in batches of 8: all index loads, then all data loads, then the adds in row order
+        for (int64_t rb = lane; rb < 2 * B; rb += (int64_t)lanes * 8) {
+            const float* src[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t r = rb + (int64_t)u * lanes;
+                src[u] = nullptr;
+                if (r < B) {
+                    int64_t pr = r;
+                    if (p_idx) { pr = ring_start + p_idx[r]; if (pr >= ring_len) pr -= ring_len; }
+                    src[u] = replay_obs0 + pr * dim + col;
+                } else if (r < 2 * B) {
+                    src[u] = pool_obs0 + (e0 + (r - B)) * dim + col;
+                }
             }
-            a = __dadd_rn(a, v);
-            q = __dadd_rn(q, __dmul_rn(v, v));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[u] ? *src[u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (src[u]) {
+                    const double x = (double)v[u];
+                    a = __dadd_rn(a, x);
+                    q = __dadd_rn(q, __dmul_rn(x, x));
+                }
         }
     }
     shd[tid] = a;

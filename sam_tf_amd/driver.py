@@ -37,7 +37,12 @@ class _Slot(object):
         self.idx_a = self.words[B:2 * B]
         self.e_start = self.words[2 * B:2 * B + 1]
         self.u = self.words[2 * B + 1:].view(torch.float64)
-        self.event = None
+        # numpy views of the pinned words: the host fills them without going through torch ops
+        w = self.words.numpy()
+        self.np_idx_p, self.np_idx_a, self.np_e = w[:B], w[B:2 * B], w[2 * B:2 * B + 1]
+        self.np_u = w[2 * B + 1:].view(np.float64)
+        self.event = torch.cuda.Event()
+        self.used = False
 
 
 class UpdateStepDriver(object):
@@ -162,25 +167,24 @@ class UpdateStepDriver(object):
         """The reference's host RNG draws for one step, in the reference's order."""
         rb = self.mu.replay_buffer
         B = self.B
-        if slot.event is not None:
+        if slot.used:
             slot.event.synchronize()
         # D batch: uniform pairs (sam.py:372-377 -> memory.py:90)
-        slot.idx_p.copy_(torch.from_numpy(np.random.randint(low=0, high=rb.num_entries, size=B)))
+        slot.np_idx_p[:] = np.random.randint(low=0, high=rb.num_entries, size=B)
         # expert batch pointer arithmetic (demo_dataset.py:33-40)
         if self.pool.pointer + B >= self.pool.num_entries:
             self.pool.init_pointer()
-        slot.e_start[0] = self.pool.pointer
+        slot.np_e[0] = self.pool.pointer
         self.pool.pointer += B
         if self.per:
-            slot.u.copy_(torch.from_numpy(rb.draw_uniforms(B)))           # memory.py:278
+            slot.np_u[:] = rb.draw_uniforms(B)                                     # memory.py:278
         else:
-            slot.idx_a.copy_(torch.from_numpy(np.random.randint(low=0, high=rb.num_entries, size=B)))
+            slot.np_idx_a[:] = np.random.randint(low=0, high=rb.num_entries, size=B)
 
     def _upload(self, slot):
         self.words.copy_(slot.words, non_blocking=True)   # ONE packed H2D copy per step
-        ev = torch.cuda.Event()
-        ev.record()
-        slot.event = ev
+        slot.event.record()
+        slot.used = True
 
     def step_randoms(self, step):
         """The D randoms the kernels drew for reward-net update `step` (for checkers)."""

@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes drive sam_tf_amd.comm.TorchComm (the mpi4py
+surface the reference threads through its helpers) and the exchange arithmetic of the update step:
+   gradient mean      helpers/mpi_adam.py:27  -> all-reduce(SUM) then 1/N inside the optimiser pass
+   running-mean sums  helpers/mpi_running_mean_std.py:55
+   sync_from_root / check_synced  helpers/mpi_adam.py:38-72
+The GPU kernels themselves are covered by the -m gpu tests; here the collectives' semantics are."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sam_tf_amd.comm import TorchComm, mpi_mean_like
+        from oracle import nets_oracle as NO
+        comm = TorchComm()
+        assert comm.Get_rank() == rank and comm.Get_size() == world
+        rs = np.random.RandomState(100 + rank)
+        # --- gradient all-reduce + mean (device-tensor form and numpy form agree)
+        g = rs.randn(5185).astype(np.float32)
+        t = torch.from_numpy(g.copy())
+        comm.allreduce_(t)
+        mean_np = mpi_mean_like(g, comm)
+        np.testing.assert_allclose(t.numpy() / world, mean_np, rtol=1e-6)
+        # oracle MpiAdam step from the per-rank grads == step from the all-reduced sum
+        all_g = [np.random.RandomState(100 + r).randn(5185).astype(np.float32) for r in range(world)]
+        th0 = np.zeros(5185)
+        th_a, _, _ = NO.mpi_adam_step(th0, np.zeros(5185), np.zeros(5185), all_g, 1e-3, 1, 5.0)
+        th_b, _, _ = NO.mpi_adam_step(th0, np.zeros(5185), np.zeros(5185), [t.numpy() / world], 1e-3, 1, 5.0)
+        np.testing.assert_allclose(th_a, th_b, rtol=1e-6, atol=1e-9)
+        # --- running-mean sums: all-reduce of the per-rank [sum, sumsq, count] == sums of all rows
+        ob = 7
+        x = rs.randn(33 + rank, ob).astype(np.float32)
+        add = NO.rms_update(np.zeros(2 * ob + 1), x, ob)
+        tot = torch.from_numpy(add.copy())
+        comm.allreduce_(tot)
+        xs = [np.random.RandomState(100 + r).randn(5185) for r in range(world)]  # burn identical draws
+        rows = np.concatenate([np.random.RandomState(100 + r).randn(5185 + (33 + r) * ob)[5185:].reshape(-1, ob)
+                               .astype(np.float32) for r in range(world)])
+        np.testing.assert_allclose(tot.numpy(), NO.rms_update(np.zeros(2 * ob + 1), rows, ob), rtol=1e-12)
+        # --- sync_from_root / check_synced semantics
+        p = torch.full((10,), float(rank))
+        comm.bcast_(p, root=0)
+        assert (p == 0).all()
+        buf = np.full(4, rank, dtype=np.float64)
+        comm.Bcast(buf, root=0)
+        assert (buf == 0).all()
+        recv = np.zeros(3)
+        comm.Allreduce(np.array([1.0, 2.0, rank]), recv)
+        np.testing.assert_allclose(recv, [world, 2 * world, sum(range(world))])
+        comm.Barrier()
+        out.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: 'ok', 1: 'ok'}, res
+
+
+def test_single_process_comm_is_local():
+    from sam_tf_amd.comm import TorchComm, mpi_mean_like
+    c = TorchComm()
+    assert c.Get_size() == 1 and c.Get_rank() == 0
+    t = torch.arange(4.0)
+    assert torch.equal(c.allreduce_(t.clone()), t)
+    np.testing.assert_allclose(mpi_mean_like(np.array([1.0, 3.0]), c), [1.0, 3.0])
+    c.Barrier()
