@@ -278,7 +278,10 @@ int samx_disc_randoms(uint64_t rng_seed, int64_t step, int64_t B, int ob_dim, in
 int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
                        const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
                        int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
-                       float* std_out, void* stream);
+                       float* std_out, void* ws, size_t ws_bytes, void* stream);
+/* Scratch for samx_d_input_stats (large inputs are summed by many workgroups into per-group float64
+ * partials that are then added in a fixed order); ws may be NULL when 2*B*ob_dim <= 16384. */
+size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
 
 /* d.get_grads/get_losses + mu's get_targ_q / actor & critic losses and grads (sam.py:398-399,

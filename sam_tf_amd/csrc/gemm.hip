@@ -1,17 +1,38 @@
 // fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32: exact f32 fma chain, so results are those of a k-ordered
 // fmaf loop) with fused bias / activation / mask epilogues.  64x64 output tile per 256-thread
-// workgroup (2x2 waves, one 32x32 accumulator each), K staged through LDS 16 deep.
+// workgroup (2x2 waves, one 32x32 accumulator each).
+//
+// These GEMMs are short (R = 256..400 for the layers, a few hundred rows per split for the weight
+// gradients) and often launch fewer workgroups than the chip has CUs, so what bounds them is the
+// global -> LDS -> MFMA latency chain of each reduction stage, not bandwidth.  Staging therefore runs
+// on the LDS-DMA path (global_load_lds_dword: no VGPR round trip, no compiler-scheduled waits) through
+// a ring of four 32-deep stages: up to three stages are in flight while one is on the matrix cores,
+// retired by COUNTED s_waitcnt vmcnt(N) and raw s_barrier (a __syncthreads() would drain the DMAs).
+//
 // Operands are addressed by (free, reduction) strides so the same kernel serves
-//   forward      Y = X W        (NN),
-//   backward     dX = dZ W^T    (NT),
-//   weight grad  dW = X^T dZ    (TN, reduction over the batch, optional split + ones row for db).
+//   forward      Y = X W        (NN: A reduction-contiguous, B free-contiguous),
+//   backward     dX = dZ W^T    (NT: both reduction-contiguous),
+//   weight grad  dW = X^T dZ    (TN: both free-contiguous; reduction over the batch, optional split
+//                                + a virtual ones row for db).
+// LDS image of one operand stage (8 KB, lane-linear per DMA instruction as the hardware requires):
+//   free-contiguous      : S[r][f], 32 rows of 64 floats, one DMA per row;
+//   reduction-contiguous : S[f][32], 64 rows of 32 floats, two rows per DMA, with the 32 reduction
+//                          positions of row f XOR-swizzled by (f & 31) ON THE SOURCE ADDRESS and again
+//                          on the read, so the MFMA operand read (32 lanes = 32 different f, same r)
+//                          hits 32 different banks.
+// Out-of-range free indices read a clamped (valid) address: they only feed output rows/columns that
+// are never stored.  Out-of-range reduction indices (last stage) and the ones row are patched in LDS
+// by the wave that issued the DMA, after its own vmcnt wait and before the barrier.
 #include "gemm.h"
 
 namespace samx {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
+constexpr int BM = 64, BN = 64, BK = 32, NS = 4;
+constexpr int TILE = BK * 64;            // floats per operand stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) float lds_float;
+typedef const __attribute__((address_space(1))) float glb_float;
 
 struct EpiCtx {
     const float* bias;
@@ -45,12 +66,81 @@ __device__ __forceinline__ float apply_epi(float v, int i, int j, const EpiCtx& 
     return v;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[BK][BM + PAD];
-    __shared__ float Bs[BK][BN + PAD];
+
+struct Operand {
+    const float* p;
+    int64_t sf, sr;  // strides of the free / reduction index (one of them is 1)
+    int F;           // free extent (rows of A incl. nothing virtual, columns of B)
+    int f0;          // first free index of this workgroup's tile
+};
+
+// DMA number d (0..31) of an operand stage; r0 = first reduction index of the stage
+template <bool RC>
+__device__ __forceinline__ void dma_one(const Operand& o, int d, int r0, int r_end, float* S, int lane) {
+    if (RC) {
+        const int fp = d * 2;  // row pair
+        const int f = fp + (lane >> 5);
+        int gr = r0 + ((lane & 31) ^ (f & 31));
+        gr = gr < r_end ? gr : r_end - 1;
+        int gf = o.f0 + f;
+        gf = gf < o.F ? gf : o.F - 1;
+        __builtin_amdgcn_global_load_lds((glb_float*)(o.p + (int64_t)gf * o.sf + gr), (lds_float*)(S + fp * 32),
+                                         4, 0, 0);
+    } else {
+        int gf = o.f0 + lane;
+        gf = gf < o.F ? gf : o.F - 1;
+        int gr = r0 + d;
+        gr = gr < r_end ? gr : r_end - 1;
+        __builtin_amdgcn_global_load_lds((glb_float*)(o.p + (int64_t)gr * o.sr + gf), (lds_float*)(S + d * 64),
+                                         4, 0, 0);
+    }
+}
+
+// zero the reduction tail (r0 + r >= r_end) of what DMA d filled
+template <bool RC>
+__device__ __forceinline__ void zero_tail(int rv, float* S, int d, int lane) {
+    if (RC) {
+        if (((lane & 31) ^ ((2 * d + (lane >> 5)) & 31)) >= rv) S[d * 64 + lane] = 0.f;
+    } else {
+        if (d >= rv) S[d * 64 + lane] = 0.f;
+    }
+}
+
+template <bool RC>
+__device__ __forceinline__ int frag_base(int lane, int w32) {
+    // operand element (f = w32 + (lane & 31), r = 2 kk + (lane >> 5))
+    if (RC) return (w32 + (lane & 31)) * 32;
+    return (lane >> 5) * 64 + w32 + (lane & 31);
+}
+template <bool RC>
+__device__ __forceinline__ float frag(const float* S, int base, int kk, int lane) {
+    if (RC) return S[base + ((2 * kk + (lane >> 5)) ^ (lane & 31))];  // (w32 + l) & 31 == l & 31
+    return S[base + kk * 128];
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+}
+
+// KS = 1: 4 waves, wave w owns the 32x32 quadrant w of the tile and runs the whole reduction.
+// KS = 4: 16 waves, wave w owns quadrant w & 3 and the quarter w >> 2 of every stage's reduction; the
+//         four partial accumulators of a quadrant are added through LDS in slice order at the end.
+//         Used when a launch has too few workgroups to give every SIMD a wave: the serial chain of
+//         dependent MFMAs per wave is what such a launch waits for, and this cuts it by four.
+template <int EPI, bool A_RC, bool B_RC, int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
+    constexpr int NW = 4 * KS;        // waves
+    constexpr int DPW = 32 / NW;      // DMAs per wave per operand stage
+    constexpr int MPW = (BK / 2) / KS;  // MFMAs per wave per stage
+    __shared__ float lds[NS * 2 * TILE];  // ONE array: [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int quad = wave & 3, slice = wave >> 2;
+    const int wm = quad >> 1, wn = quad & 1;
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     const bool ones = g.a_ones_rows >= 0;
     const int Mo = g.M + (ones ? 1 : 0);
@@ -64,57 +154,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
-    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-        // ---- stage A tile: As[r][i]
-        if (g.a_sr == 1) {  // reduction index contiguous in memory
-            const int i = tid >> 2, rq = (tid & 3) * 4, gi = i0 + i;
+    const int T = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;  // block-uniform
+    const Operand oa{g.A, g.a_si, g.a_sr, g.M, i0}, ob{g.B, g.b_sj, g.b_sr, g.N, j0};
+    const int ones_lane = g.M - i0;  // lane of the virtual ones row in this tile (A free-contiguous)
+    const bool patch_ones = ones && ones_lane >= 0 && ones_lane < BM;
+    const int abase = frag_base<A_RC>(lane, wm * 32), bbase = frag_base<B_RC>(lane, wn * 32);
+    const int d0 = wave * DPW;  // this wave's DMAs of a stage: d0 .. d0 + DPW - 1, for A and for B
+
+    for (int s = 0; s < NS - 1 && s < T; ++s) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + rq + q;
-                float v = 0.f;
-                if (r < r_end) {
-                    if (gi < g.M) v = g.A[(int64_t)gi * g.a_si + r];
-                    else if (ones && gi == g.M) v = (r < g.a_ones_rows) ? 1.f : 0.f;
-                }
-                As[rq + q][i] = v;
-            }
-        } else {  // free index contiguous
-            const int rr = tid >> 4, iq = (tid & 15) * 4, r = r0 + rr;
+        for (int q = 0; q < DPW; ++q) {
+            dma_one<A_RC>(oa, d0 + q, r_begin + s * BK, r_end, lds + s * 2 * TILE, lane);
+            dma_one<B_RC>(ob, d0 + q, r_begin + s * BK, r_end, lds + s * 2 * TILE + TILE, lane);
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        float* Sa = lds + (t % NS) * 2 * TILE;
+        float* Sb = Sa + TILE;
+        // stages issued after t and still allowed in flight: t+1 .. min(t+NS-2, T-1)
+        const int ahead = min(NS - 2, T - 1 - t);
+        if (ahead >= 2) wait_vm<4 * DPW>();
+        else if (ahead == 1) wait_vm<2 * DPW>();
+        else wait_vm<0>();
+        const int r0 = r_begin + t * BK, rv = r_end - r0;
+        if (rv < BK) {  // last, partial stage: this wave zeroes the tail of what it loaded
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gi = i0 + iq + q;
-                float v = 0.f;
-                if (r < r_end) {
-                    if (gi < g.M) v = g.A[(int64_t)r * g.a_sr + gi];
-                    else if (ones && gi == g.M) v = (r < g.a_ones_rows) ? 1.f : 0.f;
-                }
-                As[rr][iq + q] = v;
+            for (int q = 0; q < DPW; ++q) {
+                zero_tail<A_RC>(rv, Sa, d0 + q, lane);
+                zero_tail<B_RC>(rv, Sb, d0 + q, lane);
             }
         }
-        // ---- stage B tile: Bs[r][j]
-        if (g.b_sj == 1) {
-            const int rr = tid >> 4, jq = (tid & 15) * 4, r = r0 + rr;
+        if (patch_ones && lane == ones_lane) {  // A(M, r) = (r < a_ones_rows); A is free-contiguous
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gj = j0 + jq + q;
-                Bs[rr][jq + q] = (r < r_end && gj < g.N) ? g.B[(int64_t)r * g.b_sr + gj] : 0.f;
+            for (int q = 0; q < DPW; ++q) {
+                const int gr = r0 + d0 + q;
+                Sa[(d0 + q) * 64 + lane] = (gr < r_end && gr < g.a_ones_rows) ? 1.f : 0.f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // every wave is past the MFMAs of stage t-1, so that slot is refilled now, the DMAs issued
+        // between the MFMAs of this stage
+        const bool refill = t + NS - 1 < T;
+        float* Nx = lds + ((t + NS - 1) % NS) * 2 * TILE;
+        const int rn = r0 + (NS - 1) * BK;
+        float fa[MPW], fb[MPW];  // this wave's operand fragments of the stage, read ahead of the MFMAs
+#pragma unroll
+        for (int k = 0; k < MPW; ++k) {
+            fa[k] = frag<A_RC>(Sa, abase, slice * MPW + k, lane);
+            fb[k] = frag<B_RC>(Sb, bbase, slice * MPW + k, lane);
+        }
+        if (refill) {
+#pragma unroll
+            for (int k = 0; k < MPW; ++k) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
+                if (k < DPW) dma_one<A_RC>(oa, d0 + k, rn, r_end, Nx, lane);
+                else if (k < 2 * DPW) dma_one<B_RC>(ob, d0 + k - DPW, rn, r_end, Nx + TILE, lane);
             }
         } else {
-            const int j = tid >> 2, rq = (tid & 3) * 4, gj = j0 + j;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + rq + q;
-                Bs[rq + q][j] = (r < r_end && gj < g.N) ? g.B[(int64_t)gj * g.b_sj + r] : 0.f;
-            }
+            for (int k = 0; k < MPW; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
+        }
+    }
+
+    if (KS > 1) {  // add the slices' accumulators (slice order: deterministic)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (slice > 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[(((slice - 1) * 4 + quad) * 16 + q) * 64 + lane] = acc[q];
         }
         __syncthreads();
+        if (slice > 0) return;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a = As[2 * kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[2 * kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
+        for (int sl = 0; sl < KS - 1; ++sl)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += lds[((sl * 4 + quad) * 16 + q) * 64 + lane];
     }
 
     EpiCtx e{g.bias, g.aux, g.ld_aux, g.add, g.ld_add, g.alpha, g.M};
@@ -136,18 +249,38 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mo * g.N) return;
     const int i = (int)(idx / g.N), j = (int)(idx % g.N);
+    const int64_t zs = (int64_t)Mo * g.N;
     float s = 0.f;
-    for (int z = 0; z < g.nsplit; ++z) s += g.partials[(int64_t)z * Mo * g.N + idx];
+    int z = 0;
+    for (; z + 4 <= g.nsplit; z += 4) {  // four loads in flight, added in split order
+        const float t0 = g.partials[z * zs + idx], t1 = g.partials[(z + 1) * zs + idx],
+                    t2 = g.partials[(z + 2) * zs + idx], t3 = g.partials[(z + 3) * zs + idx];
+        s += t0; s += t1; s += t2; s += t3;
+    }
+    for (; z < g.nsplit; ++z) s += g.partials[z * zs + idx];
     EpiCtx e{g.bias, g.aux, g.ld_aux, g.add, g.ld_add, g.alpha, g.M};
     g.C[(int64_t)i * g.ldc + j] = apply_epi<EPI>(s, i, j, e);
+}
+
+template <int EPI, int KS>
+int launch_ks(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
+    if (a_rc && !b_rc) gemm_kernel<EPI, true, false, KS><<<grid, 256 * KS, 0, stream>>>(g);
+    else if (a_rc && b_rc) gemm_kernel<EPI, true, true, KS><<<grid, 256 * KS, 0, stream>>>(g);
+    else if (!a_rc && !b_rc) gemm_kernel<EPI, false, false, KS><<<grid, 256 * KS, 0, stream>>>(g);
+    else return fail(SAMX_ERR_UNSUPPORTED, "gemm: operand layout (A free-contiguous, B reduction-contiguous)");
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
 }
 
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t stream) {
     const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
     dim3 grid(cdiv(g.N, BN), cdiv(Mo, BM), g.nsplit);
-    gemm_kernel<EPI><<<grid, 256, 0, stream>>>(g);
-    SAMX_LAUNCH_CHECK();
+    // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
+    const bool few = (int64_t)grid.x * grid.y * grid.z < 512;
+    int rc = few ? launch_ks<EPI, 4>(g, grid, stream) : launch_ks<EPI, 1>(g, grid, stream);
+    if (rc != SAMX_OK) return rc;
     if (g.nsplit > 1) {
         int64_t tot = (int64_t)Mo * g.N;
         reduce_partials_kernel<EPI><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(g, Mo);
@@ -160,8 +293,8 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 
 int pick_nsplit(int Mo, int N, int R) {
     int tiles = cdiv(Mo, BM) * cdiv(N, BN);
-    int want = 256 / tiles;
-    int most = R / 128;  // keep at least 8 K-steps per split
+    int want = 512 / tiles;  // two workgroups per CU
+    int most = R / 128;      // keep at least 4 stages per split
     int s = want < most ? want : most;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -175,6 +308,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
                  "gemm: each operand needs one unit stride");
     SAMX_REQUIRE(g.nsplit == 1 || g.partials, "gemm: split needs a partials buffer");
     SAMX_REQUIRE(g.nsplit >= 1 && g.nsplit <= 65535, "gemm: bad nsplit");
+    SAMX_REQUIRE(g.a_ones_rows < 0 || g.a_si == 1, "gemm: the ones row needs a free-contiguous A");
     switch (g.epi) {
         case EPI_NONE: return launch<EPI_NONE>(g, stream);
         case EPI_BIAS: return launch<EPI_BIAS>(g, stream);

@@ -236,17 +236,35 @@ __device__ double sumsq_f32(const float* x, int64_t n, double* sh) {
     return block_sum_d(a, sh);
 }
 
+// sum of squares of the two decayed kernels (network_util.py:43-56), spread over kWdBlocks workgroups;
+// block b writes its float64 partial, critic_losses_kernel adds them in block order
+constexpr int kWdBlocks = 64;
+__global__ __launch_bounds__(256) void wd_sumsq_kernel(const float* __restrict__ W1, int64_t n1,
+                                                       const float* __restrict__ W2, int64_t n2,
+                                                       double* __restrict__ part) {
+    __shared__ double sh[4];
+    double a = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * 256) {
+        const double w = (double)(i < n1 ? W1[i] : W2[i - n1]);
+        a += w * w;
+    }
+    a = block_sum_d(a, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
 // {critic_td_loss_1, critic_wd, critic_total_loss}  (sam_agent.py:473-517)
 __global__ __launch_bounds__(1024) void critic_losses_kernel(const float* rowloss, int64_t B,
                                                              float td_scale, float wd_scale,
-                                                             const float* W1, int64_t n1,
-                                                             const float* W2, int64_t n2,
+                                                             const double* wd_part, int n_part,
                                                              float* losses) {
     __shared__ double sh[16];
     const double l = sum_f32(rowloss, B, sh) / (double)B * td_scale;
-    double wd = 0.0;
-    if (wd_scale > 0.f) wd = 0.5 * wd_scale * (sumsq_f32(W1, n1, sh) + sumsq_f32(W2, n2, sh));
     if (threadIdx.x == 0) {
+        double wd = 0.0;
+        if (wd_scale > 0.f) {
+            for (int i = 0; i < n_part; ++i) wd += wd_part[i];
+            wd *= 0.5 * wd_scale;
+        }
         losses[0] = (float)l;
         losses[1] = (float)wd;
         losses[2] = (float)(l + wd);
@@ -432,6 +450,7 @@ int hidden(const Net& c, const float* X, int64_t M, float* A1, float* A2, hipStr
 struct AgentWs {
     float *XC, *A1a, *A2a, *A1c, *A2c, *DZ2c, *DZ1c, *A1d, *A2d, *DZ2d, *DZ1d, *dAd, *dPre, *DZ2a,
         *DZ1a, *row0, *row1, *row2, *partials;
+    double* wd_part;
     size_t partial_floats;
 };
 
@@ -458,6 +477,7 @@ AgentWs carve_agent(Arena& ar, const samx_mlp* da, const samx_mlp* dc, const sam
     w.row0 = ar.take<float>(B);
     w.row1 = ar.take<float>(B);
     w.row2 = ar.take<float>(B);
+    w.wd_part = ar.take<double>(kWdBlocks);
     size_t pf = wgrad_partial_floats(dc, B);
     if (da) { size_t s = wgrad_partial_floats(da, B); if (s > pf) pf = s; }
     w.partial_floats = pf;
@@ -605,8 +625,12 @@ int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, con
                  0.f, st));
     TRY(wgrad(w.XC, c.in, c.in, w.DZ1c, c.h1, c.h1, B, B, grad_out + c.oW1, wd_scale, c.W1, w.partials,
               w.partial_floats, st));
-    critic_losses_kernel<<<1, 1024, 0, st>>>(w.row0, B, td_scale, wd_scale, c.W1, (int64_t)c.in * c.h1,
-                                             c.W2, (int64_t)c.h1 * c.h2, losses_out);
+    if (wd_scale > 0.f) {
+        wd_sumsq_kernel<<<kWdBlocks, 256, 0, st>>>(c.W1, (int64_t)c.in * c.h1, c.W2, (int64_t)c.h1 * c.h2,
+                                                   w.wd_part);
+        SAMX_LAUNCH_CHECK();
+    }
+    critic_losses_kernel<<<1, 1024, 0, st>>>(w.row0, B, td_scale, wd_scale, w.wd_part, kWdBlocks, losses_out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

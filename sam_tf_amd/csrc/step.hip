@@ -5,6 +5,7 @@
 #include "samx_common.h"
 #include "fused_small.h"
 #include "rng.h"
+#include <stdlib.h>
 #include "../../include/samx.h"
 
 using namespace samx;
@@ -14,7 +15,7 @@ namespace {
 struct StepWs {
     float *agent_part, *disc_part, *agent_loss, *disc_loss, *gp_out, *sumsq;
     double* gp_part;
-    void* nets_ws;
+    void *nets_ws, *nets_ws2;  // layer-wise path: one per agent role (they run side by side)
     size_t nets_bytes;
     void* disc_ws;
     size_t disc_bytes;
@@ -22,6 +23,33 @@ struct StepWs {
     float *g_pobs, *g_pacs, *g_eobs, *g_eacs, *g_obs0, *g_acs, *g_rews, *g_dones, *g_obs1, *r_eob, *r_eac,
         *r_real, *r_fake;
 };
+
+// Two side streams per device for the layer-wise path: the discriminator, target+critic and actor
+// roles of a step do not depend on each other, so they are enqueued on three streams that fork from
+// and join back into the caller's stream (events only — this also works under stream capture, where
+// the side streams become parallel branches of the captured graph).  Created on first use, which
+// therefore must not happen while a capture is in progress (the host driver warms up first).
+struct SideStreams {
+    hipStream_t s[2];
+    hipEvent_t fork, join[2];
+};
+int side_streams(SideStreams** out) {
+    static SideStreams* per_dev[64] = {nullptr};
+    int dev = 0;
+    SAMX_CHECK_HIP(hipGetDevice(&dev));
+    SAMX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    if (!per_dev[dev]) {
+        SideStreams* ss = new SideStreams();
+        for (int i = 0; i < 2; ++i) {
+            SAMX_CHECK_HIP(hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking));
+            SAMX_CHECK_HIP(hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming));
+        }
+        SAMX_CHECK_HIP(hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming));
+        per_dev[dev] = ss;
+    }
+    *out = per_dev[dev];
+    return SAMX_OK;
+}
 
 bool use_fused(const samx_learner* L, int64_t B) {
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
@@ -45,6 +73,7 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.nets_bytes = f ? 0 : samx_nets_ws_bytes(&L->actor, &L->critic, &L->reward, B);
     w.disc_bytes = f ? 0 : samx_disc_ws_bytes(&L->reward, B);
     w.nets_ws = ar.take<char>(w.nets_bytes);
+    w.nets_ws2 = ar.take<char>(w.nets_bytes);
     w.disc_ws = ar.take<char>(w.disc_bytes);
     const int64_t ob = L->ob_dim, ac = L->ac_dim, n = f ? 0 : B;
     w.g_pobs = ar.take<float>(n * ob); w.g_pacs = ar.take<float>(n * ac);
@@ -204,6 +233,94 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
     }
 }
 
+// Large inputs (Humanoid-shaped: 2B x 376): the same sums in two launches.  Stage 1: workgroup g adds
+// rows g, g+G, ... (columns across the threads, coalesced) in float64; stage 2: one wave per column
+// adds the G partials (lane l takes l, l+64, ... in order, then a fixed xor tree) and commits.
+constexpr int kStatGroupsMax = 128;
+
+__global__ __launch_bounds__(256) void d_input_partials_kernel(
+    const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
+    const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
+    const int64_t* __restrict__ e_start, int64_t B, int dim, double* __restrict__ part) {
+    const int G = gridDim.x, g = blockIdx.x;
+    const int64_t e0 = e_start ? e_start[0] : 0;
+    for (int c0 = 0; c0 < dim; c0 += 256) {
+        const int col = c0 + threadIdx.x;
+        double a = 0.0, q = 0.0;
+        for (int64_t rb = g; rb < 2 * B; rb += (int64_t)G * 8) {
+            float v[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t r = rb + (int64_t)u * G;
+                ok[u] = r < 2 * B && col < dim;
+                v[u] = 0.f;
+                if (ok[u]) {
+                    if (r < B) {
+                        int64_t pr = r;
+                        if (p_idx) { pr = ring_start + p_idx[r]; if (pr >= ring_len) pr -= ring_len; }
+                        v[u] = replay_obs0[pr * dim + col];
+                    } else {
+                        v[u] = pool_obs0[(e0 + (r - B)) * dim + col];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (ok[u]) {
+                    const double x = (double)v[u];
+                    a = __dadd_rn(a, x);
+                    q = __dadd_rn(q, __dmul_rn(x, x));
+                }
+        }
+        if (col < dim) {
+            part[((int64_t)g * 2) * dim + col] = a;
+            part[((int64_t)g * 2 + 1) * dim + col] = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void d_input_commit_kernel(const double* __restrict__ part, int G, int64_t B,
+                                                            int dim, double* __restrict__ addvec, int commit,
+                                                            double* __restrict__ sums,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ std_out) {
+    const int col = blockIdx.x, lane = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int g = lane; g < G; g += 64) {
+        a = __dadd_rn(a, part[((int64_t)g * 2) * dim + col]);
+        q = __dadd_rn(q, part[((int64_t)g * 2 + 1) * dim + col]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a = __dadd_rn(a, __shfl_xor(a, o, 64));
+        q = __dadd_rn(q, __shfl_xor(q, o, 64));
+    }
+    if (lane == 0) {
+        addvec[col] = a;
+        addvec[dim + col] = q;
+        if (col == 0) addvec[2 * dim] = (double)(2 * B);
+        if (commit) {  // helpers/mpi_running_mean_std.py:31-45 ; the count is advanced by column 0 LAST
+            const double cnt = sums[2 * dim] + (double)(2 * B);
+            const double s1 = __dadd_rn(sums[col], a), s2 = __dadd_rn(sums[dim + col], q);
+            sums[col] = s1;
+            sums[dim + col] = s2;
+            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+            mean_out[col] = mean;
+            std_out[col] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+        }
+    }
+}
+
+// the running count, advanced once every column has used the old value (stream order)
+__global__ void d_input_count_kernel(double* sums, int dim, int64_t B) {
+    if (threadIdx.x == 0) sums[2 * dim] = sums[2 * dim] + (double)(2 * B);
+}
+
+int stat_groups(int64_t B) {
+    int64_t g = (2 * B) / 32;
+    return (int)(g < 1 ? 1 : (g > kStatGroupsMax ? kStatGroupsMax : g));
+}
+
 }  // namespace
 
 extern "C" {
@@ -220,18 +337,42 @@ int samx_disc_randoms(uint64_t rng_seed, int64_t step, int64_t B, int ob_dim, in
     return SAMX_OK;
 }
 
+size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim) {
+    if (B <= 0 || ob_dim <= 0) return 0;
+    return (size_t)stat_groups(B) * 2 * ob_dim * sizeof(double) + 256;
+}
+
 int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
                        const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
                        int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
-                       float* std_out, void* stream) {
+                       float* std_out, void* ws, size_t ws_bytes, void* stream) {
     SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "samx_d_input_stats: bad arguments");
     SAMX_REQUIRE(ob_dim <= 1024, "samx_d_input_stats: ob_dim %d > 1024", ob_dim);
     SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_d_input_stats: bad ring geometry");
     SAMX_REQUIRE(!commit || (sums && mean_out && std_out), "samx_d_input_stats: commit needs sums/mean/std");
+    hipStream_t st = (hipStream_t)stream;
+    if (2 * B * (int64_t)ob_dim > 16384) {  // two-stage form
+        const int G = stat_groups(B);
+        SAMX_REQUIRE(ws, "samx_d_input_stats: this size needs a workspace (samx_d_input_stats_ws_bytes)");
+        if (ws_bytes < samx_d_input_stats_ws_bytes(B, ob_dim))
+            return fail(SAMX_ERR_WORKSPACE, "samx_d_input_stats: workspace %zu < %zu", ws_bytes,
+                        samx_d_input_stats_ws_bytes(B, ob_dim));
+        double* part = (double*)ws;
+        d_input_partials_kernel<<<G, 256, 0, st>>>(replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start,
+                                                   B, ob_dim, part);
+        SAMX_LAUNCH_CHECK();
+        d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out);
+        SAMX_LAUNCH_CHECK();
+        if (commit) {
+            d_input_count_kernel<<<1, 64, 0, st>>>(sums, ob_dim, B);
+            SAMX_LAUNCH_CHECK();
+        }
+        return SAMX_OK;
+    }
     int dimpad = 1;
     while (dimpad < ob_dim) dimpad *= 2;
-    d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
+    d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), st>>>(
         replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
         mean_out, std_out);
     SAMX_LAUNCH_CHECK();
@@ -311,23 +452,43 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
             dense.fake_labels = b->label_smoothing == 2 ? w.r_fake : nullptr;
         }
         b = &dense;
+        // fork: D role stays on the caller's stream, target+critic on side 0, actor on side 1
+        static int serial = -1;  // SAMX_SERIAL_ROLES=1: everything on the caller's stream (profiling aid)
+        if (serial < 0) { const char* e = getenv("SAMX_SERIAL_ROLES"); serial = e ? atoi(e) : 0; }
+        hipStream_t s_tc = st, s_a = st;
+        SideStreams* ss = nullptr;
+        if (!serial) {
+            rc = side_streams(&ss);
+            if (rc != SAMX_OK) return rc;
+            SAMX_CHECK_HIP(hipEventRecord(ss->fork, st));
+            SAMX_CHECK_HIP(hipStreamWaitEvent(ss->s[0], ss->fork, 0));
+            SAMX_CHECK_HIP(hipStreamWaitEvent(ss->s[1], ss->fork, 0));
+            s_tc = ss->s[0];
+            s_a = ss->s[1];
+        }
+        rc = samx_actor_grad(&L->actor, pa, &L->critic, pc, &L->reward, L->actor_reward_params, b->obs0,
+                             L->mu_mean, L->mu_std, B, L->ac_high, L->q_actor_loss_scale,
+                             L->d_actor_loss_scale, o->actor_losses, L->grads, w.nets_ws2, w.nets_bytes,
+                             (void*)s_a);
+        if (rc != SAMX_OK) return rc;
+        rc = samx_targ_q(&L->actor, ta, &L->critic, tc, b->obs1, b->rews, b->dones1, b->td_len, L->mu_mean,
+                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, w.nets_ws, w.nets_bytes, (void*)s_tc);
+        if (rc != SAMX_OK) return rc;
+        rc = samx_critic_grad(&L->critic, pc, b->obs0, b->acs, b->iws, o->targ_q, L->mu_mean, L->mu_std, B,
+                              L->ob_dim, L->td_loss_scale, L->wd_scale, o->critic_losses, L->grads + Pa,
+                              o->td, w.nets_ws, w.nets_bytes, (void*)s_tc);
+        if (rc != SAMX_OK) return rc;
         rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
                             b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,
                             L->ent_reg_scale, o->d_losses, L->grads + Pa + Pc, w.disc_ws, w.disc_bytes,
                             stream);
         if (rc != SAMX_OK) return rc;
-        rc = samx_targ_q(&L->actor, ta, &L->critic, tc, b->obs1, b->rews, b->dones1, b->td_len, L->mu_mean,
-                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, w.nets_ws, w.nets_bytes, stream);
-        if (rc != SAMX_OK) return rc;
-        rc = samx_actor_grad(&L->actor, pa, &L->critic, pc, &L->reward, L->actor_reward_params, b->obs0,
-                             L->mu_mean, L->mu_std, B, L->ac_high, L->q_actor_loss_scale,
-                             L->d_actor_loss_scale, o->actor_losses, L->grads, w.nets_ws, w.nets_bytes,
-                             stream);
-        if (rc != SAMX_OK) return rc;
-        rc = samx_critic_grad(&L->critic, pc, b->obs0, b->acs, b->iws, o->targ_q, L->mu_mean, L->mu_std, B,
-                              L->ob_dim, L->td_loss_scale, L->wd_scale, o->critic_losses, L->grads + Pa,
-                              o->td, w.nets_ws, w.nets_bytes, stream);
-        if (rc != SAMX_OK) return rc;
+        if (!serial) {  // join
+            for (int i = 0; i < 2; ++i) {
+                SAMX_CHECK_HIP(hipEventRecord(ss->join[i], ss->s[i]));
+                SAMX_CHECK_HIP(hipStreamWaitEvent(st, ss->join[i], 0));
+            }
+        }
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f);
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;

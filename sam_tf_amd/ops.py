@@ -423,6 +423,17 @@ def disc_randoms(seed, step, B, ob, ac, want_real=True, want_fake=False, device=
     return eo, ea, real, fake
 
 
+_STATS_WS = {}
+
+
+def _stats_ws(B, ob, device):
+    key = (B, ob, str(device))
+    if key not in _STATS_WS:
+        n = int(_L().samx_d_input_stats_ws_bytes(B, ob))
+        _STATS_WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return _STATS_WS[key]
+
+
 def d_input_stats(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec, commit=False, sums=None,
                   mean=None, std=None):
     ring_len, ob = replay_obs0.shape
@@ -431,9 +442,10 @@ def d_input_stats(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec,
     _chk(addvec, F64, (2 * ob + 1,), 'addvec')
     if commit:
         _chk(sums, F64, (2 * ob + 1,), 'sums'); _chk(mean, F32, (ob,), 'mean'); _chk(std, F32, (ob,), 'std')
+    ws = _stats_ws(int(B), int(ob), replay_obs0.device)
     check(_L().samx_d_input_stats(ptr(replay_obs0), int(ring_start), int(ring_len), ptr(p_idx), ptr(pool_obs0),
                                   ptr(e_start), int(B), int(ob), ptr(addvec), int(bool(commit)), ptr(sums),
-                                  ptr(mean), ptr(std), stream_ptr()))
+                                  ptr(mean), ptr(std), ptr(ws), ws.numel(), stream_ptr()))
 
 
 def make_step_out(B, device='cuda'):
