@@ -173,13 +173,12 @@ def main():
     comm = TorchComm(device)
     cfg = CONFIGS[args.config]
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
-    drv.prepare()
-    for _ in range(args.warmup):
-        drv.step()
+    drv.prepare(1)
+    drv.prepare(drv.K)
+    drv.run(args.warmup)
     comm.Barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv.step()
+    drv.run(args.steps)   # K consecutive steps per graph launch where nothing needs the host in between
     torch.cuda.synchronize(); comm.Barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     if world > 1:
@@ -203,6 +202,7 @@ def main():
                                 cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
                                 mu.replay_buffer.num_entries),
                    'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
+                   'steps_per_graph_launch': drv.K,
                    'finite_params': finite},
         'roofline': {'bound': 'mfma',
                      'kernel': 'samx_step_grads (%s)' % ('fused whole-network kernels' if drv.fused

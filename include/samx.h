@@ -253,6 +253,16 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
      * (real ~ 1.2 - 0.5u, discriminator.py:104-109), 2 = also fake ~ 0.3 - 0.3u (lines 97-103). */
     uint64_t rng_seed;
     int32_t label_smoothing;
+    /* d_rms_sums != NULL: the commit of d.obs_rms.update for this batch (sam.py:389-390,
+     * helpers/mpi_running_mean_std.py:40-45) happens INSIDE samx_step_grads.  d_rms_addvec
+     * (double[2*ob+1]) must hold the batch's [sum, sum of squares, count] — from samx_d_input_stats
+     * with commit = 0 or samx_d_input_sums_many, which can run any time before, e.g. for many steps
+     * at once.  The discriminator normalises with the statistics of d_rms_sums + d_rms_addvec, and at
+     * the end d_rms_sums (double[2*ob+1]) is advanced and learner.d_mean / d_std are rewritten (they
+     * are outputs in this mode).  Single process only (N > 1 needs the all-reduce of line 55 in
+     * between) and only on the whole-network fused path, else SAMX_ERR_UNSUPPORTED. */
+    double* d_rms_sums;
+    const double* d_rms_addvec;
 } samx_batch;
 
 typedef struct samx_step_out {
@@ -282,6 +292,14 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
 /* Scratch for samx_d_input_stats (large inputs are summed by many workgroups into per-group float64
  * partials that are then added in a fixed order); ws may be NULL when 2*B*ob_dim <= 16384. */
 size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
+/* The batch sums (no commit) of K consecutive steps in ONE launch: step k reads its index words at
+ * p_idx + k*idx_stride and e_start + k*idx_stride (int64 words) and writes addvec + k*addvec_stride
+ * (doubles).  The sums of a batch do not depend on the learner, so a multi-step launch computes them
+ * up front.  2*B*ob_dim <= 16384 (the sizes of the fused path). */
+int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                           const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start,
+                           int64_t idx_stride, int64_t B, int ob_dim, double* addvec,
+                           int64_t addvec_stride, int64_t K, void* stream);
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
 
 /* d.get_grads/get_losses + mu's get_targ_q / actor & critic losses and grads (sam.py:398-399,

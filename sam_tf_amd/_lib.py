@@ -44,7 +44,7 @@ class Batch(C.Structure):
         'p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
         'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'p_idx', 'a_idx', 'e_start')] +
                 [('ring_start', C.c_int64), ('ring_len', C.c_int64), ('rng_seed', C.c_uint64),
-                 ('label_smoothing', C.c_int32)])
+                 ('label_smoothing', C.c_int32), ('d_rms_sums', C.c_void_p), ('d_rms_addvec', C.c_void_p)])
 
 
 class StepOut(C.Structure):
@@ -94,6 +94,7 @@ SIGNATURES = {
     'samx_d_input_stats': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
                                      _P, _SZ, _P]),
     'samx_d_input_stats_ws_bytes': (_SZ, [_I64, C.c_int]),
+    'samx_d_input_sums_many': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _I64, _P]),
     'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
     'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),
     'samx_step_apply': (C.c_int, [_LP, _I64, C.c_int, _F, _P, _SZ, _P]),

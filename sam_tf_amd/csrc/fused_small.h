@@ -44,6 +44,12 @@ struct DiscArgs {
     uint64_t rng_seed;
     const int64_t* rng_step;  // device: reward-net update count
     int label_smoothing;
+    // d.obs_rms.update folded into the step (sam.py:389-390; single process only).  rms_sums != NULL:
+    // rms_addvec holds this batch's float64 column sums (computed ahead); every workgroup normalises
+    // with the statistics of sums + addvec and finalize commits them (FinalizeArgs::rms_*).
+    // mean/stdv are then unused.
+    const double* rms_sums;    // [2*ob+1]
+    const double* rms_addvec;  // [2*ob+1]
 };
 
 struct Segment {
@@ -79,6 +85,10 @@ struct FinalizeArgs {
     const double* gp_part;   // [gp_tiles][2] sums of squares of the input gradient (NULL: no D segment)
     int gp_tiles, ob, ac;
     float* disc_losses;
+    // commit of the inline running-statistics update (NULL: none)
+    double* rms_sums;
+    const double* rms_addvec;
+    float *rms_mean, *rms_std;
 };
 
 struct ApplySeg {

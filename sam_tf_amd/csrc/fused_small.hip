@@ -20,6 +20,7 @@
 #include "fused_small.h"
 #include "rng.h"
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace samx {
@@ -517,7 +518,8 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
 // terms, full backward, weight-gradient slot.  Tiles [2B/16, 3B/16): interpolates — forward, the
 // input gradient g = d score / d input, and this tile's share of sum g_ob^2, sum g_ac^2.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int sect) {
+__device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int sect, const float* mean,
+                                 const float* stdv) {
     // sect 0: policy rows, 1: expert rows, 2: eps*policy + (1-eps)*expert  (discriminator.py:129-134)
     const int ob = a.ob, ac = a.ac, w = ob + ac;
     const int64_t e0 = a.e_start ? a.e_start[0] : 0;
@@ -535,8 +537,8 @@ __device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int
             if (sect == 2)
                 e = a.eps_ob ? a.eps_ob[g * ob + c]
                              : philox_uniform(a.rng_seed, step, RNG_EPS_OB, (uint64_t)(g * ob + c));
-            if (a.mean) {
-                const float m = a.mean[c], sd = a.stdv[c];
+            if (mean) {
+                const float m = mean[c], sd = stdv[c];
                 pv = fminf(fmaxf((pv - m) / sd, -5.f), 5.f);
                 ev = fminf(fmaxf((ev - m) / sd, -5.f), 5.f);
             }
@@ -549,6 +551,23 @@ __device__ inline void disc_rows(float* XC, const DiscArgs& a, int64_t row0, int
         }
         XC[r * LD + c] = sect == 0 ? pv : (sect == 1 ? ev : e * pv + (1.f - e) * ev);
     }
+}
+
+// d.obs_rms.update folded into the step (helpers/mpi_running_mean_std.py:31-45): the batch's float64
+// column sums were computed ahead (samx_d_input_stats commit = 0 / samx_d_input_sums_many); every
+// workgroup derives the mean/std that INCLUDE this batch from sums + addvec (same arithmetic as the
+// commit in finalize, hence the same bits) and keeps them in LDS.
+__device__ inline void disc_inline_stats(const DiscArgs& a, float* sh_mean, float* sh_std) {
+    const int tid = threadIdx.x, dim = a.ob;
+    if (tid < dim) {
+        const double cnt = a.rms_sums[2 * dim] + a.rms_addvec[2 * dim];
+        const double s1 = __dadd_rn(a.rms_sums[tid], a.rms_addvec[tid]),
+                     s2 = __dadd_rn(a.rms_sums[dim + tid], a.rms_addvec[dim + tid]);
+        const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+        sh_mean[tid] = mean;
+        sh_std[tid] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -594,9 +613,17 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     float* DZa = p; p += R * LD;
     float* DZb = p; p += R * LD;
     float* sh = p; p += 96;
+    float* ms = p; p += 128;  // mean[64] | std[64] when the statistics are updated inline
     float* s_ = sh; float* dq = sh + 16; float* r0_ = sh + 32; float* r1_ = sh + 48; float* r2_ = sh + 64;
     load_net(n, a.params);
-    disc_rows(XC, a, row0, sect);
+    const float* mean = a.mean;
+    const float* stdv = a.stdv;
+    if (a.rms_sums) {
+        disc_inline_stats(a, ms, ms + 64);
+        mean = ms;
+        stdv = ms + 64;
+    }
+    disc_rows(XC, a, row0, sect, mean, stdv);
     stage_wait();
     if (sect == 2) {
         // Interpolate rows.  d(10*GP)/d(theta) = k * sum_rows <V, dg/dtheta> with V = g/(B*dim) and the
@@ -813,6 +840,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
                 f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * gp_loss);
             }
         }
+        if (f.rms_sums) {  // commit of the inline d.obs_rms.update (mpi_running_mean_std.py:40-45,31-34)
+            const int dim = f.ob;
+            const double add_n = f.rms_addvec[2 * dim];
+            const double cnt = f.rms_sums[2 * dim] + add_n;  // every lane reads the old count first
+            for (int c = tid; c < dim; c += 64) {
+                const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
+                             s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
+                f.rms_sums[c] = s1;
+                f.rms_sums[dim + c] = s2;
+                const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+                f.rms_mean[c] = mean;
+                f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+            }
+            if (tid == 0) f.rms_sums[2 * dim] = cnt;
+        }
         if (tid == 0)
             for (int k = 0; k < f.nseg; ++k)
                 if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
@@ -890,7 +932,7 @@ size_t agent_lds_bytes(int ob, int ac, bool use_d) {
     return f * sizeof(float);
 }
 size_t disc_lds_bytes(int in) {
-    size_t f = net_lds_floats(in, 1) + 6 * R * LD + 96;
+    size_t f = net_lds_floats(in, 1) + 6 * R * LD + 96 + 128;
     return f * sizeof(float);
 }
 

@@ -168,9 +168,14 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
     const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
     const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
-    int commit, double* __restrict__ sums, float* __restrict__ mean_out, float* __restrict__ std_out) {
+    int commit, double* __restrict__ sums, float* __restrict__ mean_out, float* __restrict__ std_out,
+    int64_t idx_stride, int64_t addvec_stride) {
     extern __shared__ double shd[];  // [2][1024]
     const int tid = threadIdx.x;
+    // one workgroup per step of a multi-step launch (blockIdx.x = step; a single step has stride 0)
+    if (p_idx) p_idx += blockIdx.x * idx_stride;
+    if (e_start) e_start += blockIdx.x * idx_stride;
+    addvec += blockIdx.x * addvec_stride;
     const int col = tid % dimpad, lane = tid / dimpad, lanes = 1024 / dimpad;
     const int64_t e0 = e_start ? e_start[0] : 0;
     double a = 0.0, q = 0.0;
@@ -374,7 +379,27 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
     while (dimpad < ob_dim) dimpad *= 2;
     d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), st>>>(
         replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
-        mean_out, std_out);
+        mean_out, std_out, 0, 0);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                           const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start,
+                           int64_t idx_stride, int64_t B, int ob_dim, double* addvec,
+                           int64_t addvec_stride, int64_t K, void* stream) {
+    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0 && K > 0 && K <= 65535,
+                 "samx_d_input_sums_many: bad arguments");
+    SAMX_REQUIRE(2 * B * (int64_t)ob_dim <= 16384, "samx_d_input_sums_many: batch too large (2*B*ob = %lld)",
+                 (long long)(2 * B * ob_dim));
+    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
+                 "samx_d_input_sums_many: bad ring geometry");
+    SAMX_REQUIRE(idx_stride >= 0 && addvec_stride >= 2 * ob_dim + 1, "samx_d_input_sums_many: bad strides");
+    int dimpad = 1;
+    while (dimpad < ob_dim) dimpad *= 2;
+    d_input_stats_kernel<<<(unsigned)K, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
+        replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, 0, nullptr,
+        nullptr, nullptr, idx_stride, addvec_stride);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -417,6 +442,13 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     const float* ta = L->targets;
     const float* tc = L->targets + Pa;
 
+    SAMX_REQUIRE((b->d_rms_sums == nullptr) == (b->d_rms_addvec == nullptr),
+                 "samx_step_grads: d_rms_sums/d_rms_addvec go together");
+    if (b->d_rms_sums) {
+        if (!use_fused(L, B))
+            return fail(SAMX_ERR_UNSUPPORTED, "samx_step_grads: inline statistics need the fused path");
+        SAMX_REQUIRE(L->d_mean && L->d_std, "samx_step_grads: inline statistics need learner.d_mean/d_std");
+    }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense
         // rows and materialised randoms, so indirection / in-kernel draws are resolved first.
@@ -506,6 +538,7 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     d.gp_out = w.gp_out;
     d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
     d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
+    d.rms_sums = b->d_rms_sums; d.rms_addvec = b->d_rms_addvec;
 
     fused::AgentArgs a;
     a.obs0 = b->obs0; a.acs = b->acs; a.rews = b->rews; a.dones1 = b->dones1; a.obs1 = b->obs1;
@@ -551,6 +584,8 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     f.disc_loss_part = w.disc_loss; f.disc_tiles_b = tiles;
     f.ent_scale = L->ent_reg_scale; f.gp_coeff = 10.f; f.gp = w.gp_out; f.disc_losses = o->d_losses;
     f.gp_part = w.gp_part; f.gp_tiles = tiles; f.ob = L->ob_dim; f.ac = L->ac_dim;
+    f.rms_sums = b->d_rms_sums; f.rms_addvec = b->d_rms_addvec;
+    f.rms_mean = const_cast<float*>(L->d_mean); f.rms_std = const_cast<float*>(L->d_std);
     return fused::launch_finalize(f, st);
 }
 

@@ -28,26 +28,25 @@ from . import ops
 
 
 class _Slot(object):
-    """Pinned staging for one step's host-drawn numbers (one packed H2D copy); an event guards reuse.
-    Layout (int64 words): [idx_p (B) | idx_a (B) | e_start (1)] then B float64 PER uniforms."""
+    """Pinned staging for the host-drawn numbers of up to K consecutive steps (one packed H2D copy);
+    an event guards reuse.  Row layout (int64 words): [idx_p (B) | idx_a (B) | e_start (1)] then B
+    float64 PER uniforms."""
 
-    def __init__(self, B):
-        self.words = torch.empty(2 * B + 1 + B, dtype=torch.int64).pin_memory()
-        self.idx_p = self.words[:B]
-        self.idx_a = self.words[B:2 * B]
-        self.e_start = self.words[2 * B:2 * B + 1]
-        self.u = self.words[2 * B + 1:].view(torch.float64)
+    def __init__(self, B, K):
+        self.W = 3 * B + 1
+        self.words = torch.empty(K, self.W, dtype=torch.int64).pin_memory()
         # numpy views of the pinned words: the host fills them without going through torch ops
         w = self.words.numpy()
-        self.np_idx_p, self.np_idx_a, self.np_e = w[:B], w[B:2 * B], w[2 * B:2 * B + 1]
-        self.np_u = w[2 * B + 1:].view(np.float64)
+        self.np_idx = w[:, :2 * B].reshape(K, 2, B)   # [k][0] = idx_p, [k][1] = idx_a
+        self.np_idx_p, self.np_idx_a, self.np_e = w[:, :B], w[:, B:2 * B], w[:, 2 * B]
+        self.np_u = w[:, 2 * B + 1:].view(np.float64)
         self.event = torch.cuda.Event()
         self.used = False
 
 
 class UpdateStepDriver(object):
 
-    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4):
+    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16):
         self.mu, self.d, self.pool = mu, d, expert_pool
         self.L = mu.L
         self.comm = mu.comm
@@ -57,15 +56,22 @@ class UpdateStepDriver(object):
         self.dev = dev
         self.per = bool(mu.hps.prioritized_replay)
         self.use_graph = bool(use_graph)
+        # Several consecutive steps per graph launch: possible when nothing between two steps needs
+        # the host — one process (no collective) and uniform replay (PER's priority refresh computes
+        # p ** alpha with the host libm).  The host RNG draws of those steps are made up front, in the
+        # reference's order, so the sampled indices are the same as with one launch per step.
+        self.K = int(steps_per_launch) if (self.use_graph and self.world == 1 and not self.per) else 1
         f32 = dict(dtype=torch.float32, device=dev)
         rb = mu.replay_buffer
         assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
         # static device buffers (their addresses are baked into the captured graphs)
-        self.words = torch.zeros(3 * B + 1, dtype=torch.int64, device=dev)
-        self.idx_p = self.words[:B]
-        self.idx_a = self.words[B:2 * B]
-        self.e_start = self.words[2 * B:2 * B + 1]
-        self.u = self.words[2 * B + 1:].view(torch.float64)
+        self.W = 3 * B + 1
+        self.words = torch.zeros(self.K, self.W, dtype=torch.int64, device=dev)
+        # step 0's views (what the single-step plan and the checkers read)
+        self.idx_p = self.words[0, :B]
+        self.idx_a = self.words[0, B:2 * B]
+        self.e_start = self.words[0, 2 * B:2 * B + 1]
+        self.u = self.words[0, 2 * B + 1:].view(torch.float64)
         self.iws = torch.zeros(B, dtype=torch.float64, device=dev)
         self.iws32 = torch.zeros(B, **f32)
         hp = d.hps
@@ -78,34 +84,56 @@ class UpdateStepDriver(object):
         self.gb = {k: torch.zeros(B, st[k].shape[1], **f32) for k in ('obs0', 'acs')}  # PER refresh rows
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
-        self.slots = [_Slot(B) for _ in range(n_slots)]
+        self.slots = [_Slot(B, self.K) for _ in range(n_slots)]
         self.step_no = 0
-        self.plan = None
+        self.launch_no = 0
+        self.plans = {}
         self.fused = self.L.fused(B)
         self._make_batch()
 
     def _make_batch(self):
-        """(Re)build the samx_batch: every row is read IN PLACE from the replay storage / expert pool
-        through the index words (no gather pass); D randoms are drawn inside the kernels."""
+        """(Re)build the samx_batch of each of the K steps of a launch: every row is read IN PLACE
+        from the replay storage / expert pool through that step's index words (no gather pass); D
+        randoms are drawn inside the kernels."""
         rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
+        B = self.B
         self._batch_start = rb.start
-        self.batch = ops.make_batch(
-            self.B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
-            obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
-            obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=self.idx_p, a_idx=self.idx_a,
-            e_start=self.e_start, ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
-            label_smoothing=self.label_mode)
+        # single process + fused path: the d.obs_rms update rides inside the step kernels
+        self.inline_stats = bool(self.fused and self.world == 1 and self.d.hps.rmsify_obs)
+        r = self.d.obs_rms if self.inline_stats else None
+        if r is not None:  # the K batches' [sum, sumsq, count], filled by ONE kernel at the head of a launch
+            self.addvecs = torch.zeros(self.K, 2 * self.mu.ob_dim + 1, dtype=torch.float64, device=self.dev)
+        self.batches = []
+        for k in range(self.K):
+            w = self.words[k]
+            self.batches.append(ops.make_batch(
+                B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
+                obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
+                obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=w[:B], a_idx=w[B:2 * B],
+                e_start=w[2 * B:2 * B + 1], ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
+                label_smoothing=self.label_mode, d_rms_sums=r.sums if r else None,
+                d_rms_addvec=self.addvecs[k] if r else None))
+        self.batch = self.batches[0]
 
     # ------------------------------------------------------------------ device segments
-    def _seg_inputs(self):
+    def _seg_inputs(self, k=0):
         """d.obs_rms.update on the D batch (sam.py:389-390); single process: sums + commit at once."""
         d, rb = self.d, self.mu.replay_buffer
-        if d.hps.rmsify_obs:
+        if d.hps.rmsify_obs and not self.inline_stats:
             r = d.obs_rms
-            ops.d_input_stats(rb.store['obs0'], self._batch_start, self.idx_p, self.pool.obs0, self.e_start,
-                              self.B, r.addvec, commit=self.world == 1, sums=r.sums, mean=r.mean, std=r.std)
+            w = self.words[k]
+            ops.d_input_stats(rb.store['obs0'], self._batch_start, w[:self.B], self.pool.obs0,
+                              w[2 * self.B:2 * self.B + 1], self.B, r.addvec, commit=self.world == 1,
+                              sums=r.sums, mean=r.mean, std=r.std)
 
-    def _seg_grads(self):
+    def _seg_sums(self, K):
+        """The D-input sums of all K steps of the launch (they do not depend on the learner)."""
+        if self.inline_stats:
+            rb = self.mu.replay_buffer
+            ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], self.B,
+                                  self.pool.obs0, self.addvecs[:K])
+
+    def _seg_grads(self, k=0):
         mu, d = self.mu, self.d
         if d.hps.rmsify_obs and self.world > 1:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
@@ -113,7 +141,7 @@ class UpdateStepDriver(object):
             mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
-        ops.step_grads(self.L, self.batch, self.out)
+        ops.step_grads(self.L, self.batches[k], self.out)
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
         ops.step_apply(self.L, self.B, 3 if self.world == 1 else 1, 1.0)
         if self.world == 1:
@@ -132,11 +160,13 @@ class UpdateStepDriver(object):
                           mean, std, mu.ws, out=self.td_post)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
-    def _build_plan(self):
+    def _build_plan(self, K):
         d = self.d
         ar = self.comm.allreduce_
         if self.world == 1:
-            segs, colls = [[self._seg_inputs, self._seg_grads]], [None]
+            segs = [[(lambda: self._seg_sums(K))] +
+                    [(lambda k=k: (self._seg_inputs(k), self._seg_grads(k))) for k in range(K)]]
+            colls = [None]
         else:
             segs = [[self._seg_inputs], [self._seg_grads], [self._seg_apply]]
             colls = [(lambda: ar(d.obs_rms.addvec)) if d.hps.rmsify_obs else None,
@@ -163,26 +193,34 @@ class UpdateStepDriver(object):
         return plan
 
     # ------------------------------------------------------------------ host side of a step
-    def _draw(self, slot):
-        """The reference's host RNG draws for one step, in the reference's order."""
+    def _draw(self, slot, K):
+        """The reference's host RNG draws for K consecutive steps, in the reference's order."""
         rb = self.mu.replay_buffer
         B = self.B
         if slot.used:
             slot.event.synchronize()
-        # D batch: uniform pairs (sam.py:372-377 -> memory.py:90)
-        slot.np_idx_p[:] = np.random.randint(low=0, high=rb.num_entries, size=B)
-        # expert batch pointer arithmetic (demo_dataset.py:33-40)
-        if self.pool.pointer + B >= self.pool.num_entries:
-            self.pool.init_pointer()
-        slot.np_e[0] = self.pool.pointer
-        self.pool.pointer += B
         if self.per:
-            slot.np_u[:] = rb.draw_uniforms(B)                                     # memory.py:278
+            # D batch: uniform pairs (sam.py:372-377 -> memory.py:90), then the PER uniforms
+            slot.np_idx_p[0] = np.random.randint(low=0, high=rb.num_entries, size=B)
+            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
         else:
-            slot.np_idx_a[:] = np.random.randint(low=0, high=rb.num_entries, size=B)
+            # per step: D pairs, then the agent's batch (memory.py:90 twice).  One call of size
+            # K*2*B consumes the generator exactly like 2K calls of size B.
+            slot.np_idx[:K] = np.random.randint(low=0, high=rb.num_entries, size=(K, 2, B))
+        # expert batch pointer arithmetic (demo_dataset.py:33-40)
+        for k in range(K):
+            if self.pool.pointer + B >= self.pool.num_entries:
+                assert k == 0, "a reshuffle of the expert pool cannot fall inside a multi-step launch"
+                self.pool.init_pointer()
+            slot.np_e[k] = self.pool.pointer
+            self.pool.pointer += B
 
-    def _upload(self, slot):
-        self.words.copy_(slot.words, non_blocking=True)   # ONE packed H2D copy per step
+    def _upload(self, slot, K):
+        # ONE packed H2D copy per launch
+        if K == self.K:
+            self.words.copy_(slot.words, non_blocking=True)
+        else:
+            self.words[:K].copy_(slot.words[:K], non_blocking=True)
         slot.event.record()
         slot.used = True
 
@@ -192,11 +230,11 @@ class UpdateStepDriver(object):
                                 want_real=self.label_mode >= 1, want_fake=self.label_mode == 2,
                                 device=self.dev)
 
-    def prepare(self):
-        """Build (and, with use_graph, capture) the device plan.  Capturing executes the segments —
-        learner state, running sums and host RNG positions are snapshotted and restored, so
-        prepare() leaves the learner exactly as it found it."""
-        if self.plan is not None:
+    def prepare(self, K=1):
+        """Build (and, with use_graph, capture) the device plan for launches of K steps.  Capturing
+        executes the segments — learner state, running sums and host RNG positions are snapshotted
+        and restored, so prepare() leaves the learner exactly as it found it."""
+        if K in self.plans:
             return
         mu, d, L = self.mu, self.d, self.L
         keep = [L.params, L.targets, L.m, L.v, L.steps]
@@ -206,10 +244,16 @@ class UpdateStepDriver(object):
         rng_np, rng_py = np.random.get_state(), _random.getstate()
         ptr0 = self.pool.pointer
         slot = self.slots[0]
-        self._draw(slot)
-        self._upload(slot)
+        # warm-up indices: drawn without touching the expert-pool order
+        if slot.used:
+            slot.event.synchronize()
+        slot.np_idx[:K] = np.random.randint(low=0, high=mu.replay_buffer.num_entries, size=(K, 2, self.B))
+        slot.np_e[:K] = 0
+        if self.per:
+            slot.np_u[0] = mu.replay_buffer.draw_uniforms(self.B)
+        self._upload(slot, K)
         torch.cuda.synchronize()
-        self.plan = self._build_plan()
+        self.plans[K] = self._build_plan(K)
         torch.cuda.synchronize()
         for t, sv in zip(keep, saved):
             t.copy_(sv)
@@ -218,15 +262,18 @@ class UpdateStepDriver(object):
         self.pool.pointer = ptr0
         torch.cuda.synchronize()
 
-    def step(self):
-        if self.plan is None:
-            self.prepare()
+    @property
+    def plan(self):
+        return self.plans.get(1)
+
+    def _launch(self, K):
+        self.prepare(K)
         assert self.mu.replay_buffer.start == self._batch_start, \
             "replay ring moved: call driver.refresh() after appending transitions"
-        slot = self.slots[self.step_no % len(self.slots)]
-        self._draw(slot)
-        self._upload(slot)
-        for run in self.plan:
+        slot = self.slots[self.launch_no % len(self.slots)]
+        self._draw(slot, K)
+        self._upload(slot, K)
+        for run in self.plans[K]:
             run()
         if self.per:
             # |td| + 1e-6 in float32 (numpy: float32 array + python float stays float32,
@@ -236,11 +283,28 @@ class UpdateStepDriver(object):
             torch.cuda.current_stream().synchronize()
             new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
             self.mu.replay_buffer.update_priorities(self._idx_host.numpy(), new_priorities)
-        self.step_no += 1
+        self.step_no += K
+        self.launch_no += 1
+
+    def step(self):
+        """One update step (one launch)."""
+        self._launch(1)
+
+    def run(self, n):
+        """n consecutive update steps, K per graph launch where the configuration allows it (see
+        __init__); same arithmetic and same sampled indices as n calls of step()."""
+        B, pool = self.B, self.pool
+        while n > 0:
+            K = self.K if n >= self.K else 1
+            # a reshuffle of the expert pool is host work between two steps: keep it out of a launch
+            if K > 1 and pool.pointer + K * B >= pool.num_entries:
+                K = 1
+            self._launch(K)
+            n -= K
 
     def refresh(self):
         """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""
-        self.plan = None
+        self.plans = {}
         self._make_batch()
         self.prepare()
 

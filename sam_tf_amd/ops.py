@@ -382,6 +382,7 @@ class LearnerState(object):
 _BATCH_F32 = ('p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
               'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')
 _BATCH_I64 = ('p_idx', 'a_idx', 'e_start')
+_BATCH_F64 = ('d_rms_sums', 'd_rms_addvec')
 _BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing')
 
 
@@ -400,10 +401,10 @@ def make_batch(B, **fields):
         if k in _BATCH_INT:
             setattr(b, k, int(t))
             continue
-        want = F32 if k in _BATCH_F32 else I64
-        assert k in _BATCH_F32 or k in _BATCH_I64, 'unknown batch field %s' % k
+        want = F32 if k in _BATCH_F32 else (F64 if k in _BATCH_F64 else I64)
+        assert k in _BATCH_F32 or k in _BATCH_I64 or k in _BATCH_F64, 'unknown batch field %s' % k
         assert t.is_cuda and t.dtype == want and t.is_contiguous(), k
-        dense = not ((indirect_p and k in ('p_obs', 'p_acs')) or (indirect_e and k in ('e_obs', 'e_acs')) or
+        dense = k not in _BATCH_F64 and not ((indirect_p and k in ('p_obs', 'p_acs')) or (indirect_e and k in ('e_obs', 'e_acs')) or
                      (indirect_a and k in ('obs0', 'acs', 'rews', 'dones1', 'obs1')) or k == 'e_start')
         if dense:
             assert t.shape[0] == B, '%s must have %d rows' % (k, B)
@@ -446,6 +447,20 @@ def d_input_stats(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec,
     check(_L().samx_d_input_stats(ptr(replay_obs0), int(ring_start), int(ring_len), ptr(p_idx), ptr(pool_obs0),
                                   ptr(e_start), int(B), int(ob), ptr(addvec), int(bool(commit)), ptr(sums),
                                   ptr(mean), ptr(std), ptr(ws), ws.numel(), stream_ptr()))
+
+
+def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
+    """Batch sums of K steps at once.  words: int64 [K, W] with idx_p at [:, :B] and e_start at
+    [:, 2B]; addvecs: float64 [K, 2*ob+1]."""
+    ring_len, ob = replay_obs0.shape
+    K, W = words.shape
+    _chk(replay_obs0, F32, (ring_len, ob), 'replay_obs0'); _chk(pool_obs0, F32, (pool_obs0.shape[0], ob), 'pool')
+    _chk(words, I64, (K, W), 'words'); _chk(addvecs, F64, (K, 2 * ob + 1), 'addvecs')
+    assert W >= 2 * B + 1
+    check(_L().samx_d_input_sums_many(ptr(replay_obs0), int(ring_start), int(ring_len),
+                                      C.c_void_p(words.data_ptr()), ptr(pool_obs0),
+                                      C.c_void_p(words.data_ptr() + 8 * 2 * B), W, int(B), int(ob),
+                                      ptr(addvecs), 2 * ob + 1, K, stream_ptr()))
 
 
 def make_step_out(B, device='cuda'):
