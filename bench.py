@@ -99,22 +99,21 @@ def build_learner(cfg, comm, device, seed, use_graph):
 
 
 def time_passes(drv, cfg, iters=50):
-    """Average device time of the step's passes, HIP events recorded on the launch stream."""
+    """Average device time of the step's passes, HIP events recorded on the launch stream (torch's
+    current stream is the stream every libsamx call is handed)."""
     from sam_tf_amd import ops
     st = torch.cuda.current_stream()
     L, B = drv.L, drv.B
-    keep = [t.clone() for t in (L.params, L.targets, L.m, L.v, L.steps)]
-
-    def grads():
-        ops.step_grads(L, drv.batch, drv.out)
-
-    def apply_():
-        ops.step_apply(L, B, 3, 1.0)
-
-    def inputs():
-        drv._seg_inputs()
+    keep = [L.params, L.targets, L.m, L.v, L.steps]
+    if drv.d.hps.rmsify_obs:
+        keep += [drv.d.obs_rms.sums, drv.d.obs_rms.mean, drv.d.obs_rms.std]
+    saved = [t.clone() for t in keep]
+    fns = (('network_passes', lambda: ops.step_grads_part(L, drv.batch, drv.out, 1)),
+           ('reduce_losses', lambda: ops.step_grads_part(L, drv.batch, drv.out, 2)),
+           ('step_apply', lambda: ops.step_apply(L, B, 3, 1.0)),
+           ('d_input_sums(K steps)', lambda: (drv._seg_sums(drv.K), drv._seg_inputs())))
     out = {}
-    for name, fn in (('inputs(gather+rms)', inputs), ('step_grads', grads), ('step_apply', apply_)):
+    for name, fn in fns:
         fn(); fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -123,9 +122,20 @@ def time_passes(drv, cfg, iters=50):
         e1.record(st)
         e1.synchronize()
         out[name] = e0.elapsed_time(e1) / iters * 1e-3  # seconds
-    for t, sv in zip((L.params, L.targets, L.m, L.v, L.steps), keep):
+    for t, sv in zip(keep, saved):
         t.copy_(sv)
     return out
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_<config>.json, written by profiles/collect_pmc.py on the GPU box); None when that
+    config has not been measured."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % config)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get('traffic_bytes_per_launch')
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -188,9 +198,12 @@ def main():
     finite = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
 
     passes = time_passes(drv, cfg)
-    # dominant device pass: samx_step_grads = every network forward/backward of the step
-    # (fused path: disc1 + disc2 + agent + finalize kernels; layer-wise path: the MFMA GEMM chain)
-    achieved = flops_per_step(cfg) / passes['step_grads'] / 1e12
+    # Dominant kernel: the network passes of the step.  Fused path (64x64 nets): ONE launch of
+    # samx::fused::step_kernel carries every matmul of the step, so its algorithmic work is the whole
+    # F of SURVEY.md 8(d) and `achieved` = F / its launch duration.  Layer-wise path: the same F over
+    # the duration of the three concurrent GEMM chains.
+    dom = passes['network_passes']
+    achieved = flops_per_step(cfg) / dom / 1e12
     result = {
         'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'],
         'value': world * args.steps / el, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -202,15 +215,18 @@ def main():
                                 cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
                                 mu.replay_buffer.num_entries),
                    'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
-                   'steps_per_graph_launch': drv.K,
-                   'finite_params': finite},
+                   'steps_per_graph_launch': drv.K, 'finite_params': finite},
         'roofline': {'bound': 'mfma',
-                     'kernel': 'samx_step_grads (%s)' % ('fused whole-network kernels' if drv.fused
-                                                         else 'layer-wise MFMA f32 GEMM chain'),
+                     'kernel': ('samx::fused::step_kernel (whole-network fused, all three roles)' if drv.fused
+                                else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
+                                     'on three streams'),
                      'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
-                     'pass_us': {k: v * 1e6 for k, v in passes.items()},
-                     'step_flops': flops_per_step(cfg)},
+                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': pmc_traffic(args.config),
+                     'kernel_us': dom * 1e6, 'flops_per_launch': flops_per_step(cfg),
+                     'note': ('latency-bound: %.1f MFLOP and < 1 MB per launch; neither the MFMA nor the HBM '
+                              'roofline binds (DESIGN.md 3.1)' % (flops_per_step(cfg) / 1e6)) if drv.fused
+                             else 'fp32 MFMA (exact f32) peak 157.3 TFLOP/s',
+                     'pass_us': {k: v * 1e6 for k, v in passes.items()}},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu:

@@ -308,6 +308,13 @@ size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
 int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_step_out* out, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* Measurement aid: the same call split in two.  part 1 = the network passes only (fused path: the one
+ * whole-network kernel; layer-wise path: the GEMM chains of the three roles), part 2 = the reduction
+ * of the per-tile partials / norms / scalar losses / step tick, part 3 = both (= samx_step_grads).
+ * bench.py times part 1 alone with HIP events for the roofline line. */
+int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const samx_step_out* out,
+                         void* ws, size_t ws_bytes, int part, void* stream);
+
 /* d.optimize + actor/critic optimize + update_target_net (sam.py:402,433; sam_agent.py:690-691):
  * mode bit 0: write learner.clipped = grads clipped by their own norm (tf_util.py:137-151);
  * mode bit 1: grads * grad_scale -> clip_by_global_norm -> Adam -> Polyak on the agent's targets;

@@ -97,6 +97,7 @@ SIGNATURES = {
     'samx_d_input_sums_many': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _I64, _P]),
     'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
     'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),
+    'samx_step_grads_part': (C.c_int, [_LP, _BP, _OP, _P, _SZ, C.c_int, _P]),
     'samx_step_apply': (C.c_int, [_LP, _I64, C.c_int, _F, _P, _SZ, _P]),
 }
 

@@ -415,7 +415,13 @@ size_t samx_step_ws_bytes(const samx_learner* L, int64_t B) {
 
 int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                     size_t ws_bytes, void* stream) {
+    return samx_step_grads_part(L, b, o, ws, ws_bytes, 3, stream);
+}
+
+int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
+                         size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
+    SAMX_REQUIRE(part >= 1 && part <= 3, "samx_step_grads_part: part must be 1, 2 or 3");
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(b && o && ws, "samx_step_grads: null argument");
     SAMX_REQUIRE(b->B > 0, "samx_step_grads: empty batch");
@@ -521,6 +527,7 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
                 SAMX_CHECK_HIP(hipStreamWaitEvent(st, ss->join[i], 0));
             }
         }
+        if (!(part & 2)) return SAMX_OK;
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f);
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;
@@ -550,8 +557,11 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
     a.targ_q_out = o->targ_q; a.td_out = o->td;
     a.partials = w.agent_part; a.P = Pa + Pc; a.Pa = Pa; a.loss_part = w.agent_loss;
     a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
-    rc = fused::launch_step(&a, &d, st);
-    if (rc != SAMX_OK) return rc;
+    if (part & 1) {
+        rc = fused::launch_step(&a, &d, st);
+        if (rc != SAMX_OK) return rc;
+    }
+    if (!(part & 2)) return SAMX_OK;
 
     fused::FinalizeArgs f;
     f.nseg = 3;

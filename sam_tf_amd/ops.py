@@ -480,6 +480,13 @@ def step_grads(L, batch, out):
                                stream_ptr()))
 
 
+def step_grads_part(L, batch, out, part):
+    """Measurement aid (include/samx.h): part 1 = network passes, 2 = reduction/losses, 3 = both."""
+    ws = L.ws(batch.B)
+    check(_L().samx_step_grads_part(C.byref(L.c), C.byref(batch), C.byref(out), ptr(ws), ws.numel(),
+                                    int(part), stream_ptr()))
+
+
 def step_apply(L, B, mode, grad_scale=1.0):
     ws = L.ws(B)
     check(_L().samx_step_apply(C.byref(L.c), int(B), int(mode), float(grad_scale), ptr(ws), ws.numel(),
