@@ -65,7 +65,8 @@ def build_learner(cfg, comm, device, seed, use_graph):
     rank = comm.Get_rank()
     env = SyntheticEnv(cfg['ob'], cfg['ac'], 1.0)
     hps = make_hps(hid_widths=cfg['h'], batch_size=cfg['B'], mem_size=cfg['mem'],
-                   prioritized_replay=cfg['per'], seed=seed)
+                   prioritized_replay=cfg['per'], seed=seed,
+                   with_layernorm=bool(cfg.get('ln', False)))
     d = Discriminator('d', env, hps, comm, device=device)
     mu = SAMAgent('mu', comm, env, hps, d, device=device)
     # synthetic transitions: obs ~ N(0,1), acs ~ U(-1,1), rews ~ U(0,5),
@@ -164,6 +165,7 @@ def main():
     ap.add_argument('--config', default='C2', choices=sorted(CONFIGS))
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--layernorm', action='store_true', help='with_layernorm nets (layer-wise path)')
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
 
@@ -181,7 +183,7 @@ def main():
 
     from sam_tf_amd.comm import TorchComm
     comm = TorchComm(device)
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config], ln=args.layernorm)
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
     drv.prepare(1)
     drv.prepare(drv.K)
@@ -210,10 +212,10 @@ def main():
         'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %s: obs %d, act %d, %dx%d MLPs, batch %d per GPU, %s replay (%d rows '
-                               'resident), D gradient penalty, rmsify_obs' %
+                               'resident), D gradient penalty, rmsify_obs%s' %
                                (args.config, cfg['name'], cfg['ob'], cfg['ac'], cfg['h'][0], cfg['h'][1],
                                 cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
-                                mu.replay_buffer.num_entries),
+                                mu.replay_buffer.num_entries, ', with_layernorm' if cfg.get('ln') else ''),
                    'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                    'steps_per_graph_launch': drv.K, 'finite_params': finite},
         'roofline': {'bound': 'mfma',
@@ -221,7 +223,7 @@ def main():
                                 else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
                                      'on three streams'),
                      'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': pmc_traffic(args.config),
+                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': pmc_traffic(args.config + ('-ln' if cfg.get('ln') else '')),
                      'kernel_us': dom * 1e6, 'flops_per_launch': flops_per_step(cfg),
                      'note': ('latency-bound: %.1f MFLOP and < 1 MB per launch; neither the MFMA nor the HBM '
                               'roofline binds (DESIGN.md 3.1)' % (flops_per_step(cfg) / 1e6)) if drv.fused

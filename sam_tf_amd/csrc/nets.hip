@@ -12,24 +12,31 @@ namespace {
 
 struct Net {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
-    int in, h1, h2, out;
-    int64_t oW1, ob1, oW2, ob2, oW3, ob3;  // offsets in the flat vector
+    const float *beta1, *gamma1, *beta2, *gamma2;  // LayerNorm (networks.py:53-70), null without it
+    int in, h1, h2, out, ln;
+    int64_t oW1, ob1, oW2, ob2, oW3, ob3, obeta1, ogamma1, obeta2, ogamma2;  // offsets in the flat vector
 };
 
 Net split(const samx_mlp* d, const float* p) {
     Net n;
-    n.in = d->in_dim; n.h1 = d->h1; n.h2 = d->h2; n.out = d->out_dim;
+    n.in = d->in_dim; n.h1 = d->h1; n.h2 = d->h2; n.out = d->out_dim; n.ln = d->layernorm ? 1 : 0;
     int64_t o = 0;
     n.oW1 = o; o += (int64_t)n.in * n.h1;
     n.ob1 = o; o += n.h1;
-    if (d->layernorm) o += 2 * n.h1;
+    n.obeta1 = n.ogamma1 = n.obeta2 = n.ogamma2 = 0;
+    n.beta1 = n.gamma1 = n.beta2 = n.gamma2 = nullptr;
+    if (n.ln) { n.obeta1 = o; o += n.h1; n.ogamma1 = o; o += n.h1; }
     n.oW2 = o; o += (int64_t)n.h1 * n.h2;
     n.ob2 = o; o += n.h2;
-    if (d->layernorm) o += 2 * n.h2;
+    if (n.ln) { n.obeta2 = o; o += n.h2; n.ogamma2 = o; o += n.h2; }
     n.oW3 = o; o += (int64_t)n.h2 * n.out;
     n.ob3 = o;
     n.W1 = p + n.oW1; n.b1 = p + n.ob1; n.W2 = p + n.oW2; n.b2 = p + n.ob2;
     n.W3 = p + n.oW3; n.b3 = p + n.ob3;
+    if (n.ln) {
+        n.beta1 = p + n.obeta1; n.gamma1 = p + n.ogamma1;
+        n.beta2 = p + n.obeta2; n.gamma2 = p + n.ogamma2;
+    }
     return n;
 }
 
@@ -38,7 +45,6 @@ int check_desc(const samx_mlp* d, const char* who) {
     SAMX_REQUIRE(d->in_dim > 0 && d->h1 > 0 && d->h2 > 0 && d->out_dim > 0,
                  "%s: non-positive layer size", who);
     SAMX_REQUIRE(d->h1 <= 4096 && d->h2 <= 4096 && d->in_dim <= 65536, "%s: layer too wide", who);
-    if (d->layernorm) return fail(SAMX_ERR_UNSUPPORTED, "%s: layernorm path not built yet", who);
     return SAMX_OK;
 }
 
@@ -120,7 +126,8 @@ struct HeadArgs {
     float* out1 = nullptr;       // td | ce
     float* out2 = nullptr;       // dq | ent
     float* out3 = nullptr;       // sigmoid
-    float* DZ2 = nullptr;        // [M, h2]
+    float* DZ2 = nullptr;        // [M, h2]: dq * w3 * lrelu'(H2), or (ln) the cotangent of the LayerNorm output dq * w3
+    int ln = 0;
 };
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -199,13 +206,151 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
                 a.out3[row] = sg;
             }
         } else {
-            dq = 1.f;  // interpolate rows: seed of d(sum scores)/d(inputs) (discriminator.py:136)
+            // interpolate rows: seed of d(sum scores)/d(inputs) (discriminator.py:136).  flag: the
+            // LayerNorm layout, where rows [2B,3B) are the primal copy and take no seed.
+            dq = (a.flag && row < 3 * a.B) ? 0.f : 1.f;
         }
         if (lane == 0) a.out0[row] = dq;
     }
     // dZ2 = dq * w3 * lrelu'(A2)
     float* dz = a.DZ2 + row * a.h2;
-    for (int c = lane; c < a.h2; c += 64) dz[c] = dq * a.w3[c] * (h[c] >= 0.f ? 1.f : 0.2f);
+    if (a.ln) {
+        for (int c = lane; c < a.h2; c += 64) dz[c] = dq * a.w3[c];
+    } else {
+        for (int c = lane; c < a.h2; c += 64) dz[c] = dq * a.w3[c] * (h[c] >= 0.f ? 1.f : 0.2f);
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm row kernels
+// Post-activation LayerNorm over the last axis, biased variance, eps 1e-8 (network_util.py:32-39,
+// networks.py:53-70).  One wave per row.
+constexpr float kLnEps = 1e-8f;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ beta,
+                                                     const float* __restrict__ gamma, int64_t M, int H,
+                                                     float* __restrict__ XH, float* __restrict__ N,
+                                                     float* __restrict__ R) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* a = A + row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += a[c];
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = a[c] - mean; v = fmaf(d, d, v); }
+    const float rs = 1.f / sqrtf(wave_sum(v) / (float)H + kLnEps);
+    for (int c = lane; c < H; c += 64) {
+        const float xh = (a[c] - mean) * rs;
+        XH[row * H + c] = xh;
+        N[row * H + c] = fmaf(gamma[c], xh, beta[c]);
+    }
+    if (lane == 0) R[row] = rs;
+}
+
+// cotangent of the LayerNorm output -> cotangent of the pre-activation:
+//   dxh = dn * gamma ; da = rs (dxh - mean(dxh) - xh mean(dxh xh)) [+ add] ; dz = da * lrelu'(a)
+// TA (optional) receives da before `add` and before the mask.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ DN, const float* __restrict__ A,
+                                                     const float* __restrict__ XH, const float* __restrict__ R,
+                                                     const float* __restrict__ gamma, int64_t M, int H,
+                                                     const float* add, float* DZ, float* __restrict__ TA) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t o = row * H;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float d = DN[o + c] * gamma[c];
+        s1 += d;
+        s2 = fmaf(d, XH[o + c], s2);
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H, rs = R[row];
+    for (int c = lane; c < H; c += 64) {
+        const float xh = XH[o + c];
+        float da = rs * (DN[o + c] * gamma[c] - m1 - xh * m2);
+        if (TA) TA[o + c] = da;
+        if (add) da += add[o + c];
+        DZ[o + c] = da * (A[o + c] >= 0.f ? 1.f : 0.2f);
+    }
+}
+
+// Tangent of a LayerNorm layer along a direction, and the cotangent that the tangent's dependence
+// on the primal activation sends back (second-order term of the gradient penalty; derivation in
+// DESIGN.md 3.5).  Row r of the tangent stream, primal quantities from the same row of the primal copy.
+//   ad = ZD * lrelu'(a) ; d = ad - mean(ad) ; c = mean(xh ad) ; u = rs (d - c xh) ; nd = gamma u
+//   ub = gamma TN ; Aq = <ub, d> ; Bq = <ub, xh>
+//   PA = -(rs^2 (Aq - c Bq)/H) xh - (rs Bq/H) u - rs c TA      (times lrelu'(a) when mask_out)
+__global__ __launch_bounds__(256) void ln_tan_kernel(const float* __restrict__ ZD, const float* __restrict__ A,
+                                                     const float* __restrict__ XH, const float* __restrict__ R,
+                                                     const float* __restrict__ gamma, const float* __restrict__ TN,
+                                                     const float* __restrict__ TA, int64_t M, int H,
+                                                     float* __restrict__ U, float* __restrict__ ND,
+                                                     float* __restrict__ PA, int mask_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t o = row * H;
+    float s1 = 0.f, s2 = 0.f, sa = 0.f, su = 0.f, sb = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float ad = ZD[o + c] * (A[o + c] >= 0.f ? 1.f : 0.2f);
+        const float xh = XH[o + c], ub = gamma[c] * TN[o + c];
+        s1 += ad;
+        s2 = fmaf(xh, ad, s2);
+        sa = fmaf(ub, ad, sa);
+        su += ub;
+        sb = fmaf(ub, xh, sb);
+    }
+    const float fH = (float)H;
+    const float mean_ad = wave_sum(s1) / fH, cc = wave_sum(s2) / fH;
+    const float Aq = wave_sum(sa) - mean_ad * wave_sum(su), Bq = wave_sum(sb), rs = R[row];
+    const float k1 = -(rs * rs * (Aq - cc * Bq) / fH), k2 = -(rs * Bq / fH), k3 = -(rs * cc);
+    for (int c = lane; c < H; c += 64) {
+        const float ad = ZD[o + c] * (A[o + c] >= 0.f ? 1.f : 0.2f);
+        const float xh = XH[o + c];
+        const float u = rs * ((ad - mean_ad) - cc * xh);
+        U[o + c] = u;
+        ND[o + c] = gamma[c] * u;
+        const float pa = k1 * xh + k2 * u + k3 * TA[o + c];
+        PA[o + c] = mask_out ? pa * (A[o + c] >= 0.f ? 1.f : 0.2f) : pa;
+    }
+}
+
+// LayerNorm parameter gradients: dbeta[j] = sum_{r < Mb} DN[r,j], dgamma[j] = sum_{r < Mg} DN[r,j] XH[r,j].
+// Stage 1: block (x = 64 columns, y = row chunk) -> part[y][2][H]; stage 2 adds the chunks in order.
+constexpr int kLnChunksMax = 32;
+__global__ __launch_bounds__(256) void ln_pgrad1_kernel(const float* __restrict__ DN, const float* __restrict__ XH,
+                                                        int64_t Mb, int64_t Mg, int H, int64_t chunk,
+                                                        float* __restrict__ part) {
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, col = blockIdx.x * 64 + cl;
+    const int64_t r0 = blockIdx.y * chunk, r1 = min(r0 + chunk, max(Mb, Mg));
+    float b = 0.f, g = 0.f;
+    if (col < H)
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const float dn = DN[r * H + col];
+            if (r < Mb) b += dn;
+            if (r < Mg) g = fmaf(dn, XH[r * H + col], g);
+        }
+    sh[0][rl][cl] = b;
+    sh[1][rl][cl] = g;
+    __syncthreads();
+    if (rl == 0 && col < H) {
+        part[((int64_t)blockIdx.y * 2) * H + col] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        part[((int64_t)blockIdx.y * 2 + 1) * H + col] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+__global__ __launch_bounds__(256) void ln_pgrad2_kernel(const float* __restrict__ part, int S, int H,
+                                                        float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= H) return;
+    float b = 0.f, g = 0.f;
+    for (int s = 0; s < S; ++s) {
+        b += part[((int64_t)s * 2) * H + col];
+        g += part[((int64_t)s * 2 + 1) * H + col];
+    }
+    dbeta[col] = b;
+    dgamma[col] = g;
 }
 
 template <int MODE>
@@ -426,30 +571,137 @@ int grid1d(int64_t n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-// ---------------------------------------------------------------- role: shared forward pieces
+// ---------------------------------------------------------------- role: shared pieces
 
-// XC[:, 0:ob] = obz ; XC[:, ob:] = actor(obz) ; returns hidden activations in A1a/A2a
-int actor_into(const samx_mlp* da, const Net& a, const float* obs, const float* mean,
-               const float* stdv, int64_t B, int acdim, float high, float* XC, float* A1a, float* A2a,
-               hipStream_t st) {
-    const int ob = a.in, ld = ob + acdim;
-    prep_kernel<<<grid1d(B * ob), 256, 0, st>>>(obs, nullptr, mean, stdv, B, ob, 0, XC, ld);
+int rows4(int64_t M) { return (int)((M + 3) / 4); }
+
+// Hidden-layer buffers of one network evaluation over M rows.  Without LayerNorm N1/N2 alias A1/A2.
+struct Hid {
+    float *A1, *A2;    // post-activation (the lrelu mask source)
+    float *N1, *N2;    // what the next layer reads: LayerNorm output, or the activation itself
+    float *XH1, *XH2;  // normalised activations (LayerNorm only)
+    float *R1, *R2;    // 1/std per row (LayerNorm only)
+};
+
+Hid carve_hid(Arena& ar, const samx_mlp* d, int64_t M) {
+    Hid h;
+    const int h1 = d ? d->h1 : 1, h2 = d ? d->h2 : 1;
+    const bool ln = d && d->layernorm;
+    h.A1 = ar.take<float>(M * h1);
+    h.A2 = ar.take<float>(M * h2);
+    h.N1 = ln ? ar.take<float>(M * h1) : h.A1;
+    h.N2 = ln ? ar.take<float>(M * h2) : h.A2;
+    h.XH1 = ar.take<float>(ln ? M * h1 : 1);
+    h.XH2 = ar.take<float>(ln ? M * h2 : 1);
+    h.R1 = ar.take<float>(ln ? M : 1);
+    h.R2 = ar.take<float>(ln ? M : 1);
+    return h;
+}
+
+Hid rows_of(const Hid& h, const Net& c, int64_t r0) {  // the same buffers from row r0 on
+    Hid o = h;
+    o.A1 += r0 * c.h1; o.A2 += r0 * c.h2;
+    o.N1 += r0 * c.h1; o.N2 += r0 * c.h2;
+    if (c.ln) { o.XH1 += r0 * c.h1; o.XH2 += r0 * c.h2; o.R1 += r0; o.R2 += r0; }
+    return o;
+}
+
+int ln_fwd(const float* A, const float* beta, const float* gamma, int64_t M, int H, float* XH, float* N,
+           float* R, hipStream_t st) {
+    ln_fwd_kernel<<<rows4(M), 256, 0, st>>>(A, beta, gamma, M, H, XH, N, R);
     SAMX_LAUNCH_CHECK();
-    TRY(fwd(XC, ld, B, ob, a.W1, a.b1, a.h1, A1a, a.h1, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
-    TRY(fwd(A1a, a.h1, B, a.h1, a.W2, a.b2, a.h2, A2a, a.h2, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
-    TRY(fwd(A2a, a.h2, B, a.h2, a.W3, a.b3, a.out, XC + ob, ld, EPI_BIAS_TANH, high, nullptr, 0, st));
+    return SAMX_OK;
+}
+int ln_bwd(const float* DN, const float* A, const float* XH, const float* R, const float* gamma, int64_t M,
+           int H, const float* add, float* DZ, float* TA, hipStream_t st) {
+    ln_bwd_kernel<<<rows4(M), 256, 0, st>>>(DN, A, XH, R, gamma, M, H, add, DZ, TA);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+int ln_chunks(int64_t M) {
+    int64_t s = (M + 63) / 64;
+    return (int)(s < 1 ? 1 : (s > kLnChunksMax ? kLnChunksMax : s));
+}
+// dbeta over rows < Mb, dgamma over rows < Mg; part: 2 * kLnChunksMax * H floats
+int ln_pgrad(const float* DN, const float* XH, int64_t Mb, int64_t Mg, int H, float* dbeta, float* dgamma,
+             float* part, hipStream_t st) {
+    const int64_t M = Mb > Mg ? Mb : Mg;
+    const int S = ln_chunks(M);
+    const int64_t chunk = ((M + S - 1) / S + 3) / 4 * 4;
+    ln_pgrad1_kernel<<<dim3((H + 63) / 64, S), 256, 0, st>>>(DN, XH, Mb, Mg, H, chunk, part);
+    SAMX_LAUNCH_CHECK();
+    ln_pgrad2_kernel<<<(H + 255) / 256, 256, 0, st>>>(part, S, H, dbeta, dgamma);
+    SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
 
-int hidden(const Net& c, const float* X, int64_t M, float* A1, float* A2, hipStream_t st) {
-    TRY(fwd(X, c.in, M, c.in, c.W1, c.b1, c.h1, A1, c.h1, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
-    TRY(fwd(A1, c.h1, M, c.h1, c.W2, c.b2, c.h2, A2, c.h2, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+// forward through the two hidden layers: h.N2 is the input of the head
+int hidden(const Net& c, const float* X, int64_t ldx, int64_t M, const Hid& h, hipStream_t st) {
+    TRY(fwd(X, ldx, M, c.in, c.W1, c.b1, c.h1, h.A1, c.h1, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    if (c.ln) TRY(ln_fwd(h.A1, c.beta1, c.gamma1, M, c.h1, h.XH1, h.N1, h.R1, st));
+    TRY(fwd(h.N1, c.h1, M, c.h1, c.W2, c.b2, c.h2, h.A2, c.h2, EPI_BIAS_LRELU, 0.f, nullptr, 0, st));
+    if (c.ln) TRY(ln_fwd(h.A2, c.beta2, c.gamma2, M, c.h2, h.XH2, h.N2, h.R2, st));
+    return SAMX_OK;
+}
+
+// Cotangent buffers of the two hidden layers: DN = of the layer output (LayerNorm only), DZ = of the
+// pre-activation.
+struct Cot {
+    float *DN1, *DN2, *DZ1, *DZ2;
+};
+Cot carve_cot(Arena& ar, const samx_mlp* d, int64_t M) {
+    Cot c;
+    const int h1 = d ? d->h1 : 1, h2 = d ? d->h2 : 1;
+    const bool ln = d && d->layernorm;
+    c.DZ2 = ar.take<float>(M * h2);
+    c.DZ1 = ar.take<float>(M * h1);
+    c.DN2 = ln ? ar.take<float>(M * h2) : c.DZ2;
+    c.DN1 = ln ? ar.take<float>(M * h1) : c.DZ1;
+    return c;
+}
+// where a head (or the layer above) must leave the cotangent of the second hidden layer's output
+float* top_cot(const Net& c, const Cot& k) { return c.ln ? k.DN2 : k.DZ2; }
+
+// from the cotangent of the second hidden output (k.DN2 with LayerNorm; without it k.DZ2 already holds
+// the masked pre-activation cotangent) down to k.DZ1
+int back_hidden(const Net& c, int64_t M, const Hid& h, const Cot& k, hipStream_t st) {
+    if (c.ln) {
+        TRY(ln_bwd(k.DN2, h.A2, h.XH2, h.R2, c.gamma2, M, c.h2, nullptr, k.DZ2, nullptr, st));
+        TRY(bwd_data(k.DZ2, c.h2, M, c.h2, c.W2, c.h2, c.h1, k.DN1, c.h1, EPI_NONE, nullptr, 0, nullptr, 0, 0.f,
+                     st));
+        TRY(ln_bwd(k.DN1, h.A1, h.XH1, h.R1, c.gamma1, M, c.h1, nullptr, k.DZ1, nullptr, st));
+    } else {
+        TRY(bwd_data(k.DZ2, c.h2, M, c.h2, c.W2, c.h2, c.h1, k.DZ1, c.h1, EPI_MASK, h.A1, c.h1, nullptr, 0, 0.f,
+                     st));
+    }
+    return SAMX_OK;
+}
+
+// LayerNorm parameter gradients of both layers into the flat gradient
+int ln_pgrads(const Net& c, int64_t Mb, int64_t Mg, const Hid& h, const Cot& k, float* grad, float* part,
+              hipStream_t st) {
+    if (!c.ln) return SAMX_OK;
+    TRY(ln_pgrad(k.DN2, h.XH2, Mb, Mg, c.h2, grad + c.obeta2, grad + c.ogamma2, part, st));
+    TRY(ln_pgrad(k.DN1, h.XH1, Mb, Mg, c.h1, grad + c.obeta1, grad + c.ogamma1, part, st));
+    return SAMX_OK;
+}
+
+// XC[:, 0:ob] = obz ; XC[:, ob:] = actor(obz) ; hidden activations stay in ha
+int actor_into(const Net& a, const float* obs, const float* mean, const float* stdv, int64_t B, int acdim,
+               float high, float* XC, const Hid& ha, hipStream_t st) {
+    const int ob = a.in, ld = ob + acdim;
+    prep_kernel<<<grid1d(B * ob), 256, 0, st>>>(obs, nullptr, mean, stdv, B, ob, 0, XC, ld);
+    SAMX_LAUNCH_CHECK();
+    TRY(hidden(a, XC, ld, B, ha, st));
+    TRY(fwd(ha.N2, a.h2, B, a.h2, a.W3, a.b3, a.out, XC + ob, ld, EPI_BIAS_TANH, high, nullptr, 0, st));
     return SAMX_OK;
 }
 
 struct AgentWs {
-    float *XC, *A1a, *A2a, *A1c, *A2c, *DZ2c, *DZ1c, *A1d, *A2d, *DZ2d, *DZ1d, *dAd, *dPre, *DZ2a,
-        *DZ1a, *row0, *row1, *row2, *partials;
+    float* XC;
+    Hid ha, hc, hd;   // actor, critic, reward-net evaluations
+    Cot ka, kc, kd;
+    float *dAd, *dPre, *row0, *row1, *row2, *partials, *lnpart;
     double* wd_part;
     size_t partial_floats;
 };
@@ -457,32 +709,33 @@ struct AgentWs {
 AgentWs carve_agent(Arena& ar, const samx_mlp* da, const samx_mlp* dc, const samx_mlp* dd, int64_t B) {
     AgentWs w;
     const int acdim = dc->in_dim - (da ? da->in_dim : 0);
-    const int h1a = da ? da->h1 : 1, h2a = da ? da->h2 : 1;
     w.XC = ar.take<float>(B * dc->in_dim);
-    w.A1a = ar.take<float>(B * h1a);
-    w.A2a = ar.take<float>(B * h2a);
-    w.A1c = ar.take<float>(B * dc->h1);
-    w.A2c = ar.take<float>(B * dc->h2);
-    w.DZ2c = ar.take<float>(B * dc->h2);
-    w.DZ1c = ar.take<float>(B * dc->h1);
-    const int h1d = dd ? dd->h1 : 1, h2d = dd ? dd->h2 : 1;
-    w.A1d = ar.take<float>(B * h1d);
-    w.A2d = ar.take<float>(B * h2d);
-    w.DZ2d = ar.take<float>(B * h2d);
-    w.DZ1d = ar.take<float>(B * h1d);
+    w.ha = carve_hid(ar, da, B);
+    w.hc = carve_hid(ar, dc, B);
+    w.hd = carve_hid(ar, dd, B);
+    w.ka = carve_cot(ar, da, B);
+    w.kc = carve_cot(ar, dc, B);
+    w.kd = carve_cot(ar, dd, B);
     w.dAd = ar.take<float>(B * (acdim > 0 ? acdim : 1));
     w.dPre = ar.take<float>(B * (acdim > 0 ? acdim : 1));
-    w.DZ2a = ar.take<float>(B * h2a);
-    w.DZ1a = ar.take<float>(B * h1a);
     w.row0 = ar.take<float>(B);
     w.row1 = ar.take<float>(B);
     w.row2 = ar.take<float>(B);
     w.wd_part = ar.take<double>(kWdBlocks);
+    int hmax = dc->h1 > dc->h2 ? dc->h1 : dc->h2;
+    if (da) { hmax = da->h1 > hmax ? da->h1 : hmax; hmax = da->h2 > hmax ? da->h2 : hmax; }
+    w.lnpart = ar.take<float>((size_t)2 * kLnChunksMax * hmax);
     size_t pf = wgrad_partial_floats(dc, B);
     if (da) { size_t s = wgrad_partial_floats(da, B); if (s > pf) pf = s; }
     w.partial_floats = pf;
     w.partials = ar.take<float>(pf);
     return w;
+}
+
+HeadArgs head_of(const Net& c, const Hid& h, int64_t M) {
+    HeadArgs a;
+    a.H2 = h.N2; a.w3 = c.W3; a.b3 = c.b3; a.M = M; a.h2 = c.h2; a.ln = c.ln;
+    return a;
 }
 
 }  // namespace
@@ -514,14 +767,14 @@ int samx_act_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const fl
     AgentWs w = carve_agent(ar, da, dc, nullptr, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_act_q: workspace %zu < %zu", ws_bytes, ar.off);
     Net a = split(da, pa), c = split(dc, pc);
-    TRY(actor_into(da, a, obs, mean, stdv, B, da->out_dim, high, w.XC, w.A1a, w.A2a, st));
+    TRY(actor_into(a, obs, mean, stdv, B, da->out_dim, high, w.XC, w.ha, st));
     copy_cols_kernel<<<grid1d(B * da->out_dim), 256, 0, st>>>(w.XC + da->in_dim, dc->in_dim, B,
                                                              da->out_dim, ac_out);
     SAMX_LAUNCH_CHECK();
     if (q_out) {
-        TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-        HeadArgs h;
-        h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.out0 = q_out;
+        TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+        HeadArgs h = head_of(c, w.hc, B);
+        h.out0 = q_out;
         TRY(launch_head<HEAD_Q>(h, st));
     }
     return SAMX_OK;
@@ -542,10 +795,9 @@ int samx_targ_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const f
     AgentWs w = carve_agent(ar, da, dc, nullptr, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_targ_q: workspace %zu < %zu", ws_bytes, ar.off);
     Net a = split(da, pa), c = split(dc, pc);
-    TRY(actor_into(da, a, obs1, mean, stdv, B, da->out_dim, high, w.XC, w.A1a, w.A2a, st));
-    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-    HeadArgs h;
-    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
+    TRY(actor_into(a, obs1, mean, stdv, B, da->out_dim, high, w.XC, w.ha, st));
+    TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+    HeadArgs h = head_of(c, w.hc, B);
     h.r0 = rews; h.r1 = dones1; h.r2 = td_len; h.c0 = gamma; h.out0 = out;
     return launch_head<HEAD_TARG>(h, st);
 }
@@ -566,9 +818,9 @@ int samx_td_errors(const samx_mlp* dc, const float* pc, const float* obs0, const
     prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs0, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
                                                  c.in);
     SAMX_LAUNCH_CHECK();
-    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-    HeadArgs h;
-    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.r0 = tc1s; h.out0 = td_out;
+    TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+    HeadArgs h = head_of(c, w.hc, B);
+    h.r0 = tc1s; h.out0 = td_out;
     return launch_head<HEAD_TD>(h, st);
 }
 
@@ -587,9 +839,9 @@ int samx_reward(const samx_mlp* dd, const float* pd, const float* obs, const flo
     prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
                                                  c.in);
     SAMX_LAUNCH_CHECK();
-    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-    HeadArgs h;
-    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2; h.flag = non_satur_grad; h.out0 = out;
+    TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+    HeadArgs h = head_of(c, w.hc, B);
+    h.flag = non_satur_grad; h.out0 = out;
     return launch_head<HEAD_REWARD>(h, st);
 }
 
@@ -611,20 +863,19 @@ int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, con
     prep_kernel<<<grid1d(B * c.in), 256, 0, st>>>(obs0, acs, mean, stdv, B, ob_dim, c.in - ob_dim, w.XC,
                                                  c.in);
     SAMX_LAUNCH_CHECK();
-    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-    HeadArgs h;
-    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
+    TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+    HeadArgs h = head_of(c, w.hc, B);
     h.r0 = tc1s; h.r1 = iws; h.c0 = td_scale / (float)B;
-    h.out0 = w.row0; h.out1 = td_out; h.out2 = w.row1; h.DZ2 = w.DZ2c;
+    h.out0 = w.row0; h.out1 = td_out; h.out2 = w.row1; h.DZ2 = top_cot(c, w.kc);
     TRY(launch_head<HEAD_CRITIC>(h, st));
-    TRY(wgrad(w.A2c, c.h2, c.h2, w.row1, 1, 1, B, B, grad_out + c.oW3, 0.f, nullptr, w.partials,
+    TRY(wgrad(w.hc.N2, c.h2, c.h2, w.row1, 1, 1, B, B, grad_out + c.oW3, 0.f, nullptr, w.partials,
               w.partial_floats, st));
-    TRY(wgrad(w.A1c, c.h1, c.h1, w.DZ2c, c.h2, c.h2, B, B, grad_out + c.oW2, wd_scale, c.W2, w.partials,
+    TRY(back_hidden(c, B, w.hc, w.kc, st));
+    TRY(wgrad(w.hc.N1, c.h1, c.h1, w.kc.DZ2, c.h2, c.h2, B, B, grad_out + c.oW2, wd_scale, c.W2, w.partials,
               w.partial_floats, st));
-    TRY(bwd_data(w.DZ2c, c.h2, B, c.h2, c.W2, c.h2, c.h1, w.DZ1c, c.h1, EPI_MASK, w.A1c, c.h1, nullptr, 0,
-                 0.f, st));
-    TRY(wgrad(w.XC, c.in, c.in, w.DZ1c, c.h1, c.h1, B, B, grad_out + c.oW1, wd_scale, c.W1, w.partials,
+    TRY(wgrad(w.XC, c.in, c.in, w.kc.DZ1, c.h1, c.h1, B, B, grad_out + c.oW1, wd_scale, c.W1, w.partials,
               w.partial_floats, st));
+    TRY(ln_pgrads(c, B, B, w.hc, w.kc, grad_out, w.lnpart, st));
     if (wd_scale > 0.f) {
         wd_sumsq_kernel<<<kWdBlocks, 256, 0, st>>>(c.W1, (int64_t)c.in * c.h1, c.W2, (int64_t)c.h1 * c.h2,
                                                    w.wd_part);
@@ -657,41 +908,43 @@ int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, con
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_actor_grad: workspace %zu < %zu", ws_bytes, ar.off);
     Net a = split(da, pa), c = split(dc, pc);
     const int ob = a.in, A = a.out, ld = ob + A;
-    TRY(actor_into(da, a, obs0, mean, stdv, B, A, high, w.XC, w.A1a, w.A2a, st));
+    TRY(actor_into(a, obs0, mean, stdv, B, A, high, w.XC, w.ha, st));
     // Q branch: forward, then back to the action input
-    TRY(hidden(c, w.XC, B, w.A1c, w.A2c, st));
-    HeadArgs h;
-    h.H2 = w.A2c; h.w3 = c.W3; h.b3 = c.b3; h.M = B; h.h2 = c.h2;
-    h.c0 = -q_scale / (float)B; h.out0 = w.row0; h.DZ2 = w.DZ2c;
+    TRY(hidden(c, w.XC, c.in, B, w.hc, st));
+    HeadArgs h = head_of(c, w.hc, B);
+    h.c0 = -q_scale / (float)B; h.out0 = w.row0; h.DZ2 = top_cot(c, w.kc);
     TRY(launch_head<HEAD_ACTOR_Q>(h, st));
-    TRY(bwd_data(w.DZ2c, c.h2, B, c.h2, c.W2, c.h2, c.h1, w.DZ1c, c.h1, EPI_MASK, w.A1c, c.h1, nullptr, 0,
-                 0.f, st));
+    TRY(back_hidden(c, B, w.hc, w.kc, st));
     const float* add = nullptr;
     if (use_d) {
         Net d = split(dd, pd);
-        TRY(hidden(d, w.XC, B, w.A1d, w.A2d, st));
-        HeadArgs hd;
-        hd.H2 = w.A2d; hd.w3 = d.W3; hd.b3 = d.b3; hd.M = B; hd.h2 = d.h2;
-        hd.c0 = -d_scale / (float)B; hd.out0 = w.row1; hd.DZ2 = w.DZ2d;
+        TRY(hidden(d, w.XC, d.in, B, w.hd, st));
+        HeadArgs hd = head_of(d, w.hd, B);
+        hd.c0 = -d_scale / (float)B; hd.out0 = w.row1; hd.DZ2 = top_cot(d, w.kd);
         TRY(launch_head<HEAD_ACTOR_Q>(hd, st));
-        TRY(bwd_data(w.DZ2d, d.h2, B, d.h2, d.W2, d.h2, d.h1, w.DZ1d, d.h1, EPI_MASK, w.A1d, d.h1, nullptr,
-                     0, 0.f, st));
-        TRY(bwd_data(w.DZ1d, d.h1, B, d.h1, d.W1 + (int64_t)ob * d.h1, d.h1, A, w.dAd, A, EPI_NONE,
+        TRY(back_hidden(d, B, w.hd, w.kd, st));
+        TRY(bwd_data(w.kd.DZ1, d.h1, B, d.h1, d.W1 + (int64_t)ob * d.h1, d.h1, A, w.dAd, A, EPI_NONE,
                      nullptr, 0, nullptr, 0, 0.f, st));
         add = w.dAd;
     }
     // d loss / d pre-tanh = (dQ/da [+ dD/da]) * high * (1 - tanh^2)
-    TRY(bwd_data(w.DZ1c, c.h1, B, c.h1, c.W1 + (int64_t)ob * c.h1, c.h1, A, w.dPre, A, EPI_ADD_TANHGRAD,
+    TRY(bwd_data(w.kc.DZ1, c.h1, B, c.h1, c.W1 + (int64_t)ob * c.h1, c.h1, A, w.dPre, A, EPI_ADD_TANHGRAD,
                  w.XC + ob, ld, add, A, high, st));
-    TRY(wgrad(w.A2a, a.h2, a.h2, w.dPre, A, A, B, B, grad_out + a.oW3, 0.f, nullptr, w.partials,
+    TRY(wgrad(w.ha.N2, a.h2, a.h2, w.dPre, A, A, B, B, grad_out + a.oW3, 0.f, nullptr, w.partials,
               w.partial_floats, st));
-    TRY(bwd_data(w.dPre, A, B, A, a.W3, A, a.h2, w.DZ2a, a.h2, EPI_MASK, w.A2a, a.h2, nullptr, 0, 0.f, st));
-    TRY(wgrad(w.A1a, a.h1, a.h1, w.DZ2a, a.h2, a.h2, B, B, grad_out + a.oW2, 0.f, nullptr, w.partials,
+    // actor backward: cotangent of its second hidden output = dPre W3^T
+    if (a.ln) {
+        TRY(bwd_data(w.dPre, A, B, A, a.W3, A, a.h2, w.ka.DN2, a.h2, EPI_NONE, nullptr, 0, nullptr, 0, 0.f, st));
+    } else {
+        TRY(bwd_data(w.dPre, A, B, A, a.W3, A, a.h2, w.ka.DZ2, a.h2, EPI_MASK, w.ha.A2, a.h2, nullptr, 0, 0.f,
+                     st));
+    }
+    TRY(back_hidden(a, B, w.ha, w.ka, st));
+    TRY(wgrad(w.ha.N1, a.h1, a.h1, w.ka.DZ2, a.h2, a.h2, B, B, grad_out + a.oW2, 0.f, nullptr, w.partials,
               w.partial_floats, st));
-    TRY(bwd_data(w.DZ2a, a.h2, B, a.h2, a.W2, a.h2, a.h1, w.DZ1a, a.h1, EPI_MASK, w.A1a, a.h1, nullptr, 0,
-                 0.f, st));
-    TRY(wgrad(w.XC, ld, ob, w.DZ1a, a.h1, a.h1, B, B, grad_out + a.oW1, 0.f, nullptr, w.partials,
+    TRY(wgrad(w.XC, ld, ob, w.ka.DZ1, a.h1, a.h1, B, B, grad_out + a.oW1, 0.f, nullptr, w.partials,
               w.partial_floats, st));
+    TRY(ln_pgrads(a, B, B, w.ha, w.ka, grad_out, w.lnpart, st));
     actor_losses_kernel<<<1, 1024, 0, st>>>(w.row0, use_d ? w.row1 : nullptr, B, q_scale, d_scale,
                                             losses_out);
     SAMX_LAUNCH_CHECK();
@@ -699,28 +952,45 @@ int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, con
 }
 
 namespace {
+// Row blocks of the discriminator pass.  Without LayerNorm: [policy | expert | interpolate] (3B).
+// With LayerNorm: [policy | expert | interpolate copy (primal stream) | interpolate (tangent stream)]
+// (4B) — see samx_disc_grad.
 struct DiscWs {
-    float *X, *A1, *A2, *DS, *DZ2, *DZ1, *G, *ce, *ent, *sg, *gp, *partials;
+    float* X;
+    Hid h;
+    Cot k;
+    float *DS, *G, *ce, *ent, *sg, *gp, *partials, *ZD, *TA1, *TA2, *lnpart;
     double* gp_part;
     size_t partial_floats;
 };
 DiscWs carve_disc(Arena& ar, const samx_mlp* dd, int64_t B) {
     DiscWs w;
-    w.X = ar.take<float>(3 * B * dd->in_dim);
-    w.A1 = ar.take<float>(3 * B * dd->h1);
-    w.A2 = ar.take<float>(3 * B * dd->h2);
-    w.DS = ar.take<float>(3 * B);
-    w.DZ2 = ar.take<float>(3 * B * dd->h2);
-    w.DZ1 = ar.take<float>(3 * B * dd->h1);
+    const bool ln = dd->layernorm;
+    const int64_t M = (ln ? 4 : 3) * B;
+    const int hmax = dd->h1 > dd->h2 ? dd->h1 : dd->h2;
+    w.X = ar.take<float>(M * dd->in_dim);
+    w.h = carve_hid(ar, dd, M);
+    w.k = carve_cot(ar, dd, M);
+    w.DS = ar.take<float>(M);
     w.G = ar.take<float>(B * dd->in_dim);
     w.ce = ar.take<float>(2 * B);
     w.ent = ar.take<float>(2 * B);
     w.sg = ar.take<float>(2 * B);
     w.gp = ar.take<float>(4);
     w.gp_part = ar.take<double>(2 * kGpBlocks);
-    w.partial_floats = wgrad_partial_floats(dd, 3 * B);
+    w.ZD = ar.take<float>(ln ? B * hmax : 1);
+    w.TA1 = ar.take<float>(ln ? B * dd->h1 : 1);
+    w.TA2 = ar.take<float>(ln ? B * dd->h2 : 1);
+    w.lnpart = ar.take<float>(ln ? (size_t)2 * kLnChunksMax * hmax : 1);
+    w.partial_floats = wgrad_partial_floats(dd, M);
     w.partials = ar.take<float>(w.partial_floats);
     return w;
+}
+
+// interpolate rows also into a second block (LayerNorm path: the primal copy)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int64_t n,
+                                                        float* __restrict__ dst) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) dst[t] = src[t];
 }
 }  // namespace
 
@@ -748,43 +1018,105 @@ int samx_disc_grad(const samx_mlp* dd, const float* pd, const float* p_obs, cons
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_disc_grad: workspace %zu < %zu", ws_bytes, ar.off);
     Net d = split(dd, pd);
     const int ob = ob_dim, ac = d.in - ob_dim;
-    const int64_t M = 3 * B;
     const float gp_coeff = 10.f;  // discriminator.py:154
     disc_prep_kernel<<<grid1d(B * d.in), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, mean,
                                                       stdv, B, ob, ac, w.X);
     SAMX_LAUNCH_CHECK();
-    TRY(hidden(d, w.X, M, w.A1, w.A2, st));
-    HeadArgs h;
-    h.H2 = w.A2; h.w3 = d.W3; h.b3 = d.b3; h.M = M; h.h2 = d.h2; h.B = B;
-    h.r0 = fake_labels; h.r1 = real_labels; h.c1 = ent_reg_scale;
-    h.out0 = w.DS; h.out1 = w.ce; h.out2 = w.ent; h.out3 = w.sg; h.DZ2 = w.DZ2;
-    TRY(launch_head<HEAD_DISC>(h, st));
-    // back to the first pre-activation for all 3B rows; for the interpolate rows this is the
-    // input-gradient chain of discriminator.py:136
-    TRY(bwd_data(w.DZ2, d.h2, M, d.h2, d.W2, d.h2, d.h1, w.DZ1, d.h1, EPI_MASK, w.A1, d.h1, nullptr, 0, 0.f,
-                 st));
-    const float* DZ1i = w.DZ1 + 2 * B * d.h1;
-    TRY(bwd_data(DZ1i, d.h1, B, d.h1, d.W1, d.h1, d.in, w.G, d.in, EPI_NONE, nullptr, 0, nullptr, 0, 0.f,
-                 st));
-    gp_sumsq_kernel<<<kGpBlocks, 256, 0, st>>>(w.G, B, ob, ac, w.gp_part);
-    SAMX_LAUNCH_CHECK();
-    // V (cotangent of the input gradient) replaces the interpolates in X: they are not needed again
-    float* Xi = w.X + 2 * B * d.in;
-    gp_scale_kernel<<<grid1d(B * d.in), 256, 0, st>>>(w.G, B, ob, ac, w.gp_part, kGpBlocks, gp_coeff, Xi,
-                                                     w.gp);
-    SAMX_LAUNCH_CHECK();
-    // tangent pass along V through the interpolate rows, in place over their activations
-    float* A1i = w.A1 + 2 * B * d.h1;
-    float* A2i = w.A2 + 2 * B * d.h2;
-    TRY(fwd(Xi, d.in, B, d.in, d.W1, nullptr, d.h1, A1i, d.h1, EPI_MASK, 0.f, A1i, d.h1, st));
-    TRY(fwd(A1i, d.h1, B, d.h1, d.W2, nullptr, d.h2, A2i, d.h2, EPI_MASK, 0.f, A2i, d.h2, st));
-    // parameter gradients: one reduction over the 3B stacked rows per layer
-    TRY(wgrad(w.A2, d.h2, d.h2, w.DS, 1, 1, M, 2 * B, grad_out + d.oW3, 0.f, nullptr, w.partials,
-              w.partial_floats, st));
-    TRY(wgrad(w.A1, d.h1, d.h1, w.DZ2, d.h2, d.h2, M, 2 * B, grad_out + d.oW2, 0.f, nullptr, w.partials,
-              w.partial_floats, st));
-    TRY(wgrad(w.X, d.in, d.in, w.DZ1, d.h1, d.h1, M, 2 * B, grad_out + d.oW1, 0.f, nullptr, w.partials,
-              w.partial_floats, st));
+
+    if (!d.ln) {
+        // ---- leaky-ReLU only: the tangent of the network is linear in its masks, the second-order
+        // term has no primal stream.  Rows [0,B) policy, [B,2B) expert, [2B,3B) interpolates.
+        const int64_t M = 3 * B;
+        TRY(hidden(d, w.X, d.in, M, w.h, st));
+        HeadArgs h = head_of(d, w.h, M);
+        h.B = B; h.r0 = fake_labels; h.r1 = real_labels; h.c1 = ent_reg_scale;
+        h.out0 = w.DS; h.out1 = w.ce; h.out2 = w.ent; h.out3 = w.sg; h.DZ2 = w.k.DZ2;
+        TRY(launch_head<HEAD_DISC>(h, st));
+        // back to the first pre-activation for all 3B rows; for the interpolate rows this is the
+        // input-gradient chain of discriminator.py:136
+        TRY(back_hidden(d, M, w.h, w.k, st));
+        const float* DZ1i = w.k.DZ1 + 2 * B * d.h1;
+        TRY(bwd_data(DZ1i, d.h1, B, d.h1, d.W1, d.h1, d.in, w.G, d.in, EPI_NONE, nullptr, 0, nullptr, 0, 0.f,
+                     st));
+        gp_sumsq_kernel<<<kGpBlocks, 256, 0, st>>>(w.G, B, ob, ac, w.gp_part);
+        SAMX_LAUNCH_CHECK();
+        // V (cotangent of the input gradient) replaces the interpolates in X: not needed again
+        float* Xi = w.X + 2 * B * d.in;
+        gp_scale_kernel<<<grid1d(B * d.in), 256, 0, st>>>(w.G, B, ob, ac, w.gp_part, kGpBlocks, gp_coeff, Xi,
+                                                         w.gp);
+        SAMX_LAUNCH_CHECK();
+        // tangent pass along V through the interpolate rows, in place over their activations
+        float* A1i = w.h.A1 + 2 * B * d.h1;
+        float* A2i = w.h.A2 + 2 * B * d.h2;
+        TRY(fwd(Xi, d.in, B, d.in, d.W1, nullptr, d.h1, A1i, d.h1, EPI_MASK, 0.f, A1i, d.h1, st));
+        TRY(fwd(A1i, d.h1, B, d.h1, d.W2, nullptr, d.h2, A2i, d.h2, EPI_MASK, 0.f, A2i, d.h2, st));
+        // parameter gradients: one reduction over the 3B stacked rows per layer
+        TRY(wgrad(w.h.A2, d.h2, d.h2, w.DS, 1, 1, M, 2 * B, grad_out + d.oW3, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.h.A1, d.h1, d.h1, w.k.DZ2, d.h2, d.h2, M, 2 * B, grad_out + d.oW2, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.X, d.in, d.in, w.k.DZ1, d.h1, d.h1, M, 2 * B, grad_out + d.oW1, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+    } else {
+        // ---- with LayerNorm the tangent of a layer depends on its primal activation, so the
+        // gradient of <V, d score/d input> has two streams:
+        //   T (tangent)  rows Ri = [3B,4B): the first backward leaves T_n / T_z there; afterwards their
+        //                forward-side slots are overwritten by the tangent forward (V, u, n-dot);
+        //   P (primal)   rows Rt = [2B,3B): an exact copy of the interpolates' forward; receives the
+        //                cotangents the tangent layers send back to the primal activations.
+        // One weight-gradient reduction per layer then runs over all 4B stacked rows, biases and
+        // LayerNorm betas over the first 3B.
+        const int64_t M = 4 * B, Rt = 2 * B, Ri = 3 * B;
+        copy_rows_kernel<<<grid1d(B * d.in), 256, 0, st>>>(w.X + Rt * d.in, B * d.in, w.X + Ri * d.in);
+        SAMX_LAUNCH_CHECK();
+        TRY(hidden(d, w.X, d.in, M, w.h, st));
+        HeadArgs h = head_of(d, w.h, M);
+        h.B = B; h.r0 = fake_labels; h.r1 = real_labels; h.c1 = ent_reg_scale;
+        h.out0 = w.DS; h.out1 = w.ce; h.out2 = w.ent; h.out3 = w.sg; h.DZ2 = w.k.DN2; h.flag = 1;
+        TRY(launch_head<HEAD_DISC>(h, st));  // seeds: policy/expert dq, Rt 0, Ri 1
+        // first backward over all rows, keeping T_a (pre-mask) of the Ri rows
+        Hid hi = rows_of(w.h, d, Ri), ht = rows_of(w.h, d, Rt);
+        TRY(ln_bwd(w.k.DN2, w.h.A2, w.h.XH2, w.h.R2, d.gamma2, Ri, d.h2, nullptr, w.k.DZ2, nullptr, st));
+        TRY(ln_bwd(w.k.DN2 + Ri * d.h2, hi.A2, hi.XH2, hi.R2, d.gamma2, B, d.h2, nullptr, w.k.DZ2 + Ri * d.h2,
+                   w.TA2, st));
+        TRY(bwd_data(w.k.DZ2, d.h2, M, d.h2, d.W2, d.h2, d.h1, w.k.DN1, d.h1, EPI_NONE, nullptr, 0, nullptr, 0,
+                     0.f, st));
+        TRY(ln_bwd(w.k.DN1, w.h.A1, w.h.XH1, w.h.R1, d.gamma1, Ri, d.h1, nullptr, w.k.DZ1, nullptr, st));
+        TRY(ln_bwd(w.k.DN1 + Ri * d.h1, hi.A1, hi.XH1, hi.R1, d.gamma1, B, d.h1, nullptr, w.k.DZ1 + Ri * d.h1,
+                   w.TA1, st));
+        TRY(bwd_data(w.k.DZ1 + Ri * d.h1, d.h1, B, d.h1, d.W1, d.h1, d.in, w.G, d.in, EPI_NONE, nullptr, 0,
+                     nullptr, 0, 0.f, st));
+        gp_sumsq_kernel<<<kGpBlocks, 256, 0, st>>>(w.G, B, ob, ac, w.gp_part);
+        SAMX_LAUNCH_CHECK();
+        float* Xi = w.X + Ri * d.in;  // V replaces the Ri copy of the interpolates
+        gp_scale_kernel<<<grid1d(B * d.in), 256, 0, st>>>(w.G, B, ob, ac, w.gp_part, kGpBlocks, gp_coeff, Xi,
+                                                         w.gp);
+        SAMX_LAUNCH_CHECK();
+        // tangent forward, layer 1: z-dot = V W1 ; LayerNorm tangent with the primal copy's statistics.
+        // Its primal cotangent P_a1 is parked (unmasked) in DZ1[Rt] until P_n1 has come down.
+        TRY(fwd(Xi, d.in, B, d.in, d.W1, nullptr, d.h1, w.ZD, d.h1, EPI_NONE, 0.f, nullptr, 0, st));
+        ln_tan_kernel<<<rows4(B), 256, 0, st>>>(w.ZD, ht.A1, ht.XH1, ht.R1, d.gamma1, w.k.DN1 + Ri * d.h1, w.TA1,
+                                                B, d.h1, hi.XH1, hi.N1, w.k.DZ1 + Rt * d.h1, 0);
+        SAMX_LAUNCH_CHECK();
+        // layer 2: z-dot = n-dot1 W2 ; P_z2 = P_a2 * mask straight into DZ2[Rt]
+        TRY(fwd(hi.N1, d.h1, B, d.h1, d.W2, nullptr, d.h2, w.ZD, d.h2, EPI_NONE, 0.f, nullptr, 0, st));
+        ln_tan_kernel<<<rows4(B), 256, 0, st>>>(w.ZD, ht.A2, ht.XH2, ht.R2, d.gamma2, w.k.DN2 + Ri * d.h2, w.TA2,
+                                                B, d.h2, hi.XH2, hi.N2, w.k.DZ2 + Rt * d.h2, 1);
+        SAMX_LAUNCH_CHECK();
+        // primal stream: P_n1 = P_z2 W2^T ; P_z1 = (J1(gamma1 P_n1) + P_a1) * mask
+        TRY(bwd_data(w.k.DZ2 + Rt * d.h2, d.h2, B, d.h2, d.W2, d.h2, d.h1, w.k.DN1 + Rt * d.h1, d.h1, EPI_NONE,
+                     nullptr, 0, nullptr, 0, 0.f, st));
+        TRY(ln_bwd(w.k.DN1 + Rt * d.h1, ht.A1, ht.XH1, ht.R1, d.gamma1, B, d.h1, w.k.DZ1 + Rt * d.h1,
+                   w.k.DZ1 + Rt * d.h1, nullptr, st));
+        // parameter gradients over the 4B stacked rows (ones row over the first 3B)
+        TRY(wgrad(w.h.N2, d.h2, d.h2, w.DS, 1, 1, M, 3 * B, grad_out + d.oW3, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.h.N1, d.h1, d.h1, w.k.DZ2, d.h2, d.h2, M, 3 * B, grad_out + d.oW2, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.X, d.in, d.in, w.k.DZ1, d.h1, d.h1, M, 3 * B, grad_out + d.oW1, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(ln_pgrads(d, 3 * B, M, w.h, w.k, grad_out, w.lnpart, st));
+    }
     disc_losses_kernel<<<1, 1024, 0, st>>>(w.ce, w.ent, w.sg, w.gp, B, ent_reg_scale, gp_coeff,
                                            losses_out);
     SAMX_LAUNCH_CHECK();

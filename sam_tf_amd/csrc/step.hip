@@ -455,6 +455,12 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             return fail(SAMX_ERR_UNSUPPORTED, "samx_step_grads: inline statistics need the fused path");
         SAMX_REQUIRE(L->d_mean && L->d_std, "samx_step_grads: inline statistics need learner.d_mean/d_std");
     }
+    if (!use_fused(L, B) && !(part & 1)) {  // reduction part only
+        fused::ApplyArgs f = make_apply(L, w, 0, 1.f);
+        rc = fused::launch_seg_sumsq(f, st);
+        if (rc != SAMX_OK) return rc;
+        return fused::launch_tick(L->steps, L->steps + 1, L->steps + 2, st);
+    }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense
         // rows and materialised randoms, so indirection / in-kernel draws are resolved first.

@@ -21,8 +21,9 @@ class OracleLearner(object):
         from oracle.replay_oracle import PrioritizedReplayOracle
         self.NO = NO
         h1, h2 = mu.hps.hid_widths
-        self.da = NO.MLP(mu.ob_dim, h1, h2, mu.ac_dim, False)
-        self.dc = NO.MLP(mu.ob_dim + mu.ac_dim, h1, h2, 1, False)
+        ln = bool(mu.hps.with_layernorm)
+        self.da = NO.MLP(mu.ob_dim, h1, h2, mu.ac_dim, ln)
+        self.dc = NO.MLP(mu.ob_dim + mu.ac_dim, h1, h2, 1, ln)
         self.pa = mu.actor.get_flat().astype(np.float64); self.pc = mu.critic.get_flat().astype(np.float64)
         self.pa_t = mu.targ_actor.get_flat().astype(np.float64)
         self.pc_t = mu.targ_critic.get_flat().astype(np.float64)
@@ -92,11 +93,11 @@ class OracleLearner(object):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln'])
 def test_k_steps_match_oracle(cfg_name, graph):
     import bench
     from sam_tf_amd.comm import TorchComm
-    cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+    cfg = dict(bench.CONFIGS[cfg_name.split('-')[0]], mem=2048, ln=cfg_name.endswith('-ln'))
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])

@@ -31,11 +31,12 @@ ALL = SMALL + ['C4', 'C5']
 
 
 @pytest.mark.parametrize('rms', [True, False])
+@pytest.mark.parametrize('ln', [False, True])
 @pytest.mark.parametrize('name', ALL)
-def test_targ_q_and_act(name, rms):
+def test_targ_q_and_act(name, rms, ln):
     from sam_tf_amd import ops
     from oracle import nets_oracle as NO
-    c = make_case(name); P, D = c['P'], c['D']
+    c = make_case(name, ln=ln); P, D = c['P'], c['D']
     da, dc, dd = _descs(c)
     mean, std = (c['mean'], c['std']) if rms else (None, None)
     ws = ops.nets_ws(da, dc, None, c['B'])
@@ -53,11 +54,12 @@ def test_targ_q_and_act(name, rms):
 
 
 @pytest.mark.parametrize('per', [True, False])
+@pytest.mark.parametrize('ln', [False, True])
 @pytest.mark.parametrize('name', ALL)
-def test_critic_grad(name, per):
+def test_critic_grad(name, per, ln):
     from sam_tf_amd import ops
     from oracle import nets_oracle as NO
-    c = make_case(name); P, D = c['P'], c['D']
+    c = make_case(name, ln=ln); P, D = c['P'], c['D']
     da, dc, dd = _descs(c)
     tc = (D['rews'] * 0.7 - 0.5).astype(np.float32)  # mixes |td| < 1 and > 1 (both huber branches)
     iws = D['iws'] if per else None
@@ -77,11 +79,12 @@ def test_critic_grad(name, per):
 
 
 @pytest.mark.parametrize('d_scale', [0.0, 0.5])
+@pytest.mark.parametrize('ln', [False, True])
 @pytest.mark.parametrize('name', ALL)
-def test_actor_grad(name, d_scale):
+def test_actor_grad(name, d_scale, ln):
     from sam_tf_amd import ops
     from oracle import nets_oracle as NO
-    c = make_case(name); P, D = c['P'], c['D']
+    c = make_case(name, ln=ln); P, D = c['P'], c['D']
     da, dc, dd = _descs(c)
     el, eg = NO.actor_loss_grad(P['pa'], c['da'], P['pc'], c['dc'], P['pd'] if d_scale else None,
                                 c['dd'], D['obs0'], c['mean'], c['std'], 0.4, 1.0, d_scale)
@@ -93,11 +96,12 @@ def test_actor_grad(name, d_scale):
 
 
 @pytest.mark.parametrize('ent', [0.0, 1e-3])
+@pytest.mark.parametrize('ln', [False, True])
 @pytest.mark.parametrize('name', ALL)
-def test_disc_grad_and_reward(name, ent):
+def test_disc_grad_and_reward(name, ent, ln):
     from sam_tf_amd import ops
     from oracle import nets_oracle as NO
-    c = make_case(name); P, D = c['P'], c['D']
+    c = make_case(name, ln=ln); P, D = c['P'], c['D']
     da, dc, dd = _descs(c)
     el, eg = NO.disc_loss_grad(P['pd'], c['dd'], D['obs0'], D['acs'], D['e_obs'], D['e_acs'], D['eps_ob'],
                                D['eps_ac'], D['real'], D['fake'], c['mean'], c['std'], ent_reg_scale=ent)

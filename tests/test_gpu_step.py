@@ -18,9 +18,9 @@ def _dev(x):
     return None if x is None else torch.as_tensor(np.ascontiguousarray(x)).cuda()
 
 
-def _setup(name, d_scale, ent, per, rms=True):
+def _setup(name, d_scale, ent, per, rms=True, ln=False):
     from sam_tf_amd import ops
-    c = make_case(name); P, D = c['P'], c['D']
+    c = make_case(name, ln=ln); P, D = c['P'], c['D']
     mk = lambda d: ops.mlp_desc(d.in_dim, d.h1, d.h2, d.out_dim, d.layernorm)
     hp = dict(HP, d_actor_loss_scale=d_scale, ent_reg_scale=ent)
     L = ops.LearnerState(mk(c['da']), mk(c['dc']), mk(c['dd']), c['ob'], c['ac'], hp)
@@ -59,15 +59,19 @@ def _oracle(c, d_scale, ent, per, rms=True):
                 grads=np.concatenate([ag, cg, dg]))
 
 
-@pytest.mark.parametrize('name,d_scale,ent,per,rms', [
-    ('C1', 0.0, 0.0, False, True), ('C2', 0.0, 0.0, False, True), ('C3', 0.0, 0.0, True, True),
-    ('C3', 0.5, 1e-3, True, True), ('C2', 0.5, 0.0, False, False),
-    ('ragged', 0.5, 0.0, True, True),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
-    ('C4', 0.0, 0.0, False, True)])
-def test_step_grads_vs_oracle(name, d_scale, ent, per, rms):
+@pytest.mark.parametrize('name,d_scale,ent,per,rms,ln', [
+    ('C1', 0.0, 0.0, False, True, False), ('C2', 0.0, 0.0, False, True, False),
+    ('C3', 0.0, 0.0, True, True, False), ('C3', 0.5, 1e-3, True, True, False),
+    ('C2', 0.5, 0.0, False, False, False),
+    ('ragged', 0.5, 0.0, True, True, False),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
+    ('C4', 0.0, 0.0, False, True, False),
+    # with_layernorm (launcher default, mujoco_sam_imitate.sh): layer-wise path, two-stream GP backward
+    ('C2', 0.5, 1e-3, True, True, True), ('ragged', 0.5, 0.0, False, True, True),
+    ('C4', 0.0, 0.0, False, True, True)])
+def test_step_grads_vs_oracle(name, d_scale, ent, per, rms, ln):
     from sam_tf_amd import ops
-    c, L, batch, out = _setup(name, d_scale, ent, per, rms)
-    assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3'))
+    c, L, batch, out = _setup(name, d_scale, ent, per, rms, ln)
+    assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3') and not ln)
     exp = _oracle(c, d_scale, ent, per, rms)
     ops.step_grads(L, batch, out)
     torch.cuda.synchronize()
