@@ -16,8 +16,9 @@ pytestmark = pytest.mark.gpu
 class OracleLearner(object):
     """fp64 mirror of sam_tf_amd.driver.UpdateStepDriver.step() built from oracle/ only."""
 
-    def __init__(self, mu, d, pool, per):
+    def __init__(self, mu, d, pool, per, world=1):
         from oracle import nets_oracle as NO
+        self.world = world
         from oracle.replay_oracle import PrioritizedReplayOracle
         self.NO = NO
         h1, h2 = mu.hps.hid_widths
@@ -61,7 +62,8 @@ class OracleLearner(object):
         NO, hp = self.NO, self.hps
         ob = self.da.in_dim
         p = self.rows(idx_p)
-        self.rms_d = NO.rms_update(self.rms_d, np.concatenate((p['obs0'], e_obs)), ob)
+        for _ in range(self.world):  # every rank contributes its rows (here: identical replicas)
+            self.rms_d = NO.rms_update(self.rms_d, np.concatenate((p['obs0'], e_obs)), ob)
         mean, std = NO.rms_mean_std(self.rms_d, ob)
         dl, g = NO.disc_loss_grad(self.pd, self.dc, p['obs0'], p['acs'], e_obs, e_acs, eps_ob, eps_ac,
                                   real, np.zeros(len(real)), mean, std)
@@ -253,3 +255,61 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
                       [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer])])
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+class _TwinComm(object):
+    """A 2-rank communicator whose other rank is an identical twin of this process: SUM all-reduce
+    doubles, broadcast is the identity.  Drives the N > 1 plan of the driver (three graph segments
+    around two collectives, local clip copies, 1/N inside the optimiser pass) on one GPU."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 2
+
+    def Barrier(self):
+        pass
+
+    def allreduce_(self, t):
+        return t.mul_(2)
+
+    def bcast_(self, t, root=0):
+        return t
+
+    def Allreduce(self, sendbuf, recvbuf, op='sum'):
+        recvbuf[...] = 2 * np.asarray(sendbuf)
+
+    def Bcast(self, buf, root=0):
+        pass
+
+
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'ragged'])
+def test_two_rank_plan_matches_oracle(cfg_name):
+    import bench
+    if cfg_name == 'ragged':  # not fusable: the layer-wise path under the N > 1 plan
+        cfg = dict(ob=5, ac=2, h=(33, 70), B=37, per=False, mem=2048, name='ragged')
+    else:
+        cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+    mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
+    assert drv.world == 2 and drv.K == 1 and not drv.inline_stats
+    drv.prepare()
+    ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
+    K = 4
+    for k in range(K):
+        drv.step()
+        torch.cuda.synchronize()
+        h = lambda t: t.cpu().numpy()
+        e0 = int(drv.e_start.item())
+        eps_ob, eps_ac, real, _ = drv.step_randoms(k)
+        out = ref.step(h(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
+                       h(eps_ac), h(real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
+        o = drv.outputs()
+        for name in ('d_losses', 'actor_losses', 'critic_losses'):
+            got, exp = h(o[name]).astype(np.float64), out[name]
+            assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-5, (name, k, got, exp)
+    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
+    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
+    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
+    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
