@@ -179,13 +179,23 @@ def critic_q(Pc, x, ac, d):
     return mlp(Pc, torch.cat([x, ac], dim=-1), d)  # ac_branch_in = 1
 
 
+def _derms(x, ret):
+    """math_util.py:15-19 with the scalar return statistics; ret = (mean, std) or None (rmsify_rets off)."""
+    return x if ret is None else x * float(ret[1]) + float(ret[0])
+
+
+def _rms(x, ret):
+    """math_util.py:8-12 (sam_agent.py:161-172: tc1z / tcnz)."""
+    return x if ret is None else (x - float(ret[0])) / float(ret[1])
+
+
 def targ_q(pa_t, pc_t, da, dc, obs1, rews, dones1, td_len, mean, std, gamma, high,
-           dtype=torch.float64, rmsify=True):
-    """sam_agent.py:196-205 (no return normalisation)."""
+           dtype=torch.float64, rmsify=True, ret=None):
+    """sam_agent.py:196-205; ret = (ret_mean, ret_std) de-normalises Q' (lines 199-201)."""
     _, Pa = _params(pa_t, da, dtype)
     _, Pc = _params(pc_t, dc, dtype)
     x1 = obz(_t(obs1, dtype), _t(mean, dtype), _t(std, dtype), rmsify)
-    qp = critic_q(Pc, x1, actor_act(Pa, x1, da, high), dc)
+    qp = _derms(critic_q(Pc, x1, actor_act(Pa, x1, da, high), dc), ret)
     r, dn, tl = _t(rews, dtype), _t(dones1, dtype), _t(td_len, dtype)
     g = torch.pow(torch.tensor(gamma, dtype=dtype), tl)
     return (r + g * (1.0 - dn) * qp).detach().numpy()
@@ -201,41 +211,59 @@ def clip_by_global_norm(g, clip_norm):
 
 
 def critic_loss_grad(pc, dc, obs0, acs, iws, tc1s, mean, std, wd_scale, td_scale=1.0,
-                     dtype=torch.float64, rmsify=True, need_grad=True):
+                     dtype=torch.float64, rmsify=True, need_grad=True, ret=None, tcns=None,
+                     tdn_scale=1.0):
     """sam_agent.py:457-520.  iws None <=> uniform replay.  Returns losses
-    [td_loss_1, wd, total], flat grad (unclipped), td_errors [B,1]."""
+    [td_loss_1, wd, total] (+ [td_loss_n] appended when tcns is given), flat grad (unclipped),
+    td_errors [B,1] (1-step).  ret = (ret_mean, ret_std): critic_pred is DE-normalised (lines 180-182)
+    while the targets are normalised (lines 161-172) — the reference's mixed-scale TD error."""
     f, Pc = _params(pc, dc, dtype, grad=True)
     x0 = obz(_t(obs0, dtype), _t(mean, dtype), _t(std, dtype), rmsify)
-    q = critic_q(Pc, x0, _t(acs, dtype), dc)
-    td = q - _t(tc1s, dtype)
+    q = _derms(critic_q(Pc, x0, _t(acs, dtype), dc), ret)
+    td = q - _rms(_t(tc1s, dtype), ret)
     h = huber(td)
     if iws is not None:
         h = h * _t(iws, dtype)
     td_loss = h.mean() * td_scale
     wd = wd_scale * 0.5 * ((Pc['W1'] ** 2).sum() + (Pc['W2'] ** 2).sum())
     loss = td_loss + wd
+    out = [td_loss, wd]
+    if tcns is not None:  # lines 483-498
+        hn = huber(q - _rms(_t(tcns, dtype), ret))
+        if iws is not None:
+            hn = hn * _t(iws, dtype)
+        tdn_loss = hn.mean() * tdn_scale
+        loss = loss + tdn_loss
     g = torch.autograd.grad(loss, f)[0].numpy() if need_grad else None
-    return (np.array([td_loss.item(), wd.item(), loss.item()]), g, td.detach().numpy())
+    losses = [td_loss.item(), wd.item(), loss.item()] + ([tdn_loss.item()] if tcns is not None else [])
+    return (np.array(losses), g, td.detach().numpy())
 
 
-def td_errors(pc, dc, obs0, acs, tc1s, mean, std, dtype=torch.float64, rmsify=True):
+def td_errors(pc, dc, obs0, acs, tc1s, mean, std, dtype=torch.float64, rmsify=True, ret=None):
     _, Pc = _params(pc, dc, dtype)
     x0 = obz(_t(obs0, dtype), _t(mean, dtype), _t(std, dtype), rmsify)
-    return (critic_q(Pc, x0, _t(acs, dtype), dc) - _t(tc1s, dtype)).detach().numpy()
+    return (_derms(critic_q(Pc, x0, _t(acs, dtype), dc), ret) - _rms(_t(tc1s, dtype), ret)).detach().numpy()
+
+
+def popart(w3, b3, old_mean, old_std, new_mean, new_std):
+    """sam_agent.py:554-590: rescale of an output layer (w [h2,1], b [1]) when the return statistics
+    move from (old_mean, old_std) to (new_mean, new_std)."""
+    w3, b3 = np.asarray(w3, dtype=np.float64), np.asarray(b3, dtype=np.float64)
+    return w3 * old_std / new_std, (b3 * old_std + old_mean - new_mean) / new_std
 
 
 def actor_loss_grad(pa, da, pc, dc, pd, dd, obs0, mean, std, high, q_scale, d_scale,
-                    dtype=torch.float64, rmsify=True, need_grad=True):
+                    dtype=torch.float64, rmsify=True, need_grad=True, ret=None):
     """sam_agent.py:406-433.  pd/dd: the reward net the agent graph evaluates (may be None when
     d_scale == 0).  Returns losses [q_loss, d_loss, total], flat grad wrt actor (unclipped)."""
     f, Pa = _params(pa, da, dtype, grad=True)
     _, Pc = _params(pc, dc, dtype)
     x0 = obz(_t(obs0, dtype), _t(mean, dtype), _t(std, dtype), rmsify)
     a = actor_act(Pa, x0, da, high)
-    q_loss = -critic_q(Pc, x0, a, dc).mean() * q_scale
+    q_loss = -_derms(critic_q(Pc, x0, a, dc), ret).mean() * q_scale  # sam_agent.py:184-187
     if pd is not None:
         _, Pd = _params(pd, dd, dtype)
-        d_loss = -critic_q(Pd, x0, a, dd).mean() * d_scale
+        d_loss = -_derms(critic_q(Pd, x0, a, dd), ret).mean() * d_scale  # sam_agent.py:191-194
     else:
         d_loss = torch.zeros((), dtype=dtype)
     loss = q_loss + d_loss
@@ -243,13 +271,13 @@ def actor_loss_grad(pa, da, pc, dc, pd, dd, obs0, mean, std, high, q_scale, d_sc
     return np.array([q_loss.item(), d_loss.item(), loss.item()]), g
 
 
-def act_q(pa, da, pc, dc, obs, mean, std, high, dtype=torch.float64, rmsify=True):
+def act_q(pa, da, pc, dc, obs, mean, std, high, dtype=torch.float64, rmsify=True, ret=None):
     """sam_agent.py:209-212: (actor_pred, critic_pred_w_actor)."""
     _, Pa = _params(pa, da, dtype)
     _, Pc = _params(pc, dc, dtype)
     x0 = obz(_t(obs, dtype), _t(mean, dtype), _t(std, dtype), rmsify)
     a = actor_act(Pa, x0, da, high)
-    return a.detach().numpy(), critic_q(Pc, x0, a, dc).detach().numpy()
+    return a.detach().numpy(), _derms(critic_q(Pc, x0, a, dc), ret).detach().numpy()
 
 
 def sigmoid_ce(x, z):

@@ -185,6 +185,36 @@ class ReplayOracle(object):
             idxs = np.random.randint(low=0, high=self.num_entries, size=batch_size)
         return self.batchify(idxs)
 
+    def lookahead(self, idxs, n, gamma):
+        """n-step TD lookahead from every sampled transition (memory.py:113-160).  Per index: the
+        window [idx, min(idx+n, num_entries)-1] of LOGICAL indices, cut after the first done1 == 1
+        inside it; rews = discounted sum over the kept rewards, accumulated in float64 from the far
+        end (math_util.py:32-43: scipy lfilter on the reversed array = y[t] = x[t] + gamma*y[t+1]);
+        obs1 of the last kept row; dones1 = 1 only when the cut happened BEFORE the window's end
+        (a done exactly at the window's end yields 0 — the reference's quirk); td_len = rows kept."""
+        idxs = np.asarray(idxs)
+        out = {k: [] for k in ('obs0', 'acs', 'rews', 'dones1', 'obs1', 'td_len', 'end_idx')}
+        for idx in idxs:
+            idx = int(idx)
+            end = min(idx + n, self.num_entries) - 1
+            win = np.arange(idx, end + 1)
+            dones = self.rings['dones1'].rows(win).ravel()
+            hit = np.nonzero(dones == 1.0)[0]
+            ep_end = idx + int(hit[0]) if hit.size else end
+            td_len = ep_end - idx + 1
+            rews = self.rings['rews'].rows(win).ravel()[:td_len]
+            acc = 0.0
+            for r in rews[::-1]:
+                acc = float(r) + gamma * acc
+            out['obs0'].append(self.rings['obs0'].rows(np.array([idx]))[0])
+            out['acs'].append(self.rings['acs'].rows(np.array([idx]))[0])
+            out['obs1'].append(self.rings['obs1'].rows(np.array([ep_end]))[0])
+            out['rews'].append(acc)
+            out['dones1'].append(0.0 if ep_end == end else 1.0)
+            out['td_len'].append(td_len)
+            out['end_idx'].append(ep_end)
+        return {k: _min2d(v) for k, v in out.items()}
+
     def recent_window(self, window):
         """Logical indices of the ``window`` newest entries, oldest first (memory.py:99-106)."""
         width = min(window, self.num_entries)

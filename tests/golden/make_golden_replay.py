@@ -151,7 +151,31 @@ def gen_rb(limit, ob, ac, seed, n_app, B, window):
     return out
 
 
+def gen_nstep(limit, ob, ac, seed, n_app, n, gamma, p_done):
+    """RB.lookahead (memory.py:113-160) on a ring with episode ends sprinkled in: the sampled logical
+    indices (every index, so all edge cases occur: done inside / exactly at the end of the window,
+    window cut by num_entries, ring wrapped when n_app > limit)."""
+    rs = np.random.RandomState(seed)
+    rb = M.RB(limit, (ob,), (ac,))
+    tr = dict(obs0=rs.randn(n_app, ob).astype(np.float32), acs=rs.randn(n_app, ac).astype(np.float32),
+              rews=rs.rand(n_app).astype(np.float32) * 5, obs1=rs.randn(n_app, ob).astype(np.float32),
+              dones1=(rs.rand(n_app) < p_done).astype(np.float32))
+    for i in range(n_app):
+        rb.append(tr['obs0'][i], tr['acs'][i], tr['rews'][i], tr['obs1'][i], tr['dones1'][i])
+    idxs = np.arange(rb.num_entries)
+    la = rb.lookahead(transitions={'idxs': idxs}, n=n, gamma=gamma)
+    out = {'in_' + k: v for k, v in tr.items()}
+    out.update(limit=limit, ob=ob, ac=ac, n=n, gamma=gamma, idxs=idxs, start=rb.ring_buffers['obs0'].start,
+               length=rb.ring_buffers['obs0'].length)
+    for k in ('obs0', 'obs1', 'acs', 'rews', 'dones1', 'td_len'):
+        out['la_' + k] = np.asarray(la[k])
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, 'replay_nstep_a.npz'), **gen_nstep(64, 3, 2, 31, 50, 5, 0.99, 0.15))
+    np.savez_compressed(os.path.join(HERE, 'replay_nstep_wrap.npz'),
+                        **gen_nstep(48, 3, 2, 32, 110, 7, 0.97, 0.1))
     np.savez_compressed(os.path.join(HERE, 'replay_tree_cap16.npz'), **gen_tree_ops(16, 1, 40, 24))
     np.savez_compressed(os.path.join(HERE, 'replay_tree_cap1024.npz'),
                         **gen_tree_ops(1024, 2, 1500, 64))

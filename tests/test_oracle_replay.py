@@ -132,3 +132,20 @@ def test_c_oracle_matches_python():
             assert ct.min(a, b) == py.min_tree.reduce(a, b)
     assert np.array_equal(ct.sumv, py.sum_tree.v)
     assert np.array_equal(ct.minv, py.min_tree.v)
+
+
+@pytest.mark.parametrize('name', ['replay_nstep_a', 'replay_nstep_wrap'])
+def test_nstep_lookahead_matches_reference(golden_dir, name):
+    """RB.lookahead (memory.py:113-160) recorded from the reference: discounted n-step reward (float64
+    Horner from the far end), episode trimming, the done-at-window-end quirk, ring wrap-around."""
+    from oracle.replay_oracle import ReplayOracle
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    rb = ReplayOracle(int(g['limit']), (int(g['ob']),), (int(g['ac']),))
+    for i in range(len(g['in_rews'])):
+        rb.append(g['in_obs0'][i], g['in_acs'][i], g['in_rews'][i], g['in_obs1'][i], g['in_dones1'][i])
+    assert rb.rings['obs0'].start == int(g['start']) and rb.num_entries == int(g['length'])
+    la = rb.lookahead(g['idxs'], int(g['n']), float(g['gamma']))
+    for k in ('obs0', 'obs1', 'acs', 'dones1', 'td_len'):
+        assert np.array_equal(np.asarray(la[k], dtype=np.float64), np.asarray(g['la_' + k], dtype=np.float64)), k
+    assert np.array_equal(la['rews'], g['la_rews'])   # float64, bit for bit
+    assert (g['la_dones1'] == 1).any() and (g['la_td_len'] < int(g['n'])).any()
