@@ -94,6 +94,17 @@ int samx_replay_gather(const float* obs0, const float* acs, const float* rews, c
                        const int64_t* idxs, int64_t B, float* o_obs0, float* o_acs, float* o_rews,
                        float* o_dones1, float* o_obs1, void* stream);
 
+/* RB.lookahead (memory.py:113-160): n-step TD lookahead from B sampled LOGICAL indices.  Per index the
+ * window [idx, min(idx+n, num_entries)-1] is cut after the first dones1 == 1; rews_out = discounted
+ * sum of the kept rewards accumulated in float64 from the far end (helpers/math_util.py:32-43), then
+ * rounded to float32 as the TF placeholder does (rews64_out, may be NULL, keeps the float64);
+ * end_idx_out = logical index of the last kept row (whose obs1 is the n-step next observation);
+ * dones_out = 1 only if the cut came before the window's end; td_len_out = rows kept. */
+int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen, int64_t start,
+                         int64_t num_entries, const int64_t* idxs, int64_t B, int n, double gamma,
+                         int64_t* end_idx_out, float* rews_out, double* rews64_out, float* dones_out,
+                         float* td_len_out, void* stream);
+
 /* RingBuffer.append of one staged transition (memory.py:36-57,177-184): `row` is the physical
  * slot the host ring arithmetic chose; packed = [obs0(ob) | acs(ac) | rew | obs1(ob) | done]. */
 int samx_replay_write(float* obs0, float* acs, float* rews, float* dones1, float* obs1,
@@ -144,6 +155,15 @@ int samx_count_mismatch(const float* a, const float* b, int64_t n, int32_t* mism
  * (sam_agent.py:150-159).  Observations are normalised and clipped to [-5, 5] inside.
  * Calls that take only a critic-shaped network get `ob_dim` (the action width is in_dim - ob_dim). */
 
+/* Return normalisation (rmsify_rets, sam_agent.py:161-201 ; helpers/math_util.py:8-19): device scalars
+ * ret_rms.mean / ret_rms.std (float[1] each).  Every call below takes `ret` (NULL = off): critic
+ * outputs are DE-normalised (q * std + mean, lines 180-201), critic targets are normalised
+ * ((t - mean) / std, lines 161-172) — including the reference's mixed-scale TD error. */
+typedef struct samx_retnorm {
+    const float* mean;
+    const float* std;
+} samx_retnorm;
+
 /* Scratch bytes that cover every agent-side call below for batch B (reward_net may be NULL). */
 size_t samx_nets_ws_bytes(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward_net,
                           int64_t B);
@@ -153,30 +173,33 @@ size_t samx_nets_ws_bytes(const samx_mlp* actor, const samx_mlp* critic, const s
 int samx_act_q(const samx_mlp* actor, const float* actor_params, const samx_mlp* critic,
                const float* critic_params, const float* obs, const float* ob_mean,
                const float* ob_std, int64_t B, float ac_high, float* ac_out, float* q_out,
-               void* ws, size_t ws_bytes, void* stream);
+               const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream);
 
 /* get_targ_q (sam_agent.py:196-205,225-226): rews + gamma^td_len * (1-dones1) * Q'(obz1, mu'(obz1)).
  * td_len NULL means 1 for every row (sam_agent.py:648-654). out float[B]. */
 int samx_targ_q(const samx_mlp* actor, const float* targ_actor_params, const samx_mlp* critic,
                 const float* targ_critic_params, const float* obs1, const float* rews,
                 const float* dones1, const float* td_len, const float* ob_mean,
-                const float* ob_std, int64_t B, float gamma, float ac_high, float* out, void* ws,
-                size_t ws_bytes, void* stream);
+                const float* ob_std, int64_t B, float gamma, float ac_high, float* out,
+                const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream);
 
 /* setup_critic (sam_agent.py:457-520): td = Q(obz0, acs) - tc1s ; loss = mean(huber(td) * iws) *
  * td_scale + wd_scale * (|W1|^2 + |W2|^2)/2.  iws NULL for uniform replay.
- * losses_out float[3] = {critic_td_loss_1, critic_wd, critic_total_loss}; grad_out float[P] the
- * unclipped flat gradient; td_out float[B] or NULL. */
+ * tcns != NULL adds the n-step term mean(huber(Q - tcns) * iws) * tdn_scale (lines 483-498).
+ * losses_out float[4] = {critic_td_loss_1, critic_wd, critic_total_loss, critic_td_loss_n (0 without
+ * tcns)}; grad_out float[P] the unclipped flat gradient; td_out / tdn_out float[B] or NULL. */
 int samx_critic_grad(const samx_mlp* critic, const float* critic_params, const float* obs0,
                      const float* acs, const float* iws, const float* tc1s, const float* ob_mean,
                      const float* ob_std, int64_t B, int ob_dim, float td_scale, float wd_scale,
-                     float* losses_out, float* grad_out, float* td_out, void* ws, size_t ws_bytes,
+                     float* losses_out, float* grad_out, float* td_out, const samx_retnorm* ret,
+                     const float* tcns, float tdn_scale, float* tdn_out, void* ws, size_t ws_bytes,
                      void* stream);
 
 /* critic_ops['td_errors'] (sam_agent.py:534-538,693-701): Q(obz0, acs) - tc1s, float[B]. */
 int samx_td_errors(const samx_mlp* critic, const float* critic_params, const float* obs0,
                    const float* acs, const float* tc1s, const float* ob_mean, const float* ob_std,
-                   int64_t B, int ob_dim, float* td_out, void* ws, size_t ws_bytes, void* stream);
+                   int64_t B, int ob_dim, float* td_out, const samx_retnorm* ret, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* setup_actor (sam_agent.py:406-433): loss = -q_scale*mean Q(obz0, mu(obz0))
  *                                           -d_scale*mean D(obz0, mu(obz0)), gradient wrt the actor only.
@@ -186,7 +209,18 @@ int samx_actor_grad(const samx_mlp* actor, const float* actor_params, const samx
                     const float* critic_params, const samx_mlp* reward_net,
                     const float* reward_params, const float* obs0, const float* ob_mean,
                     const float* ob_std, int64_t B, float ac_high, float q_scale, float d_scale,
-                    float* losses_out, float* grad_out, void* ws, size_t ws_bytes, void* stream);
+                    float* losses_out, float* grad_out, const samx_retnorm* ret, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ret_rms.update + PopArt (sam_agent.py:554-590,662-672 ; helpers/mpi_running_mean_std.py:40-45).
+ * addvec1 (and addvec2, may be NULL: the n-step targets) are float64 [sum, sumsq, count] of a batch of
+ * targets from samx_rms_batch_sums (dim 1), already all-reduced.  In one launch: remember the old
+ * mean/std, sums += addvec*, refresh ret_mean / ret_std, and with enable_popart rescale the output
+ * layer of the online and the target critic: w <- w*old_std/new_std,
+ * b <- (b*old_std + old_mean - new_mean)/new_std. */
+int samx_ret_update_popart(double* sums, const double* addvec1, const double* addvec2, float* ret_mean,
+                           float* ret_std, int enable_popart, const samx_mlp* critic,
+                           float* critic_params, float* targ_critic_params, void* stream);
 
 /* Discriminator losses + gradient (imitation_algorithms/discriminator.py:77-161): BCE(policy,
  * fake) + BCE(expert, real) - ent_reg_scale*mean entropy + 10 * gradient penalty on the

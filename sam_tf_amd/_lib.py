@@ -52,7 +52,12 @@ class StepOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('d_losses', 'actor_losses', 'critic_losses', 'targ_q', 'td')]
 
 
-_LP, _BP, _OP = C.POINTER(Learner), C.POINTER(Batch), C.POINTER(StepOut)
+class RetNorm(C.Structure):
+    """Mirror of `struct samx_retnorm`."""
+    _fields_ = [('mean', C.c_void_p), ('std', C.c_void_p)]
+
+
+_LP, _BP, _OP, _RP = C.POINTER(Learner), C.POINTER(Batch), C.POINTER(StepOut), C.POINTER(RetNorm)
 
 # name -> (restype, argtypes); must list every symbol include/samx.h declares
 SIGNATURES = {
@@ -77,14 +82,17 @@ SIGNATURES = {
     'samx_clip_copy': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
     'samx_count_mismatch': (C.c_int, [_P, _P, _I64, _P, _P]),
     'samx_nets_ws_bytes': (_SZ, [_MP, _MP, _MP, _I64]),
-    'samx_act_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
-    'samx_targ_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _P, _P, _SZ,
+    'samx_act_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _P, _P, _RP, _P, _SZ, _P]),
+    'samx_targ_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _P, _RP, _P, _SZ,
                               _P]),
     'samx_critic_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _F, _F, _P, _P,
-                                   _P, _P, _SZ, _P]),
-    'samx_td_errors': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _P, _P, _SZ, _P]),
+                                   _P, _RP, _P, _F, _P, _P, _SZ, _P]),
+    'samx_td_errors': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _P, _RP, _P, _SZ, _P]),
     'samx_actor_grad': (C.c_int, [_MP, _P, _MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _F, _F, _P, _P,
-                                  _P, _SZ, _P]),
+                                  _RP, _P, _SZ, _P]),
+    'samx_ret_update_popart': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _MP, _P, _P, _P]),
+    'samx_nstep_lookahead': (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, C.c_int, _D, _P, _P, _P, _P,
+                                       _P, _P]),
     'samx_disc_ws_bytes': (_SZ, [_MP, _I64]),
     'samx_disc_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int,
                                  _F, _P, _P, _P, _SZ, _P]),

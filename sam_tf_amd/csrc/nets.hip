@@ -128,6 +128,15 @@ struct HeadArgs {
     float* out3 = nullptr;       // sigmoid
     float* DZ2 = nullptr;        // [M, h2]: dq * w3 * lrelu'(H2), or (ln) the cotangent of the LayerNorm output dq * w3
     int ln = 0;
+    // return normalisation (sam_agent.py:161-201): device scalars, null = off.  The critic output is
+    // DE-normalised (s * std + mean), targets are normalised ((t - mean) / std).
+    const float* ret_mean = nullptr;
+    const float* ret_std = nullptr;
+    // n-step term of the critic loss (sam_agent.py:483-498)
+    const float* rn = nullptr;   // tcns
+    float cn = 0.f;              // td_loss_n_scale / B
+    float* out4 = nullptr;       // row loss of the n-step term
+    float* out5 = nullptr;       // n-step td error
 };
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -150,8 +159,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     const float* h = a.H2 + row * a.h2;
     float acc = 0.f;
     for (int c = lane; c < a.h2; c += 64) acc = fmaf(h[c], a.w3[c], acc);
-    const float s = wave_sum(acc) + a.b3[0];
+    float s = wave_sum(acc) + a.b3[0];
     float dq = 0.f;
+    const bool rn_on = a.ret_mean != nullptr;
+    const float rmean = rn_on ? a.ret_mean[0] : 0.f, rstd = rn_on ? a.ret_std[0] : 1.f;
+    if (MODE == HEAD_Q || MODE == HEAD_TARG || MODE == HEAD_TD || MODE == HEAD_CRITIC || MODE == HEAD_ACTOR_Q) {
+        if (rn_on) s = s * rstd + rmean;  // dermsify (math_util.py:15-19)
+    }
     if (MODE == HEAD_Q) {
         if (lane == 0) a.out0[row] = s;
         return;
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         return;
     }
     if (MODE == HEAD_TD) {
-        if (lane == 0) a.out0[row] = s - a.r0[row];
+        if (lane == 0) a.out0[row] = s - (rn_on ? (a.r0[row] - rmean) / rstd : a.r0[row]);
         return;
     }
     if (MODE == HEAD_REWARD) {
@@ -177,20 +191,30 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         return;
     }
     if (MODE == HEAD_CRITIC) {
-        const float td = s - a.r0[row];
+        const float td = s - (rn_on ? (a.r0[row] - rmean) / rstd : a.r0[row]);
         const float iw = a.r1 ? a.r1[row] : 1.f;
         const float ad = fabsf(td);
         const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;      // math_util.py:22-29
         const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
         dq = a.c0 * dh * iw;                                          // c0 = td_scale / B
+        float hubn = 0.f, tdn = 0.f;
+        if (a.rn) {  // n-step term on the same prediction
+            tdn = s - (rn_on ? (a.rn[row] - rmean) / rstd : a.rn[row]);
+            const float adn = fabsf(tdn);
+            hubn = adn < 1.f ? 0.5f * tdn * tdn : adn - 0.5f;
+            dq += a.cn * (adn < 1.f ? tdn : (tdn > 0.f ? 1.f : -1.f)) * iw;
+        }
+        dq *= rstd;  // d(dermsified prediction) / d(network output)
         if (lane == 0) {
             a.out0[row] = hub * iw;
             if (a.out1) a.out1[row] = td;
             a.out2[row] = dq;
+            if (a.out4) a.out4[row] = hubn * iw;
+            if (a.out5) a.out5[row] = tdn;
         }
     }
     if (MODE == HEAD_ACTOR_Q) {
-        dq = a.c0;  // -scale / B
+        dq = a.c0 * rstd;  // -scale / B, through the dermsify
         if (lane == 0) a.out0[row] = s;
     }
     if (MODE == HEAD_DISC) {
@@ -401,9 +425,11 @@ __global__ __launch_bounds__(256) void wd_sumsq_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void critic_losses_kernel(const float* rowloss, int64_t B,
                                                              float td_scale, float wd_scale,
                                                              const double* wd_part, int n_part,
-                                                             float* losses) {
+                                                             float* losses, const float* rowloss_n,
+                                                             float tdn_scale) {
     __shared__ double sh[16];
     const double l = sum_f32(rowloss, B, sh) / (double)B * td_scale;
+    const double ln_ = rowloss_n ? sum_f32(rowloss_n, B, sh) / (double)B * tdn_scale : 0.0;
     if (threadIdx.x == 0) {
         double wd = 0.0;
         if (wd_scale > 0.f) {
@@ -412,7 +438,46 @@ __global__ __launch_bounds__(1024) void critic_losses_kernel(const float* rowlos
         }
         losses[0] = (float)l;
         losses[1] = (float)wd;
-        losses[2] = (float)(l + wd);
+        losses[2] = (float)(l + ln_ + wd);
+        losses[3] = (float)ln_;
+    }
+}
+
+// PopArt (sam_agent.py:554-590,662-672) with the return-statistics update that precedes it:
+//   old = (mean, std) ; sums += addvec1 (+ addvec2) (mpi_running_mean_std.py:40-45) ; new = stats(sums) ;
+//   for the online and the target critic:  w3 <- w3 * old_std / new_std ;
+//                                          b3 <- (b3 * old_std + old_mean - new_mean) / new_std
+// One workgroup.  addvec: float64 [sum, sumsq, count] of a batch of targets (after the all-reduce).
+__global__ __launch_bounds__(256) void popart_kernel(double* sums, const double* addvec1, const double* addvec2,
+                                                     float* mean, float* stdv, int popart, float* w3a,
+                                                     float* b3a, float* w3b, float* b3b, int h2) {
+    __shared__ float sh[4];
+    if (threadIdx.x == 0) {
+        sh[0] = mean[0];
+        sh[1] = stdv[0];
+        double s0 = sums[0], s1 = sums[1], s2 = sums[2];
+        s0 = __dadd_rn(s0, addvec1[0]); s1 = __dadd_rn(s1, addvec1[1]); s2 = __dadd_rn(s2, addvec1[2]);
+        if (addvec2) {
+            s0 = __dadd_rn(s0, addvec2[0]); s1 = __dadd_rn(s1, addvec2[1]); s2 = __dadd_rn(s2, addvec2[2]);
+        }
+        sums[0] = s0; sums[1] = s1; sums[2] = s2;
+        const float m = (float)(s0 / s2), msq = (float)(s1 / s2);
+        const float sd = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(m, m)), 1e-2f));
+        mean[0] = m;
+        stdv[0] = sd;
+        sh[2] = m;
+        sh[3] = sd;
+    }
+    __syncthreads();
+    if (!popart) return;
+    const float om = sh[0], os = sh[1], nm = sh[2], ns = sh[3];
+    for (int c = threadIdx.x; c < h2; c += 256) {
+        w3a[c] = __fdiv_rn(__fmul_rn(w3a[c], os), ns);
+        w3b[c] = __fdiv_rn(__fmul_rn(w3b[c], os), ns);
+    }
+    if (threadIdx.x == 0) {
+        b3a[0] = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(b3a[0], os), om), nm), ns);
+        b3b[0] = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(b3b[0], os), om), nm), ns);
     }
 }
 
@@ -732,6 +797,10 @@ AgentWs carve_agent(Arena& ar, const samx_mlp* da, const samx_mlp* dc, const sam
     return w;
 }
 
+void set_ret(HeadArgs& h, const samx_retnorm* ret) {
+    if (ret && ret->mean) { h.ret_mean = ret->mean; h.ret_std = ret->std; }
+}
+
 HeadArgs head_of(const Net& c, const Hid& h, int64_t M) {
     HeadArgs a;
     a.H2 = h.N2; a.w3 = c.W3; a.b3 = c.b3; a.M = M; a.h2 = c.h2; a.ln = c.ln;
@@ -755,7 +824,8 @@ size_t samx_nets_ws_bytes(const samx_mlp* actor, const samx_mlp* critic, const s
 
 int samx_act_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
                const float* obs, const float* mean, const float* stdv, int64_t B, float high,
-               float* ac_out, float* q_out, void* ws, size_t ws_bytes, void* stream) {
+               float* ac_out, float* q_out, const samx_retnorm* ret, void* ws, size_t ws_bytes,
+               void* stream) {
     TRY(check_desc(da, "samx_act_q(actor)"));
     TRY(check_desc(dc, "samx_act_q(critic)"));
     SAMX_REQUIRE(pa && pc && obs && ac_out && ws, "samx_act_q: null pointer");
@@ -775,6 +845,7 @@ int samx_act_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const fl
         TRY(hidden(c, w.XC, c.in, B, w.hc, st));
         HeadArgs h = head_of(c, w.hc, B);
         h.out0 = q_out;
+        set_ret(h, ret);
         TRY(launch_head<HEAD_Q>(h, st));
     }
     return SAMX_OK;
@@ -783,7 +854,7 @@ int samx_act_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const fl
 int samx_targ_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
                 const float* obs1, const float* rews, const float* dones1, const float* td_len,
                 const float* mean, const float* stdv, int64_t B, float gamma, float high, float* out,
-                void* ws, size_t ws_bytes, void* stream) {
+                const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream) {
     TRY(check_desc(da, "samx_targ_q(actor)"));
     TRY(check_desc(dc, "samx_targ_q(critic)"));
     SAMX_REQUIRE(pa && pc && obs1 && rews && dones1 && out && ws, "samx_targ_q: null pointer");
@@ -799,12 +870,13 @@ int samx_targ_q(const samx_mlp* da, const float* pa, const samx_mlp* dc, const f
     TRY(hidden(c, w.XC, c.in, B, w.hc, st));
     HeadArgs h = head_of(c, w.hc, B);
     h.r0 = rews; h.r1 = dones1; h.r2 = td_len; h.c0 = gamma; h.out0 = out;
+    set_ret(h, ret);
     return launch_head<HEAD_TARG>(h, st);
 }
 
 int samx_td_errors(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
                    const float* tc1s, const float* mean, const float* stdv, int64_t B, int ob_dim,
-                   float* td_out, void* ws, size_t ws_bytes, void* stream) {
+                   float* td_out, const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream) {
     TRY(check_desc(dc, "samx_td_errors"));
     SAMX_REQUIRE(pc && obs0 && acs && tc1s && td_out && ws, "samx_td_errors: null pointer");
     SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_td_errors: mean/std must come together");
@@ -821,6 +893,7 @@ int samx_td_errors(const samx_mlp* dc, const float* pc, const float* obs0, const
     TRY(hidden(c, w.XC, c.in, B, w.hc, st));
     HeadArgs h = head_of(c, w.hc, B);
     h.r0 = tc1s; h.out0 = td_out;
+    set_ret(h, ret);
     return launch_head<HEAD_TD>(h, st);
 }
 
@@ -848,7 +921,8 @@ int samx_reward(const samx_mlp* dd, const float* pd, const float* obs, const flo
 int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
                      const float* iws, const float* tc1s, const float* mean, const float* stdv,
                      int64_t B, int ob_dim, float td_scale, float wd_scale, float* losses_out,
-                     float* grad_out, float* td_out, void* ws, size_t ws_bytes, void* stream) {
+                     float* grad_out, float* td_out, const samx_retnorm* ret, const float* tcns,
+                     float tdn_scale, float* tdn_out, void* ws, size_t ws_bytes, void* stream) {
     TRY(check_desc(dc, "samx_critic_grad"));
     SAMX_REQUIRE(pc && obs0 && acs && tc1s && losses_out && grad_out && ws,
                  "samx_critic_grad: null pointer");
@@ -867,6 +941,8 @@ int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, con
     HeadArgs h = head_of(c, w.hc, B);
     h.r0 = tc1s; h.r1 = iws; h.c0 = td_scale / (float)B;
     h.out0 = w.row0; h.out1 = td_out; h.out2 = w.row1; h.DZ2 = top_cot(c, w.kc);
+    set_ret(h, ret);
+    if (tcns) { h.rn = tcns; h.cn = tdn_scale / (float)B; h.out4 = w.row2; h.out5 = tdn_out; }
     TRY(launch_head<HEAD_CRITIC>(h, st));
     TRY(wgrad(w.hc.N2, c.h2, c.h2, w.row1, 1, 1, B, B, grad_out + c.oW3, 0.f, nullptr, w.partials,
               w.partial_floats, st));
@@ -881,7 +957,8 @@ int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, con
                                                    w.wd_part);
         SAMX_LAUNCH_CHECK();
     }
-    critic_losses_kernel<<<1, 1024, 0, st>>>(w.row0, B, td_scale, wd_scale, w.wd_part, kWdBlocks, losses_out);
+    critic_losses_kernel<<<1, 1024, 0, st>>>(w.row0, B, td_scale, wd_scale, w.wd_part, kWdBlocks, losses_out,
+                                             tcns ? w.row2 : nullptr, tdn_scale);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -889,7 +966,8 @@ int samx_critic_grad(const samx_mlp* dc, const float* pc, const float* obs0, con
 int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, const float* pc,
                     const samx_mlp* dd, const float* pd, const float* obs0, const float* mean,
                     const float* stdv, int64_t B, float high, float q_scale, float d_scale,
-                    float* losses_out, float* grad_out, void* ws, size_t ws_bytes, void* stream) {
+                    float* losses_out, float* grad_out, const samx_retnorm* ret, void* ws, size_t ws_bytes,
+                    void* stream) {
     TRY(check_desc(da, "samx_actor_grad(actor)"));
     TRY(check_desc(dc, "samx_actor_grad(critic)"));
     const bool use_d = d_scale != 0.f;
@@ -913,6 +991,7 @@ int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, con
     TRY(hidden(c, w.XC, c.in, B, w.hc, st));
     HeadArgs h = head_of(c, w.hc, B);
     h.c0 = -q_scale / (float)B; h.out0 = w.row0; h.DZ2 = top_cot(c, w.kc);
+    set_ret(h, ret);
     TRY(launch_head<HEAD_ACTOR_Q>(h, st));
     TRY(back_hidden(c, B, w.hc, w.kc, st));
     const float* add = nullptr;
@@ -921,6 +1000,7 @@ int samx_actor_grad(const samx_mlp* da, const float* pa, const samx_mlp* dc, con
         TRY(hidden(d, w.XC, d.in, B, w.hd, st));
         HeadArgs hd = head_of(d, w.hd, B);
         hd.c0 = -d_scale / (float)B; hd.out0 = w.row1; hd.DZ2 = top_cot(d, w.kd);
+        set_ret(hd, ret);  // d_pred_w_actor is dermsified too (sam_agent.py:191-194)
         TRY(launch_head<HEAD_ACTOR_Q>(hd, st));
         TRY(back_hidden(d, B, w.hd, w.kd, st));
         TRY(bwd_data(w.kd.DZ1, d.h1, B, d.h1, d.W1 + (int64_t)ob * d.h1, d.h1, A, w.dAd, A, EPI_NONE,
@@ -993,6 +1073,27 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) dst[t] = src[t];
 }
 }  // namespace
+
+int samx_ret_update_popart(double* sums, const double* addvec1, const double* addvec2, float* ret_mean,
+                           float* ret_std, int enable_popart, const samx_mlp* dc, float* critic_params,
+                           float* targ_critic_params, void* stream) {
+    SAMX_REQUIRE(sums && addvec1 && ret_mean && ret_std, "samx_ret_update_popart: null pointer");
+    float *w3a = nullptr, *b3a = nullptr, *w3b = nullptr, *b3b = nullptr;
+    int h2 = 0;
+    if (enable_popart) {
+        TRY(check_desc(dc, "samx_ret_update_popart"));
+        SAMX_REQUIRE(critic_params && targ_critic_params && dc->out_dim == 1,
+                     "samx_ret_update_popart: PopArt needs both critics (scalar output)");
+        Net a = split(dc, critic_params), b = split(dc, targ_critic_params);
+        w3a = critic_params + a.oW3; b3a = critic_params + a.ob3;
+        w3b = targ_critic_params + b.oW3; b3b = targ_critic_params + b.ob3;
+        h2 = a.h2;
+    }
+    popart_kernel<<<1, 256, 0, (hipStream_t)stream>>>(sums, addvec1, addvec2, ret_mean, ret_std,
+                                                      enable_popart ? 1 : 0, w3a, b3a, w3b, b3b, h2);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
 
 size_t samx_disc_ws_bytes(const samx_mlp* dd, int64_t B) {
     if (!dd || B <= 0) return 0;

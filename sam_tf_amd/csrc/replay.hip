@@ -118,6 +118,62 @@ __global__ void rms_count_kernel(double* sums, const double* addvec, int dim) {
 
 }  // namespace
 
+namespace {
+// One thread per sampled index (memory.py:125-148).  Rows are read in batches of 8 so that the 8 loads
+// of a batch are in flight together; the discounted sum then runs from the far end in float64 with
+// separate multiply and add (the order and rounding of scipy's lfilter on the reversed rewards).
+__global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ rews,
+                                                    const float* __restrict__ dones1, int64_t maxlen,
+                                                    int64_t start, int64_t num_entries,
+                                                    const int64_t* __restrict__ idxs, int64_t B, int n,
+                                                    double gamma, int64_t* __restrict__ end_idx_out,
+                                                    float* __restrict__ rews_out,
+                                                    double* __restrict__ rews64_out,
+                                                    float* __restrict__ dones_out,
+                                                    float* __restrict__ td_len_out) {
+    const int64_t t = blockIdx.x * (int64_t)128 + threadIdx.x;
+    if (t >= B) return;
+    const int64_t idx = idxs[t];
+    const int64_t last = (idx + n < num_entries ? idx + n : num_entries) - 1;  // lookahead_end_idx
+    const int win = (int)(last - idx + 1);
+    int64_t phys0 = start + idx;
+    if (phys0 >= maxlen) phys0 -= maxlen;
+    // first done inside the window
+    int hit = -1;
+    for (int k0 = 0; k0 < win && hit < 0; k0 += 8) {
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int64_t p = phys0 + k0 + u;
+            if (p >= maxlen) p -= maxlen;
+            d[u] = (k0 + u < win) ? dones1[p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (hit < 0 && d[u] == 1.0f) hit = k0 + u;
+    }
+    const int td_len = hit >= 0 ? hit + 1 : win;
+    double acc = 0.0;
+    for (int k0 = td_len - 1; k0 >= 0; k0 -= 8) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int64_t p = phys0 + (k0 - u);
+            if (p >= maxlen) p -= maxlen;
+            r[u] = (k0 - u >= 0) ? rews[p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 - u >= 0) acc = __dadd_rn((double)r[u], __dmul_rn(gamma, acc));
+    }
+    end_idx_out[t] = idx + td_len - 1;
+    rews_out[t] = (float)acc;
+    if (rews64_out) rews64_out[t] = acc;
+    dones_out[t] = (hit >= 0 && hit != win - 1) ? 1.f : 0.f;
+    td_len_out[t] = (float)td_len;
+}
+}  // namespace
+
 extern "C" {
 
 int samx_replay_gather(const float* obs0, const float* acs, const float* rews, const float* dones1,
@@ -170,6 +226,23 @@ int samx_rms_commit(double* sums, const double* addvec, int dim, float* mean_out
         rms_count_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, addvec, dim);
         SAMX_LAUNCH_CHECK();
     }
+    return SAMX_OK;
+}
+
+
+int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen, int64_t start,
+                         int64_t num_entries, const int64_t* idxs, int64_t B, int n, double gamma,
+                         int64_t* end_idx_out, float* rews_out, double* rews64_out, float* dones_out,
+                         float* td_len_out, void* stream) {
+    SAMX_REQUIRE(rews && dones1 && idxs && end_idx_out && rews_out && dones_out && td_len_out,
+                 "samx_nstep_lookahead: null pointer");
+    SAMX_REQUIRE(B > 0 && n > 1 && n <= 4096, "samx_nstep_lookahead: need B > 0 and 1 < n <= 4096");
+    SAMX_REQUIRE(maxlen > 0 && start >= 0 && start < maxlen && num_entries > 0 && num_entries <= maxlen,
+                 "samx_nstep_lookahead: bad ring geometry");
+    nstep_kernel<<<(unsigned)((B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
+        rews, dones1, maxlen, start, num_entries, idxs, B, n, gamma, end_idx_out, rews_out, rews64_out,
+        dones_out, td_len_out);
+    SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
 

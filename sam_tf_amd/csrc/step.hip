@@ -13,7 +13,7 @@ using namespace samx;
 namespace {
 
 struct StepWs {
-    float *agent_part, *disc_part, *agent_loss, *disc_loss, *gp_out, *sumsq;
+    float *agent_part, *disc_part, *agent_loss, *disc_loss, *gp_out, *sumsq, *closs4;
     double* gp_part;
     void *nets_ws, *nets_ws2;  // layer-wise path: one per agent role (they run side by side)
     size_t nets_bytes;
@@ -68,6 +68,7 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.agent_loss = ar.take<float>(tiles * 4);
     w.disc_loss = ar.take<float>(2 * tiles * 4);
     w.gp_out = ar.take<float>(4);
+    w.closs4 = ar.take<float>(4);
     w.sumsq = ar.take<float>(3 * fused::kMaxSegBlocks);
     w.gp_part = ar.take<double>(2 * tiles);
     w.nets_bytes = f ? 0 : samx_nets_ws_bytes(&L->actor, &L->critic, &L->reward, B);
@@ -512,15 +513,19 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         }
         rc = samx_actor_grad(&L->actor, pa, &L->critic, pc, &L->reward, L->actor_reward_params, b->obs0,
                              L->mu_mean, L->mu_std, B, L->ac_high, L->q_actor_loss_scale,
-                             L->d_actor_loss_scale, o->actor_losses, L->grads, w.nets_ws2, w.nets_bytes,
-                             (void*)s_a);
+                             L->d_actor_loss_scale, o->actor_losses, L->grads, nullptr, w.nets_ws2,
+                             w.nets_bytes, (void*)s_a);
         if (rc != SAMX_OK) return rc;
         rc = samx_targ_q(&L->actor, ta, &L->critic, tc, b->obs1, b->rews, b->dones1, b->td_len, L->mu_mean,
-                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, w.nets_ws, w.nets_bytes, (void*)s_tc);
+                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, nullptr, w.nets_ws, w.nets_bytes,
+                         (void*)s_tc);
         if (rc != SAMX_OK) return rc;
         rc = samx_critic_grad(&L->critic, pc, b->obs0, b->acs, b->iws, o->targ_q, L->mu_mean, L->mu_std, B,
-                              L->ob_dim, L->td_loss_scale, L->wd_scale, o->critic_losses, L->grads + Pa,
-                              o->td, w.nets_ws, w.nets_bytes, (void*)s_tc);
+                              L->ob_dim, L->td_loss_scale, L->wd_scale, w.closs4, L->grads + Pa,
+                              o->td, nullptr, nullptr, 0.f, nullptr, w.nets_ws, w.nets_bytes, (void*)s_tc);
+        if (rc != SAMX_OK) return rc;
+        SAMX_CHECK_HIP(hipMemcpyAsync(o->critic_losses, w.closs4, 3 * sizeof(float), hipMemcpyDeviceToDevice,
+                                      s_tc));
         if (rc != SAMX_OK) return rc;
         rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
                             b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,

@@ -225,7 +225,17 @@ def _flat(p, d, name):
     return _chk(p, F32, (param_count(d),), name)
 
 
-def act_q(da, pa, dc, pc, obs, mean, std, high, ws, ac_out=None, q_out=None, want_q=True):
+def _ret(ret):
+    """ret: None or (mean[1], std[1]) CUDA float32 tensors -> POINTER(RetNorm) (kept alive by caller)."""
+    if ret is None:
+        return None
+    m, s = ret
+    _chk(m, F32, (1,), 'ret_mean'); _chk(s, F32, (1,), 'ret_std')
+    r = _lib.RetNorm(m.data_ptr(), s.data_ptr())
+    return C.byref(r)
+
+
+def act_q(da, pa, dc, pc, obs, mean, std, high, ws, ac_out=None, q_out=None, want_q=True, ret=None):
     B, ob = obs.shape
     _chk(obs, F32, (B, da.in_dim), 'obs'); _flat(pa, da, 'actor params'); _flat(pc, dc, 'critic params')
     mean, std = _ms(mean, std, ob)
@@ -235,11 +245,12 @@ def act_q(da, pa, dc, pc, obs, mean, std, high, ws, ac_out=None, q_out=None, wan
         q_out = torch.empty(B, dtype=F32, device=obs.device)
     _opt(q_out, F32, (B,), 'q_out')
     check(_L().samx_act_q(C.byref(da), ptr(pa), C.byref(dc), ptr(pc), ptr(obs), ptr(mean), ptr(std), B,
-                          float(high), ptr(ac_out), ptr(q_out), ptr(ws), ws.numel(), stream_ptr()))
+                          float(high), ptr(ac_out), ptr(q_out), _ret(ret), ptr(ws), ws.numel(),
+                          stream_ptr()))
     return ac_out, q_out
 
 
-def targ_q(da, pa_t, dc, pc_t, obs1, rews, dones1, td_len, mean, std, gamma, high, ws, out=None):
+def targ_q(da, pa_t, dc, pc_t, obs1, rews, dones1, td_len, mean, std, gamma, high, ws, out=None, ret=None):
     B, ob = obs1.shape
     _chk(obs1, F32, (B, da.in_dim), 'obs1'); _flat(pa_t, da, 'targ actor'); _flat(pc_t, dc, 'targ critic')
     rews = _chk(rews.reshape(B), F32, (B,), 'rews'); dones1 = _chk(dones1.reshape(B), F32, (B,), 'dones1')
@@ -248,12 +259,14 @@ def targ_q(da, pa_t, dc, pc_t, obs1, rews, dones1, td_len, mean, std, gamma, hig
     out = torch.empty(B, dtype=F32, device=obs1.device) if out is None else _chk(out, F32, (B,), 'out')
     check(_L().samx_targ_q(C.byref(da), ptr(pa_t), C.byref(dc), ptr(pc_t), ptr(obs1), ptr(rews),
                            ptr(dones1), ptr(td_len), ptr(mean), ptr(std), B, float(gamma), float(high),
-                           ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+                           ptr(out), _ret(ret), ptr(ws), ws.numel(), stream_ptr()))
     return out
 
 
 def critic_grad(dc, pc, obs0, acs, iws, tc1s, mean, std, td_scale, wd_scale, ws, losses=None,
-                grad=None, td=None):
+                grad=None, td=None, ret=None, tcns=None, tdn_scale=1.0, tdn=None):
+    """losses: float32[4] = {td_loss_1, wd, total, td_loss_n}; the first three are returned unless
+    tcns is given (then all four)."""
     B, ob = obs0.shape
     ac = dc.in_dim - ob
     _chk(obs0, F32, (B, ob), 'obs0'); _chk(acs, F32, (B, ac), 'acs'); _flat(pc, dc, 'critic params')
@@ -261,16 +274,23 @@ def critic_grad(dc, pc, obs0, acs, iws, tc1s, mean, std, td_scale, wd_scale, ws,
     tc1s = _chk(tc1s.reshape(B), F32, (B,), 'tc1s')
     mean, std = _ms(mean, std, ob)
     dev = obs0.device
-    losses = torch.empty(3, dtype=F32, device=dev) if losses is None else _chk(losses, F32, (3,), 'losses')
+    l4 = torch.empty(4, dtype=F32, device=dev) if losses is None or losses.numel() != 4 else losses
+    _chk(l4, F32, (4,), 'losses')
     grad = torch.empty(param_count(dc), dtype=F32, device=dev) if grad is None else _flat(grad, dc, 'grad')
     td = torch.empty(B, dtype=F32, device=dev) if td is None else _chk(td, F32, (B,), 'td')
+    tcns = None if tcns is None else _chk(tcns.reshape(B), F32, (B,), 'tcns')
+    _opt(tdn, F32, (B,), 'tdn')
     check(_L().samx_critic_grad(C.byref(dc), ptr(pc), ptr(obs0), ptr(acs), ptr(iws), ptr(tc1s), ptr(mean),
-                                ptr(std), B, ob, float(td_scale), float(wd_scale), ptr(losses), ptr(grad),
-                                ptr(td), ptr(ws), ws.numel(), stream_ptr()))
-    return losses, grad, td
+                                ptr(std), B, ob, float(td_scale), float(wd_scale), ptr(l4), ptr(grad),
+                                ptr(td), _ret(ret), ptr(tcns), float(tdn_scale), ptr(tdn), ptr(ws),
+                                ws.numel(), stream_ptr()))
+    if losses is not None and losses.numel() == 3:
+        _chk(losses, F32, (3,), 'losses').copy_(l4[:3])
+        return losses, grad, td
+    return (l4 if tcns is not None else l4[:3]), grad, td
 
 
-def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None):
+def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None, ret=None):
     B, ob = obs0.shape
     ac = dc.in_dim - ob
     _chk(obs0, F32, (B, ob), 'obs0'); _chk(acs, F32, (B, ac), 'acs'); _flat(pc, dc, 'critic params')
@@ -278,12 +298,12 @@ def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None):
     mean, std = _ms(mean, std, ob)
     out = torch.empty(B, dtype=F32, device=obs0.device) if out is None else _chk(out, F32, (B,), 'out')
     check(_L().samx_td_errors(C.byref(dc), ptr(pc), ptr(obs0), ptr(acs), ptr(tc1s), ptr(mean), ptr(std),
-                              B, ob, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+                              B, ob, ptr(out), _ret(ret), ptr(ws), ws.numel(), stream_ptr()))
     return out
 
 
 def actor_grad(da, pa, dc, pc, dd, pd, obs0, mean, std, high, q_scale, d_scale, ws, losses=None,
-               grad=None):
+               grad=None, ret=None):
     B, ob = obs0.shape
     _chk(obs0, F32, (B, da.in_dim), 'obs0'); _flat(pa, da, 'actor params'); _flat(pc, dc, 'critic params')
     if pd is not None:
@@ -295,8 +315,37 @@ def actor_grad(da, pa, dc, pc, dd, pd, obs0, mean, std, high, q_scale, d_scale, 
     check(_L().samx_actor_grad(C.byref(da), ptr(pa), C.byref(dc), ptr(pc),
                                C.byref(dd) if dd is not None else None, ptr(pd), ptr(obs0), ptr(mean),
                                ptr(std), B, float(high), float(q_scale), float(d_scale), ptr(losses),
-                               ptr(grad), ptr(ws), ws.numel(), stream_ptr()))
+                               ptr(grad), _ret(ret), ptr(ws), ws.numel(), stream_ptr()))
     return losses, grad
+
+
+def ret_update_popart(sums, addvec1, addvec2, ret_mean, ret_std, enable_popart, dc, critic_params,
+                      targ_critic_params):
+    """ret_rms.update (one or two target batches) + PopArt head rescale in one launch."""
+    _chk(sums, F64, (3,), 'ret sums'); _chk(addvec1, F64, (3,), 'addvec1'); _opt(addvec2, F64, (3,), 'addvec2')
+    _chk(ret_mean, F32, (1,), 'ret_mean'); _chk(ret_std, F32, (1,), 'ret_std')
+    if enable_popart:
+        _flat(critic_params, dc, 'critic params'); _flat(targ_critic_params, dc, 'target critic params')
+    check(_L().samx_ret_update_popart(ptr(sums), ptr(addvec1), ptr(addvec2), ptr(ret_mean), ptr(ret_std),
+                                      int(bool(enable_popart)), C.byref(dc), ptr(critic_params),
+                                      ptr(targ_critic_params), stream_ptr()))
+
+
+def nstep_lookahead(store, start, num_entries, idxs, n, gamma, want64=False):
+    """RB.lookahead on device storage: returns end_idx int64[B], rews f32[B], dones f32[B], td_len
+    f32[B] (+ rews f64[B] when want64)."""
+    B = idxs.numel()
+    _chk(idxs, I64, (B,), 'idxs')
+    maxlen = store['rews'].shape[0]
+    _chk(store['rews'], F32, (maxlen, 1), 'rews'); _chk(store['dones1'], F32, (maxlen, 1), 'dones1')
+    dev = idxs.device
+    end = torch.empty(B, dtype=I64, device=dev)
+    rews, dones, tl = (torch.empty(B, dtype=F32, device=dev) for _ in range(3))
+    r64 = torch.empty(B, dtype=F64, device=dev) if want64 else None
+    check(_L().samx_nstep_lookahead(ptr(store['rews']), ptr(store['dones1']), maxlen, int(start),
+                                    int(num_entries), ptr(idxs), B, int(n), float(gamma), ptr(end), ptr(rews),
+                                    ptr(r64), ptr(dones), ptr(tl), stream_ptr()))
+    return (end, rews, dones, tl, r64) if want64 else (end, rews, dones, tl)
 
 
 def disc_grad(dd, pd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real, fake, mean, std, ent_scale, ws,

@@ -147,3 +147,26 @@ def test_gather_roundtrip_and_rms():
     # second commit with nothing to add only re-derives mean/std
     ops.rms_commit(sums, None, mean, std)
     np.testing.assert_allclose(mean.cpu().numpy(), em, rtol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['replay_nstep_a', 'replay_nstep_wrap'])
+def test_nstep_lookahead_kernel_matches_reference(name):
+    """samx_nstep_lookahead vs the vectors recorded from the reference's RB.lookahead
+    (memory.py:113-160): indices, lengths, done flags exact; the discounted reward bit-exact in float64."""
+    import os
+    import torch
+    from sam_tf_amd import memory as XP, ops
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+    rb = XP.RB(int(g['limit']), (int(g['ob']),), (int(g['ac']),))
+    for i in range(len(g['in_rews'])):
+        rb.append(g['in_obs0'][i], g['in_acs'][i], g['in_rews'][i], g['in_obs1'][i], g['in_dones1'][i])
+    assert rb.start == int(g['start']) and rb.num_entries == int(g['length'])
+    idxs = torch.as_tensor(g['idxs'].astype(np.int64)).cuda()
+    end, rews, dones, tl, r64 = ops.nstep_lookahead(rb.store, rb.start, rb.num_entries, idxs, int(g['n']),
+                                                    float(g['gamma']), want64=True)
+    assert np.array_equal(r64.cpu().numpy(), g['la_rews'].ravel())
+    assert np.array_equal(rews.cpu().numpy(), g['la_rews'].ravel().astype(np.float32))
+    assert np.array_equal(dones.cpu().numpy(), g['la_dones1'].ravel().astype(np.float32))
+    assert np.array_equal(tl.cpu().numpy(), g['la_td_len'].ravel().astype(np.float32))
+    got = rb.batchify_device(end, want=('obs1',))['obs1'].cpu().numpy()
+    assert np.array_equal(got, g['la_obs1'])
