@@ -66,7 +66,9 @@ def build_learner(cfg, comm, device, seed, use_graph):
     env = SyntheticEnv(cfg['ob'], cfg['ac'], 1.0)
     hps = make_hps(hid_widths=cfg['h'], batch_size=cfg['B'], mem_size=cfg['mem'],
                    prioritized_replay=cfg['per'], seed=seed,
-                   with_layernorm=bool(cfg.get('ln', False)))
+                   with_layernorm=bool(cfg.get('ln', False)),
+                   rmsify_rets=bool(cfg.get('ret', False)), enable_popart=bool(cfg.get('ret', False)),
+                   n_step_returns=bool(cfg.get('nstep', 0)), n=int(cfg.get('nstep', 0)) or 96)
     d = Discriminator('d', env, hps, comm, device=device)
     mu = SAMAgent('mu', comm, env, hps, d, device=device)
     # synthetic transitions: obs ~ N(0,1), acs ~ U(-1,1), rews ~ U(0,5),
@@ -77,7 +79,7 @@ def build_learner(cfg, comm, device, seed, use_graph):
     u = lambda *s: torch.rand(*s, generator=g, device=device)
     obs0, obs1 = r(n, cfg['ob']), r(n, cfg['ob'])
     mu.replay_buffer.extend_device(obs0, u(n, cfg['ac']) * 2 - 1, u(n) * 5, obs1,
-                                   (u(n) < 1e-3).float())
+                                   (u(n) < cfg.get('p_done', 1e-3)).float())
     if hps.rmsify_obs:  # what store_transition would have accumulated (sam_agent.py:627-629)
         mu.obs_rms.update_device(obs0, None, comm)
     del obs0, obs1
@@ -166,6 +168,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--layernorm', action='store_true', help='with_layernorm nets (layer-wise path)')
+    ap.add_argument('--launcher', action='store_true',
+                    help='the canonical launcher options (mujoco_sam_imitate.sh): layernorm, rmsify_rets, '
+                         'popart, n-step returns n=96')
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
 
@@ -183,7 +188,8 @@ def main():
 
     from sam_tf_amd.comm import TorchComm
     comm = TorchComm(device)
-    cfg = dict(CONFIGS[args.config], ln=args.layernorm)
+    cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher,
+               nstep=96 if args.launcher and not CONFIGS[args.config]['per'] else 0)
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
     drv.prepare(1)
     drv.prepare(drv.K)
@@ -215,7 +221,9 @@ def main():
                                'resident), D gradient penalty, rmsify_obs%s' %
                                (args.config, cfg['name'], cfg['ob'], cfg['ac'], cfg['h'][0], cfg['h'][1],
                                 cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
-                                mu.replay_buffer.num_entries, ', with_layernorm' if cfg.get('ln') else ''),
+                                mu.replay_buffer.num_entries, (', with_layernorm' if cfg.get('ln') else '') +
+                                (', rmsify_rets+popart' if cfg.get('ret') else '') +
+                                (', n-step returns n=%d' % cfg['nstep'] if cfg.get('nstep') else '')),
                    'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                    'steps_per_graph_launch': drv.K, 'finite_params': finite},
         'roofline': {'bound': 'mfma',

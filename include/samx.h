@@ -266,6 +266,17 @@ typedef struct samx_learner {
     const float *d_mean, *d_std;      /* discriminator obs statistics (discriminator.py:67-72) */
     float ac_high, gamma, polyak, clip_norm, actor_lr, critic_lr, d_lr, beta1, beta2, adam_eps;
     float td_loss_scale, wd_scale, q_actor_loss_scale, d_actor_loss_scale, ent_reg_scale;
+    /* Return normalisation / PopArt / n-step returns (sam_agent.py:161-201,483-498,554-590,662-672).
+     * All off when ret_mean == NULL and n_step == 0; when on, the step runs on the layer-wise path.
+     * ret_mean / ret_std: device float[1] (ret_rms.mean / .std); ret_sums: device double[3] [sum, sumsq,
+     * count].  With enable_popart the step updates the statistics with this batch's targets and
+     * rescales the output layer of the online and the target critic before the losses (single
+     * process; N > 1 needs an all-reduce of the sums in between: use the per-role entry points).
+     * n_step > 1: the agent batch also gets its n-step lookahead targets (batch.a_idx required). */
+    float *ret_mean, *ret_std;
+    double* ret_sums;
+    int32_t enable_popart, n_step;
+    float td_loss_n_scale;
 } samx_learner;
 
 typedef struct samx_batch {  /* device inputs of one step; B rows each */
@@ -297,14 +308,16 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
      * between) and only on the whole-network fused path, else SAMX_ERR_UNSUPPORTED. */
     double* d_rms_sums;
     const double* d_rms_addvec;
+    int64_t num_entries; /* entries in the replay ring: bounds the n-step lookahead window */
 } samx_batch;
 
 typedef struct samx_step_out {
     float* d_losses;      /* [8]  discriminator.py:145-158 */
     float* actor_losses;  /* [3]  sam_agent.py:418-430 */
-    float* critic_losses; /* [3]  sam_agent.py:479-517 */
+    float* critic_losses; /* [4]  sam_agent.py:479-517: td_loss_1, wd, total, td_loss_n (0 when off) */
     float* targ_q;        /* [B]  sam_agent.py:651-654 */
     float* td;            /* [B]  pre-update TD errors, or NULL */
+    float* targ_q_n;      /* [B]  n-step targets (sam_agent.py:656-660), or NULL */
 } samx_step_out;
 
 int samx_fused_supported(const samx_learner* L, int64_t B);

@@ -35,7 +35,9 @@ class Learner(C.Structure):
                 [(k, C.c_float) for k in ('ac_high', 'gamma', 'polyak', 'clip_norm', 'actor_lr',
                                           'critic_lr', 'd_lr', 'beta1', 'beta2', 'adam_eps',
                                           'td_loss_scale', 'wd_scale', 'q_actor_loss_scale',
-                                          'd_actor_loss_scale', 'ent_reg_scale')])
+                                          'd_actor_loss_scale', 'ent_reg_scale')] +
+                [('ret_mean', C.c_void_p), ('ret_std', C.c_void_p), ('ret_sums', C.c_void_p),
+                 ('enable_popart', C.c_int32), ('n_step', C.c_int32), ('td_loss_n_scale', C.c_float)])
 
 
 class Batch(C.Structure):
@@ -44,12 +46,14 @@ class Batch(C.Structure):
         'p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
         'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'p_idx', 'a_idx', 'e_start')] +
                 [('ring_start', C.c_int64), ('ring_len', C.c_int64), ('rng_seed', C.c_uint64),
-                 ('label_smoothing', C.c_int32), ('d_rms_sums', C.c_void_p), ('d_rms_addvec', C.c_void_p)])
+                 ('label_smoothing', C.c_int32), ('d_rms_sums', C.c_void_p), ('d_rms_addvec', C.c_void_p),
+                 ('num_entries', C.c_int64)])
 
 
 class StepOut(C.Structure):
     """Mirror of `struct samx_step_out`."""
-    _fields_ = [(k, C.c_void_p) for k in ('d_losses', 'actor_losses', 'critic_losses', 'targ_q', 'td')]
+    _fields_ = [(k, C.c_void_p) for k in ('d_losses', 'actor_losses', 'critic_losses', 'targ_q', 'td',
+                                          'targ_q_n')]
 
 
 class RetNorm(C.Structure):

@@ -7,7 +7,8 @@ State in HBM (float32 unless noted):
 `train()` keeps the reference's return value (numpy, sam_agent.py:706-711); `train_device()` is the
 same update with everything left on the GPU.
 
-Not built (SURVEY.md §8f "next"): return normalisation/PopArt, n-step returns, parameter noise.
+Return normalisation + PopArt (sam_agent.py:161-201,554-590,662-672) and n-step returns
+(sam_agent.py:483-498,634-660 ; memory.py:113-175) are built; parameter noise is not.
 """
 import numpy as np
 import torch
@@ -81,7 +82,10 @@ class SAMAgent(object):
             critic_lr=hps.critic_lr, d_lr=hps.d_lr, beta1=0.9, beta2=0.999, adam_eps=1e-8,
             td_loss_scale=hps.td_loss_1_scale, wd_scale=hps.wd_scale,
             q_actor_loss_scale=hps.q_actor_loss_scale, d_actor_loss_scale=hps.d_actor_loss_scale,
-            ent_reg_scale=hps.ent_reg_scale), device=self.device)
+            ent_reg_scale=hps.ent_reg_scale,
+            enable_popart=int(bool(hps.rmsify_rets and hps.enable_popart)),
+            n_step=int(hps.n) if hps.n_step_returns else 0, td_loss_n_scale=hps.td_loss_n_scale),
+            device=self.device)
         L = self.L
         Pac = self.Pa + self.Pc
         self.params, self.targets = L.params[:Pac], L.targets
@@ -114,6 +118,15 @@ class SAMAgent(object):
             L.set_ptr('mu_mean', self.obs_rms.mean); L.set_ptr('mu_std', self.obs_rms.std)
             L.set_ptr('d_mean', d.obs_rms.mean); L.set_ptr('d_std', d.obs_rms.std)
 
+        # return statistics (sam_agent.py:161-172): scalar running mean/std, updated only under PopArt
+        self.ret = None
+        if hps.rmsify_rets:
+            self.ret_rms = DeviceRunningMeanStd(shape=(), device=self.device)
+            self.ret = (self.ret_rms.mean, self.ret_rms.std)
+            L.set_ptr('ret_mean', self.ret_rms.mean); L.set_ptr('ret_std', self.ret_rms.std)
+            L.set_ptr('ret_sums', self.ret_rms.sums)
+            self._ret_add2 = torch.zeros(3, dtype=torch.float64, device=self.device)
+
         self.setup_replay_buffer()
         actor_opt = MpiAdam(comm, self.actor.flat, hps.clip_norm, hps.actor_lr, name='actor_adam',
                             m=L.seg(L.m, 0), v=L.seg(L.v, 0), t_dev=L.steps[0:1])
@@ -121,14 +134,16 @@ class SAMAgent(object):
                              m=L.seg(L.m, 1), v=L.seg(L.v, 1), t_dev=L.steps[1:2])
         self.actor_ops = {'names': ['actor_q_loss', 'actor_d_loss', 'actor_total_loss'],
                           'optimizer': actor_opt}
-        names = ['critic_td_loss_1', 'critic_wd', 'critic_total_loss']
+        names = ['critic_td_loss_1'] + (['critic_td_loss_n'] if hps.n_step_returns else []) + \
+            ['critic_wd', 'critic_total_loss']   # sam_agent.py:479-517
         self.critic_ops = {'names': names, 'optimizer': critic_opt}
         self.actor_losses = torch.zeros(3, dtype=torch.float32, device=self.device)
-        self.critic_losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.critic_losses = torch.zeros(4, dtype=torch.float32, device=self.device)
         B = hps.batch_size
         self.ws = ops.nets_ws(self.da, self.dc, self.d_desc, B, self.device)
         self.ws1 = ops.nets_ws(self.da, self.dc, self.d_desc, 1, self.device)
         self.targ_q = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.targ_q_n = torch.zeros(B, dtype=torch.float32, device=self.device)
         self.td = torch.zeros(B, dtype=torch.float32, device=self.device)
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
@@ -171,7 +186,7 @@ class SAMAgent(object):
         o = torch.as_tensor(np.asarray(obs, dtype=np.float32)[None]).to(self.device)
         mean, std = self._mean_std()
         ac, q = ops.act_q(self.da, self.actor.flat, self.dc, self.critic.flat, o, mean, std,
-                          self.ac_high, self.ws1, want_q=compute_q)
+                          self.ac_high, self.ws1, want_q=compute_q, ret=self.ret)
         ac = ac.cpu().numpy().flatten()
         if apply_noise and self.ac_noise is not None:
             noise = self.ac_noise.generate()
@@ -199,21 +214,48 @@ class SAMAgent(object):
         batch['idxs'] = self._idx_dev
         return batch
 
+    def lookahead_device(self, batch):
+        """memory.py:113-160 on the device: the n-step companion of a sampled batch."""
+        rb = self.replay_buffer
+        end, rews, dones, td_len = ops.nstep_lookahead(rb.store, rb.start, rb.num_entries, batch['idxs'],
+                                                       self.hps.n, self.hps.gamma)
+        obs1 = rb.batchify_device(end, want=('obs1',))['obs1']
+        return dict(obs1=obs1, rews=rews, dones1=dones, td_len=td_len)
+
     def grads_device(self, batch):
-        """TD target on the target nets, then actor and critic losses + unclipped flat gradients on
-        the pre-update parameters (sam_agent.py:651-687 without the four repeated sess.runs)."""
+        """TD target(s) on the target nets, [ret_rms update + PopArt], then actor and critic losses +
+        unclipped flat gradients on the pre-update parameters (sam_agent.py:651-687 without the four
+        repeated sess.runs)."""
         mean, std = self._mean_std()
         hp = self.hps
         ops.targ_q(self.da, self.targ_actor.flat, self.dc, self.targ_critic.flat, batch['obs1'],
                    batch['rews'], batch['dones1'], None, mean, std, hp.gamma, self.ac_high, self.ws,
-                   out=self.targ_q)
+                   out=self.targ_q, ret=self.ret)
+        tcns = None
+        if hp.n_step_returns:  # sam_agent.py:656-660
+            bn = self.lookahead_device(batch)
+            ops.targ_q(self.da, self.targ_actor.flat, self.dc, self.targ_critic.flat, bn['obs1'], bn['rews'],
+                       bn['dones1'], bn['td_len'], mean, std, hp.gamma, self.ac_high, self.ws,
+                       out=self.targ_q_n, ret=self.ret)
+            tcns = self.targ_q_n
+        if hp.rmsify_rets and hp.enable_popart:  # sam_agent.py:662-672
+            r = self.ret_rms
+            ops.rms_batch_sums(self.targ_q.view(-1, 1), None, r.addvec)
+            self.comm.allreduce_(r.addvec)          # mpi_running_mean_std.py:55
+            if tcns is not None:
+                ops.rms_batch_sums(tcns.view(-1, 1), None, self._ret_add2)
+                self.comm.allreduce_(self._ret_add2)
+            ops.ret_update_popart(r.sums, r.addvec, self._ret_add2 if tcns is not None else None, r.mean, r.std,
+                                  True, self.dc, self.critic.flat, self.targ_critic.flat)
         ops.actor_grad(self.da, self.actor.flat, self.dc, self.critic.flat, self.d_desc, self.d_params,
                        batch['obs0'], mean, std, self.ac_high, hp.q_actor_loss_scale,
-                       hp.d_actor_loss_scale, self.ws, losses=self.actor_losses, grad=self.actor_grad)
+                       hp.d_actor_loss_scale, self.ws, losses=self.actor_losses, grad=self.actor_grad,
+                       ret=self.ret)
         ops.critic_grad(self.dc, self.critic.flat, batch['obs0'], batch['acs'],
                         batch.get('iws32') if hp.prioritized_replay else None, self.targ_q, mean, std,
                         hp.td_loss_1_scale, hp.wd_scale, self.ws, losses=self.critic_losses,
-                        grad=self.critic_grad, td=self.td)
+                        grad=self.critic_grad, td=self.td, ret=self.ret, tcns=tcns,
+                        tdn_scale=hp.td_loss_n_scale)
 
     def apply_device(self, fuse_polyak=False):
         """MpiAdam on both nets: ONE all-reduce over the [actor|critic] bucket (mpi_adam.py:27),
@@ -230,7 +272,7 @@ class SAMAgent(object):
         The float32 sum matches numpy's (float32 array + python float stays float32)."""
         mean, std = self._mean_std()
         ops.td_errors(self.dc, self.critic.flat, batch['obs0'], batch['acs'], self.targ_q, mean, std,
-                      self.ws, out=self.td)
+                      self.ws, out=self.td, ret=self.ret)
         self._td_host.copy_(self.td, non_blocking=True)
         self._idx_host.copy_(batch['idxs'], non_blocking=True)
         torch.cuda.current_stream().synchronize()
@@ -258,7 +300,12 @@ class SAMAgent(object):
         return {'actor_grads': cl[:self.Pa].copy(),
                 'actor_losses': [float(x) for x in self.actor_losses.cpu().numpy()],
                 'critic_grads': cl[self.Pa:].copy(),
-                'critic_losses': [float(x) for x in self.critic_losses.cpu().numpy()]}
+                'critic_losses': self._critic_losses_host()}
+
+    def _critic_losses_host(self):
+        """In the reference's order (sam_agent.py:479-517): td_loss_1, [td_loss_n], wd, total."""
+        l = [float(x) for x in self.critic_losses.cpu().numpy()]
+        return [l[0], l[3], l[1], l[2]] if self.hps.n_step_returns else l[:3]
 
     # ---- housekeeping --------------------------------------------------------------------------
     def sync_from_root(self):

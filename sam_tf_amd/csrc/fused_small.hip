@@ -817,6 +817,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
                 const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
                 f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl;
                 f.critic_losses[2] = (float)(tl + wl);
+                f.critic_losses[3] = 0.f;  // no n-step term on this path
             }
         }
         if (f.disc_loss_part) {

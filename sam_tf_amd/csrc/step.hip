@@ -13,7 +13,7 @@ using namespace samx;
 namespace {
 
 struct StepWs {
-    float *agent_part, *disc_part, *agent_loss, *disc_loss, *gp_out, *sumsq, *closs4;
+    float *agent_part, *disc_part, *agent_loss, *disc_loss, *gp_out, *sumsq;
     double* gp_part;
     void *nets_ws, *nets_ws2;  // layer-wise path: one per agent role (they run side by side)
     size_t nets_bytes;
@@ -22,6 +22,10 @@ struct StepWs {
     // layer-wise path only: gathered rows and materialised randoms
     float *g_pobs, *g_pacs, *g_eobs, *g_eacs, *g_obs0, *g_acs, *g_rews, *g_dones, *g_obs1, *r_eob, *r_eac,
         *r_real, *r_fake;
+    // n-step lookahead (memory.py:113-160) and return-statistics sums
+    int64_t* n_end;
+    float *n_rews, *n_dones, *n_len, *n_obs1, *n_tq;
+    double *ret_add1, *ret_add2;
 };
 
 // Two side streams per device for the layer-wise path: the discriminator, target+critic and actor
@@ -31,7 +35,7 @@ struct StepWs {
 // therefore must not happen while a capture is in progress (the host driver warms up first).
 struct SideStreams {
     hipStream_t s[2];
-    hipEvent_t fork, join[2];
+    hipEvent_t fork, join[2], mid;
 };
 int side_streams(SideStreams** out) {
     static SideStreams* per_dev[64] = {nullptr};
@@ -45,6 +49,7 @@ int side_streams(SideStreams** out) {
             SAMX_CHECK_HIP(hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming));
         }
         SAMX_CHECK_HIP(hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming));
+        SAMX_CHECK_HIP(hipEventCreateWithFlags(&ss->mid, hipEventDisableTiming));
         per_dev[dev] = ss;
     }
     *out = per_dev[dev];
@@ -52,6 +57,7 @@ int side_streams(SideStreams** out) {
 }
 
 bool use_fused(const samx_learner* L, int64_t B) {
+    if (L->ret_mean || L->n_step > 0) return false;  // return normalisation / n-step: layer-wise path
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
            fused::supported(&L->reward, B) && L->critic.in_dim == L->ob_dim + L->ac_dim &&
            L->reward.in_dim == L->critic.in_dim;
@@ -68,7 +74,6 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.agent_loss = ar.take<float>(tiles * 4);
     w.disc_loss = ar.take<float>(2 * tiles * 4);
     w.gp_out = ar.take<float>(4);
-    w.closs4 = ar.take<float>(4);
     w.sumsq = ar.take<float>(3 * fused::kMaxSegBlocks);
     w.gp_part = ar.take<double>(2 * tiles);
     w.nets_bytes = f ? 0 : samx_nets_ws_bytes(&L->actor, &L->critic, &L->reward, B);
@@ -83,6 +88,11 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.g_rews = ar.take<float>(n); w.g_dones = ar.take<float>(n); w.g_obs1 = ar.take<float>(n * ob);
     w.r_eob = ar.take<float>(n * ob); w.r_eac = ar.take<float>(n * ac);
     w.r_real = ar.take<float>(n); w.r_fake = ar.take<float>(n);
+    const int64_t nn = (!f && L->n_step > 0) ? B : 0;
+    w.n_end = ar.take<int64_t>(nn);
+    w.n_rews = ar.take<float>(nn); w.n_dones = ar.take<float>(nn); w.n_len = ar.take<float>(nn);
+    w.n_obs1 = ar.take<float>(nn * ob); w.n_tq = ar.take<float>(nn);
+    w.ret_add1 = ar.take<double>(4); w.ret_add2 = ar.take<double>(4);
     return w;
 }
 
@@ -100,6 +110,10 @@ int check_learner(const samx_learner* L, const char* who) {
                  "%s: mean/std must come together", who);
     SAMX_REQUIRE(L->d_actor_loss_scale == 0.f || L->actor_reward_params,
                  "%s: d_actor_loss_scale != 0 needs actor_reward_params", who);
+    SAMX_REQUIRE((L->ret_mean == nullptr) == (L->ret_std == nullptr), "%s: ret_mean/ret_std go together", who);
+    SAMX_REQUIRE(!L->enable_popart || (L->ret_mean && L->ret_sums), "%s: PopArt needs ret_mean/ret_std/ret_sums",
+                 who);
+    SAMX_REQUIRE(L->n_step == 0 || L->n_step > 1, "%s: n_step must be 0 (off) or > 1", who);
     return SAMX_OK;
 }
 
@@ -466,6 +480,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense
         // rows and materialised randoms, so indirection / in-kernel draws are resolved first.
         samx_batch dense = *b;
+        const samx_batch* orig = b;
         const int ob = L->ob_dim, ac = L->ac_dim;
         if (b->p_idx) {
             rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
@@ -511,21 +526,58 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             s_tc = ss->s[0];
             s_a = ss->s[1];
         }
-        rc = samx_actor_grad(&L->actor, pa, &L->critic, pc, &L->reward, L->actor_reward_params, b->obs0,
-                             L->mu_mean, L->mu_std, B, L->ac_high, L->q_actor_loss_scale,
-                             L->d_actor_loss_scale, o->actor_losses, L->grads, nullptr, w.nets_ws2,
-                             w.nets_bytes, (void*)s_a);
-        if (rc != SAMX_OK) return rc;
+        samx_retnorm retv{L->ret_mean, L->ret_std};
+        const samx_retnorm* ret = L->ret_mean ? &retv : nullptr;
+        const bool popart_or_stats = L->ret_mean && L->enable_popart;  // sam_agent.py:662 (update only then)
+        // ---- target + critic role (side 0)
+        const float* tcns = nullptr;
+        if (L->n_step > 0) {  // n-step lookahead from the sampled indices (memory.py:113-160)
+            SAMX_REQUIRE(orig->a_idx && orig->num_entries > 0,
+                         "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
+            rc = samx_nstep_lookahead(orig->rews, orig->dones1, orig->ring_len, orig->ring_start, orig->num_entries,
+                                      orig->a_idx, B, L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr,
+                                      w.n_dones, w.n_len, (void*)s_tc);
+            if (rc != SAMX_OK) return rc;
+            rc = samx_replay_gather(nullptr, nullptr, nullptr, nullptr, orig->obs1, orig->ring_len, orig->ring_start,
+                                    ob, ac, w.n_end, B, nullptr, nullptr, nullptr, nullptr, w.n_obs1, (void*)s_tc);
+            if (rc != SAMX_OK) return rc;
+        }
         rc = samx_targ_q(&L->actor, ta, &L->critic, tc, b->obs1, b->rews, b->dones1, b->td_len, L->mu_mean,
-                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, nullptr, w.nets_ws, w.nets_bytes,
+                         L->mu_std, B, L->gamma, L->ac_high, o->targ_q, ret, w.nets_ws, w.nets_bytes,
                          (void*)s_tc);
         if (rc != SAMX_OK) return rc;
+        if (L->n_step > 0) {
+            float* tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
+            rc = samx_targ_q(&L->actor, ta, &L->critic, tc, w.n_obs1, w.n_rews, w.n_dones, w.n_len, L->mu_mean,
+                             L->mu_std, B, L->gamma, L->ac_high, tqn, ret, w.nets_ws, w.nets_bytes, (void*)s_tc);
+            if (rc != SAMX_OK) return rc;
+            tcns = tqn;
+        }
+        if (popart_or_stats) {  // ret_rms.update(targ_q_1 [, targ_q_n]) then PopArt (sam_agent.py:662-672)
+            rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, (void*)s_tc);
+            if (rc != SAMX_OK) return rc;
+            if (tcns) {
+                rc = samx_rms_batch_sums(tcns, B, nullptr, 0, 1, w.ret_add2, (void*)s_tc);
+                if (rc != SAMX_OK) return rc;
+            }
+            rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, tcns ? w.ret_add2 : nullptr, L->ret_mean,
+                                        L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, (void*)s_tc);
+            if (rc != SAMX_OK) return rc;
+            if (!serial) {  // the actor role reads the rescaled critic head and the new statistics
+                SAMX_CHECK_HIP(hipEventRecord(ss->mid, s_tc));
+                SAMX_CHECK_HIP(hipStreamWaitEvent(s_a, ss->mid, 0));
+            }
+        }
         rc = samx_critic_grad(&L->critic, pc, b->obs0, b->acs, b->iws, o->targ_q, L->mu_mean, L->mu_std, B,
-                              L->ob_dim, L->td_loss_scale, L->wd_scale, w.closs4, L->grads + Pa,
-                              o->td, nullptr, nullptr, 0.f, nullptr, w.nets_ws, w.nets_bytes, (void*)s_tc);
+                              L->ob_dim, L->td_loss_scale, L->wd_scale, o->critic_losses, L->grads + Pa,
+                              o->td, ret, tcns, L->td_loss_n_scale, nullptr, w.nets_ws, w.nets_bytes,
+                              (void*)s_tc);
         if (rc != SAMX_OK) return rc;
-        SAMX_CHECK_HIP(hipMemcpyAsync(o->critic_losses, w.closs4, 3 * sizeof(float), hipMemcpyDeviceToDevice,
-                                      s_tc));
+        // ---- actor role (side 1)
+        rc = samx_actor_grad(&L->actor, pa, &L->critic, pc, &L->reward, L->actor_reward_params, b->obs0,
+                             L->mu_mean, L->mu_std, B, L->ac_high, L->q_actor_loss_scale,
+                             L->d_actor_loss_scale, o->actor_losses, L->grads, ret, w.nets_ws2, w.nets_bytes,
+                             (void*)s_a);
         if (rc != SAMX_OK) return rc;
         rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
                             b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,

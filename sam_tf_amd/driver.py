@@ -61,6 +61,9 @@ class UpdateStepDriver(object):
         # p ** alpha with the host libm).  The host RNG draws of those steps are made up front, in the
         # reference's order, so the sampled indices are the same as with one launch per step.
         self.K = int(steps_per_launch) if (self.use_graph and self.world == 1 and not self.per) else 1
+        if self.world > 1 and mu.hps.rmsify_rets and mu.hps.enable_popart:
+            raise NotImplementedError('PopArt inside the fused step needs an all-reduce of the return sums '
+                                      'between target and loss passes: use SAMAgent.train() for N > 1')
         f32 = dict(dtype=torch.float32, device=dev)
         rb = mu.replay_buffer
         assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
@@ -111,7 +114,8 @@ class UpdateStepDriver(object):
                 obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
                 obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=w[:B], a_idx=w[B:2 * B],
                 e_start=w[2 * B:2 * B + 1], ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
-                label_smoothing=self.label_mode, d_rms_sums=r.sums if r else None,
+                label_smoothing=self.label_mode, num_entries=rb.num_entries,
+                d_rms_sums=r.sums if r else None,
                 d_rms_addvec=self.addvecs[k] if r else None))
         self.batch = self.batches[0]
 
@@ -240,6 +244,8 @@ class UpdateStepDriver(object):
         keep = [L.params, L.targets, L.m, L.v, L.steps]
         if d.hps.rmsify_obs:
             keep += [d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]
+        if mu.hps.rmsify_rets:
+            keep += [mu.ret_rms.sums, mu.ret_rms.mean, mu.ret_rms.std]
         saved = [t.clone() for t in keep]
         rng_np, rng_py = np.random.get_state(), _random.getstate()
         ptr0 = self.pool.pointer
@@ -312,5 +318,6 @@ class UpdateStepDriver(object):
         """What the reference's loop logs per step (sam.py:398-431), still in HBM."""
         L, t = self.L, self.out.t
         return dict(d_losses=t['d_losses'], actor_losses=t['actor_losses'],
-                    critic_losses=t['critic_losses'], actor_grads=L.seg(L.clipped, 0),
+                    critic_losses=t['critic_losses'] if self.mu.hps.n_step_returns else t['critic_losses'][:3],
+                    actor_grads=L.seg(L.clipped, 0),
                     critic_grads=L.seg(L.clipped, 1), d_grads=L.seg(L.clipped, 2))

@@ -2,9 +2,9 @@
 
 Field names follow helpers/argparsers.py:6-50 (`disambiguate`: hid_widths / ent_reg_scale with the
 actorcritic_/d_ prefix stripped); defaults are the canonical launcher
-(launchers/imitation/mujoco_sam_imitate.sh:16-64) except the four features SURVEY.md §8(f) lists as
-"next" (rmsify_rets, enable_popart, n_step_returns, param noise), which default to off and are
-rejected when switched on.
+(launchers/imitation/mujoco_sam_imitate.sh:16-64) except that with_layernorm, rmsify_rets,
+enable_popart and n_step_returns default to off here (the BASELINE.json configs); all four are built
+and switch the step onto the layer-wise path.  Parameter-space noise is rejected ("next" row N3).
 """
 from types import SimpleNamespace
 
@@ -43,9 +43,16 @@ def check_supported(hps):
         raise NotImplementedError('leaky_relu only (the reference launchers use nothing else)')
     if hps.ac_branch_in != 1:
         raise NotImplementedError('ac_branch_in=1 only (launcher default)')
-    for k in ('rmsify_rets', 'enable_popart', 'n_step_returns', 'ranked', 'unreal', 'from_raw_pixels'):
+    for k in ('ranked', 'unreal', 'from_raw_pixels'):
         if getattr(hps, k):
-            raise NotImplementedError('%s is not built (SURVEY.md §8f "next" / out of scope)' % k)
+            raise NotImplementedError('%s is not built (SURVEY.md §2: out of scope)' % k)
+    if hps.n_step_returns and hps.prioritized_replay:
+        # PrioritizedRB.n_step_lookahead_sample returns ONE dict (memory.py:323-335) but SAMAgent.train
+        # unpacks two (sam_agent.py:634-638): the reference raises on this combination
+        raise NotImplementedError('n_step_returns with prioritized_replay fails in the reference itself '
+                                  '(memory.py:323-335 vs sam_agent.py:634-638); not built')
+    if hps.n_step_returns and not hps.n > 1:
+        raise ValueError('n_step_returns needs n > 1 (sam_agent.py:85)')
     if 'adaptive-param' in hps.noise_type:
         raise NotImplementedError('parameter-space noise is a "next" row (SURVEY.md §8f N3)')
 

@@ -404,12 +404,13 @@ class LearnerState(object):
                      ('steps', self.steps)):
             setattr(self.c, k, t.data_ptr())
         for k, v in self.hp.items():
-            setattr(self.c, k, float(v))
+            setattr(self.c, k, int(v) if k in ('enable_popart', 'n_step') else float(v))
         self._keep = {}
         self._ws = {}
 
     def set_ptr(self, field, tensor):
-        """Optional pointers: actor_reward_params, mu_mean, mu_std, d_mean, d_std."""
+        """Optional pointers: actor_reward_params, mu_mean, mu_std, d_mean, d_std, ret_mean, ret_std,
+        ret_sums."""
         self._keep[field] = tensor
         setattr(self.c, field, None if tensor is None else tensor.data_ptr())
 
@@ -432,7 +433,7 @@ _BATCH_F32 = ('p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labe
               'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')
 _BATCH_I64 = ('p_idx', 'a_idx', 'e_start')
 _BATCH_F64 = ('d_rms_sums', 'd_rms_addvec')
-_BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing')
+_BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing', 'num_entries')
 
 
 def make_batch(B, **fields):
@@ -516,8 +517,9 @@ def make_step_out(B, device='cuda'):
     o = _lib.StepOut()
     o.t = dict(d_losses=torch.zeros(8, dtype=F32, device=device),
                actor_losses=torch.zeros(3, dtype=F32, device=device),
-               critic_losses=torch.zeros(3, dtype=F32, device=device),
-               targ_q=torch.zeros(B, dtype=F32, device=device), td=torch.zeros(B, dtype=F32, device=device))
+               critic_losses=torch.zeros(4, dtype=F32, device=device),
+               targ_q=torch.zeros(B, dtype=F32, device=device), td=torch.zeros(B, dtype=F32, device=device),
+               targ_q_n=torch.zeros(B, dtype=F32, device=device))
     for k, t in o.t.items():
         setattr(o, k, t.data_ptr())
     return o
