@@ -150,6 +150,14 @@ int samx_clip_copy(const float* grad, int64_t n, float clip_norm, float* out, fl
 int samx_count_mismatch(const float* a, const float* b, int64_t n, int32_t* mismatch_out,
                         void* stream);
 
+/* Parameter-space noise (sam_agent.py:40-58,352-404): out = params + N(0, stddev^2) on the dense kernels
+ * and biases, out = params on the LayerNorm variables (networks.py:325-334).  Draws are Philox /
+ * Box-Muller keyed by (seed, counter, element index): the same (seed, counter) gives the same copy. */
+int samx_perturb_params(const samx_mlp* d, const float* params, float* out, float stddev, uint64_t seed,
+                        uint64_t counter, void* stream);
+/* sqrt(mean((a - b)^2)) over n floats (the action-space distance of sam_agent.py:371); out float[1]. */
+int samx_rms_distance(const float* a, const float* b, int64_t n, float* out, void* stream);
+
 /* ---- network passes ------------------------------------------------------------------------ */
 /* ob_mean/ob_std: float[ob] from samx_rms_commit, or NULL when rmsify_obs is off
  * (sam_agent.py:150-159).  Observations are normalised and clipped to [-5, 5] inside.

@@ -8,7 +8,8 @@ State in HBM (float32 unless noted):
 same update with everything left on the GPU.
 
 Return normalisation + PopArt (sam_agent.py:161-201,554-590,662-672) and n-step returns
-(sam_agent.py:483-498,634-660 ; memory.py:113-175) are built; parameter noise is not.
+(sam_agent.py:483-498,634-660 ; memory.py:113-175) and adaptive parameter-space noise
+(sam_agent.py:40-58,352-404,727-749) are built.
 """
 import numpy as np
 import torch
@@ -49,6 +50,25 @@ class OUAcNoise(object):
 
     def reset(self):
         self.prev_noise = self.noise_0 if self.noise_0 is not None else np.zeros_like(self.mu)
+
+
+class AdaptiveParamNoise(object):
+    """imitation_algorithms/param_noise.py:1-41."""
+
+    def __init__(self, initial_std=0.1, delta=0.1):
+        self.initial_std, self.delta, self.cur_std = initial_std, delta, initial_std
+
+    def adapt_std(self, dist):
+        if dist < self.delta:
+            self.cur_std *= 1.01
+        else:
+            self.cur_std /= 1.01
+
+    def adapt_delta(self, new_delta):
+        self.delta = new_delta
+
+    def __repr__(self):
+        return "AdaptiveParamNoise(initial_std={}, delta={})".format(self.initial_std, self.delta)
 
 
 class SAMAgent(object):
@@ -127,6 +147,8 @@ class SAMAgent(object):
             L.set_ptr('ret_sums', self.ret_rms.sums)
             self._ret_add2 = torch.zeros(3, dtype=torch.float64, device=self.device)
 
+        if self.param_noise is not None:
+            self.setup_param_noise()
         self.setup_replay_buffer()
         actor_opt = MpiAdam(comm, self.actor.flat, hps.clip_norm, hps.actor_lr, name='actor_adam',
                             m=L.seg(L.m, 0), v=L.seg(L.v, 0), t_dev=L.steps[0:1])
@@ -151,12 +173,16 @@ class SAMAgent(object):
 
     # ---- set-up pieces -------------------------------------------------------------------------
     def parse_noise_type(self, noise_type):
-        """sam_agent.py:238-288 (action-space noise only; param noise is a "next" row)."""
+        """sam_agent.py:238-288 (Box action spaces)."""
         ac_noise = None
+        param_noise = None
         for cur in noise_type.split(','):
             cur = cur.strip()
             if cur == 'none':
                 pass
+            elif 'adaptive-param' in cur:
+                _, std = cur.split('_')
+                param_noise = AdaptiveParamNoise(initial_std=float(std), delta=float(std))
             elif 'normal' in cur:
                 _, std = cur.split('_')
                 ac_noise = NormalAcNoise(mu=np.zeros(self.ac_dim), sigma=float(std) * np.ones(self.ac_dim))
@@ -165,7 +191,26 @@ class SAMAgent(object):
                 ac_noise = OUAcNoise(mu=np.zeros(self.ac_dim), sigma=float(std) * np.ones(self.ac_dim))
             else:
                 raise RuntimeError("unknown specified noise type: '{}'".format(cur))
-        return None, ac_noise
+        return param_noise, ac_noise
+
+    def setup_param_noise(self):
+        """sam_agent.py:352-404: two perturbed copies of the actor — one acts in the environment
+        (pnp), one only measures the action-space effect of the current std (apnp)."""
+        self.pn_cur_std = self.param_noise.cur_std
+        self.pn_dist = None
+        self.pnp_actor = FlatNet(self.scope, 'pnp_actor', self.da, torch.zeros_like(self.actor.flat))
+        self.apnp_actor = FlatNet(self.scope, 'apnp_actor', self.da, torch.zeros_like(self.actor.flat))
+        self._pn_seed = int(self.hps.seed) * 7919 + 104729 * (self.comm.Get_rank() + 1)
+        self._pn_count = 0
+        self._pn_dist_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._perturb(self.pnp_actor)
+        self._perturb(self.apnp_actor)
+
+    def _perturb(self, net):
+        """get_p_actor_updates (sam_agent.py:40-58) with the current std."""
+        ops.perturb_params(self.da, self.actor.flat, net.flat, self.param_noise.cur_std, self._pn_seed,
+                           self._pn_count)
+        self._pn_count += 1
 
     def setup_replay_buffer(self):
         """sam_agent.py:310-335."""
@@ -187,6 +232,11 @@ class SAMAgent(object):
         mean, std = self._mean_std()
         ac, q = ops.act_q(self.da, self.actor.flat, self.dc, self.critic.flat, o, mean, std,
                           self.ac_high, self.ws1, want_q=compute_q, ret=self.ret)
+        if apply_noise and self.param_noise is not None:
+            # p_act / p_act_q (sam_agent.py:373-378): the action of the parameter-noise-perturbed actor;
+            # the Q value stays critic_pred_w_actor, i.e. Q(s, UNperturbed actor(s)) — as the reference
+            ac, _ = ops.act_q(self.da, self.pnp_actor.flat, self.dc, self.critic.flat, o, mean, std,
+                              self.ac_high, self.ws1, want_q=False, ret=self.ret)
         ac = ac.cpu().numpy().flatten()
         if apply_noise and self.ac_noise is not None:
             noise = self.ac_noise.generate()
@@ -319,6 +369,28 @@ class SAMAgent(object):
     def update_target_net(self):
         ops.polyak(self.targets, self.params, self.hps.polyak)
 
+    def adapt_param_noise(self, comm):
+        """sam_agent.py:727-740."""
+        from .comm import mpi_mean_like
+        batch = self.replay_buffer.sample(batch_size=self.hps.batch_size)
+        obs0 = torch.as_tensor(np.ascontiguousarray(batch['obs0'], dtype=np.float32)).to(self.device)
+        self._perturb(self.apnp_actor)
+        mean, std = self._mean_std()
+        B = obs0.shape[0]
+        ws = self.ws if B == self.hps.batch_size else ops.nets_ws(self.da, self.dc, self.d_desc, B, self.device)
+        a0, _ = ops.act_q(self.da, self.actor.flat, self.dc, self.critic.flat, obs0, mean, std, self.ac_high,
+                          ws, want_q=False)
+        a0 = a0.clone()
+        a1, _ = ops.act_q(self.da, self.apnp_actor.flat, self.dc, self.critic.flat, obs0, mean, std,
+                          self.ac_high, ws, want_q=False)
+        dist = float(ops.rms_distance(a0, a1, self._pn_dist_dev).item())
+        self.pn_dist = float(mpi_mean_like(np.array(dist), comm))
+        self.param_noise.adapt_std(self.pn_dist)
+        self.pn_cur_std = self.param_noise.cur_std
+
     def reset_noise(self):
+        """sam_agent.py:741-749."""
+        if self.param_noise is not None:
+            self._perturb(self.pnp_actor)
         if self.ac_noise is not None:
             self.ac_noise.reset()

@@ -3,6 +3,8 @@
 //   imitation_algorithms/sam_agent.py:20-37.
 // HBM-bound streaming: 28 bytes/parameter for Adam (+12 with the fused Polyak update).
 #include "samx_common.h"
+#include "rng.h"
+#include <math.h>
 #include "../../include/samx.h"
 #include <math.h>
 
@@ -131,6 +133,51 @@ int grid_for(int64_t n) {
 
 }  // namespace
 
+namespace {
+// Parameter-space noise (sam_agent.py:40-58): out = param + N(0, std^2) on the perturbable variables
+// (dense kernels and biases), out = param on the LayerNorm variables (networks.py:325-334).
+// Normal draws: Box-Muller over two Philox uniforms keyed by (seed, counter, element); TF's own
+// tf.random_normal stream cannot be reproduced.
+struct NoiseRanges {
+    int64_t lo[2], hi[2];  // index ranges of the non-perturbable (LayerNorm) variables
+};
+__global__ __launch_bounds__(256) void perturb_kernel(const float* __restrict__ p, float* __restrict__ out,
+                                                      int64_t n, float stdv, uint64_t seed, uint64_t counter,
+                                                      NoiseRanges r) {
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool frozen = (i >= r.lo[0] && i < r.hi[0]) || (i >= r.lo[1] && i < r.hi[1]);
+        float v = p[i];
+        if (!frozen) {
+            const float u1 = samx::philox_uniform(seed, counter, 4, (uint64_t)i);
+            const float u2 = samx::philox_uniform(seed, counter, 5, (uint64_t)i);
+            const float z = sqrtf(-2.f * logf(1.f - u1)) * cosf(6.28318530717958647692f * u2);  // 1-u1 in (0,1]
+            v += stdv * z;
+        }
+        out[i] = v;
+    }
+}
+
+// sqrt(mean((a - b)^2)) (sam_agent.py:371), one workgroup, float64 accumulation in fixed order
+__global__ __launch_bounds__(1024) void rms_distance_kernel(const float* __restrict__ a,
+                                                            const float* __restrict__ b, int64_t n,
+                                                            float* __restrict__ out) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double d = (double)a[i] - (double)b[i];
+        acc += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        out[0] = (float)sqrt(t / (double)n);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int samx_adam_partials(void) { return kPartials; }
@@ -185,6 +232,31 @@ int samx_count_mismatch(const float* a, const float* b, int64_t n, int32_t* mism
     mismatch_kernel<<<grid_for(n), kThreads, 0, (hipStream_t)stream>>>((const uint32_t*)a,
                                                                       (const uint32_t*)b, n,
                                                                       mismatch_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+
+int samx_perturb_params(const samx_mlp* d, const float* params, float* out, float stddev, uint64_t seed,
+                        uint64_t counter, void* stream) {
+    SAMX_REQUIRE(d && params && out && stddev >= 0.f, "samx_perturb_params: bad arguments");
+    const int64_t n = samx_mlp_param_count(d);
+    NoiseRanges r;
+    r.lo[0] = r.hi[0] = r.lo[1] = r.hi[1] = 0;
+    if (d->layernorm) {  // layout: W1 b1 [beta1 gamma1] W2 b2 [beta2 gamma2] W3 b3
+        r.lo[0] = (int64_t)d->in_dim * d->h1 + d->h1;
+        r.hi[0] = r.lo[0] + 2 * d->h1;
+        r.lo[1] = r.hi[0] + (int64_t)d->h1 * d->h2 + d->h2;
+        r.hi[1] = r.lo[1] + 2 * d->h2;
+    }
+    perturb_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(params, out, n, stddev, seed, counter, r);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_rms_distance(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    SAMX_REQUIRE(a && b && out && n > 0, "samx_rms_distance: bad arguments");
+    rms_distance_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a, b, n, out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -4,7 +4,7 @@ Field names follow helpers/argparsers.py:6-50 (`disambiguate`: hid_widths / ent_
 actorcritic_/d_ prefix stripped); defaults are the canonical launcher
 (launchers/imitation/mujoco_sam_imitate.sh:16-64) except that with_layernorm, rmsify_rets,
 enable_popart and n_step_returns default to off here (the BASELINE.json configs); all four are built
-and switch the step onto the layer-wise path.  Parameter-space noise is rejected ("next" row N3).
+and switch the step onto the layer-wise path.
 """
 from types import SimpleNamespace
 
@@ -53,8 +53,6 @@ def check_supported(hps):
                                   '(memory.py:323-335 vs sam_agent.py:634-638); not built')
     if hps.n_step_returns and not hps.n > 1:
         raise ValueError('n_step_returns needs n > 1 (sam_agent.py:85)')
-    if 'adaptive-param' in hps.noise_type:
-        raise NotImplementedError('parameter-space noise is a "next" row (SURVEY.md §8f N3)')
 
 
 class Box(object):

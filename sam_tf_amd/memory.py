@@ -83,9 +83,9 @@ class RB(object):
         o, a = self.ob_dim, self.ac_dim
         s[:o] = np.asarray(obs0, dtype=np.float32).ravel()
         s[o:o + a] = np.asarray(acs, dtype=np.float32).ravel()
-        s[o + a] = np.float32(rews)
+        s[o + a] = np.asarray(rews, dtype=np.float32).reshape(-1)[0]
         s[o + a + 1:2 * o + a + 1] = np.asarray(obs1, dtype=np.float32).ravel()
-        s[2 * o + a + 1] = np.float32(dones1)
+        s[2 * o + a + 1] = np.asarray(dones1, dtype=np.float32).reshape(-1)[0]
         self._row_host[0] = row
         self._stage_dev.copy_(self._stage, non_blocking=True)
         self._row_dev.copy_(self._row_host, non_blocking=True)

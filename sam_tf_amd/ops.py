@@ -201,6 +201,21 @@ def count_mismatch(a, b, out=None):
     return out
 
 
+def perturb_params(d, params, out, stddev, seed, counter):
+    _flat(params, d, 'params'); _flat(out, d, 'out')
+    check(_L().samx_perturb_params(C.byref(d), ptr(params), ptr(out), float(stddev), int(seed), int(counter),
+                                   stream_ptr()))
+    return out
+
+
+def rms_distance(a, b, out=None):
+    n = a.numel()
+    _chk(a, F32, tuple(a.shape), 'a'); _chk(b, F32, tuple(a.shape), 'b')
+    out = torch.empty(1, dtype=F32, device=a.device) if out is None else _chk(out, F32, (1,), 'out')
+    check(_L().samx_rms_distance(ptr(a), ptr(b), n, ptr(out), stream_ptr()))
+    return out
+
+
 # ------------------------------------------------------------------ network passes
 
 def nets_ws(da, dc, dd, B, device='cuda'):
