@@ -209,6 +209,16 @@ int samx_td_errors(const samx_mlp* critic, const float* critic_params, const flo
                    int64_t B, int ob_dim, float* td_out, const samx_retnorm* ret, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* The same TD errors for rows addressed IN PLACE in the replay storages: row r of the batch is storage row
+ * (ring_start + idx[r]) % ring_len (idx NULL: obs0/acs are B dense rows).  64x64 critics without return
+ * normalisation run as one whole-network launch; anything else gathers into ws and takes the layer-wise
+ * pass.  This is the PER priority refresh with the post-update critic (sam_agent.py:693-701). */
+size_t samx_td_errors_rows_ws_bytes(const samx_mlp* critic, int64_t B);
+int samx_td_errors_rows(const samx_mlp* critic, const float* critic_params, const float* obs0,
+                        const float* acs, const int64_t* idx, int64_t ring_start, int64_t ring_len,
+                        const float* tc1s, const float* ob_mean, const float* ob_std, int64_t B, int ob_dim,
+                        float* td_out, const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream);
+
 /* setup_actor (sam_agent.py:406-433): loss = -q_scale*mean Q(obz0, mu(obz0))
  *                                           -d_scale*mean D(obz0, mu(obz0)), gradient wrt the actor only.
  * reward_params may be NULL when d_scale == 0.  losses_out float[3] = {actor_q_loss, actor_d_loss,

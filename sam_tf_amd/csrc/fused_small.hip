@@ -715,6 +715,37 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     wgrad64(XC, in, DZb, part + oW1, part + ob1, R);
 }
 
+// critic_ops['td_errors'] (sam_agent.py:534-538,693-701) for 16 rows per workgroup: the PER refresh with
+// the post-update critic, rows read in place through the index words.
+struct TdArgs {
+    const float *obs0, *acs, *tc1s, *mean, *stdv, *critic;
+    float* td_out;
+    int ob, ac;
+    const int64_t* idx;
+    int64_t ring_start, ring_len;
+};
+__global__ __launch_bounds__(NT) void td_kernel(TdArgs a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    float* p = lds;
+    NetL n = carve_net(p, a.ob + a.ac, 1);
+    float* XC = p; p += R * LD;
+    float* A1 = p; p += R * LD;
+    float* A2 = p; p += R * LD;
+    float* s_ = p;
+    load_net(n, a.critic);
+    load_rows(XC, a.obs0, a.acs, a.mean, a.stdv, a.ob, a.ac, row0, a.idx, a.ring_start, a.ring_len);
+    stage_wait();
+    layer_fwd(XC, n.k4, n.W1, n.b1, A1);
+    __syncthreads();
+    layer_fwd(A1, H, n.W2, n.b2, A2);
+    __syncthreads();
+    head_dot(A2, n, s_);
+    __syncthreads();
+    if (tid < R) a.td_out[row0 + tid] = s_[tid] - a.tc1s[row0 + tid];
+}
+
 // One launch for every gradient pass of the step that needs no grid-wide value: the two agent roles
 // and the discriminator's first kernel are independent, so their workgroups share the chip.
 // Longest role first.
@@ -983,6 +1014,25 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
         attr_set = lds;
     }
     step_kernel<<<(unsigned)(s.n_a + s.n_tc + s.n_disc), NT, lds, st>>>(s);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
+              const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
+              int64_t ring_len, float* td_out, hipStream_t st) {
+    TdArgs a;
+    a.obs0 = obs0; a.acs = acs; a.tc1s = tc1s; a.mean = mean; a.stdv = stdv; a.critic = critic;
+    a.td_out = td_out; a.ob = ob; a.ac = dc->in_dim - ob; a.idx = idx; a.ring_start = ring_start;
+    a.ring_len = ring_len;
+    const size_t lds = (net_lds_floats(dc->in_dim, 1) + 3 * R * LD + 16) * sizeof(float);
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)td_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+        attr_set = lds;
+    }
+    td_kernel<<<(unsigned)(B / R), NT, lds, st>>>(a);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -419,6 +419,42 @@ int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t
     return SAMX_OK;
 }
 
+int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
+                        const int64_t* idx, int64_t ring_start, int64_t ring_len, const float* tc1s,
+                        const float* mean, const float* stdv, int64_t B, int ob_dim, float* td_out,
+                        const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream) {
+    SAMX_REQUIRE(dc && pc && obs0 && acs && tc1s && td_out && B > 0 && ob_dim > 0 && ob_dim < dc->in_dim,
+                 "samx_td_errors_rows: bad arguments");
+    SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_td_errors_rows: mean/std must come together");
+    SAMX_REQUIRE(!idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
+                 "samx_td_errors_rows: bad ring geometry");
+    const bool ret_on = ret && ret->mean;
+    if (fused::supported(dc, B) && dc->out_dim == 1 && !ret_on)
+        return fused::launch_td(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, idx, ring_start, ring_len,
+                                td_out, (hipStream_t)stream);
+    // general path: gather the rows, then the layer-wise pass
+    const int ac = dc->in_dim - ob_dim;
+    SAMX_REQUIRE(ws, "samx_td_errors_rows: this configuration needs a workspace");
+    Arena ar(ws, ws_bytes);
+    float* g_obs = ar.take<float>(idx ? B * ob_dim : 0);
+    float* g_acs = ar.take<float>(idx ? B * ac : 0);
+    const size_t nets_bytes = samx_nets_ws_bytes(dc, dc, nullptr, B);  // an upper bound for a critic-only pass
+    char* nws = ar.take<char>(nets_bytes);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_td_errors_rows: workspace %zu < %zu", ws_bytes, ar.off);
+    if (idx) {
+        int rc = samx_replay_gather(obs0, acs, nullptr, nullptr, nullptr, ring_len, ring_start, ob_dim, ac, idx, B,
+                                    g_obs, g_acs, nullptr, nullptr, nullptr, stream);
+        if (rc != SAMX_OK) return rc;
+        obs0 = g_obs; acs = g_acs;
+    }
+    return samx_td_errors(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, td_out, ret, nws, nets_bytes, stream);
+}
+
+size_t samx_td_errors_rows_ws_bytes(const samx_mlp* dc, int64_t B) {
+    if (!dc || B <= 0) return 0;
+    return (size_t)B * dc->in_dim * sizeof(float) + 1024 + samx_nets_ws_bytes(dc, dc, nullptr, B);
+}
+
 int samx_fused_supported(const samx_learner* L, int64_t B) { return L && use_fused(L, B) ? 1 : 0; }
 
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B) {

@@ -29,17 +29,19 @@ from . import ops
 
 class _Slot(object):
     """Pinned staging for the host-drawn numbers of up to K consecutive steps (one packed H2D copy);
-    an event guards reuse.  Row layout (int64 words): [idx_p (B) | idx_a (B) | e_start (1)] then B
-    float64 PER uniforms."""
+    an event guards reuse.  Row layout (int64 words): [idx_p (B) | idx_a (B) | e_start (1)], B float64
+    PER uniforms, then the PREVIOUS step's priority update: B indices and B float64 leaf values."""
 
     def __init__(self, B, K):
-        self.W = 3 * B + 1
+        self.W = 5 * B + 1
         self.words = torch.empty(K, self.W, dtype=torch.int64).pin_memory()
         # numpy views of the pinned words: the host fills them without going through torch ops
         w = self.words.numpy()
         self.np_idx = w[:, :2 * B].reshape(K, 2, B)   # [k][0] = idx_p, [k][1] = idx_a
         self.np_idx_p, self.np_idx_a, self.np_e = w[:, :B], w[:, B:2 * B], w[:, 2 * B]
-        self.np_u = w[:, 2 * B + 1:].view(np.float64)
+        self.np_u = w[:, 2 * B + 1:3 * B + 1].view(np.float64)
+        self.np_prev_idx = w[:, 3 * B + 1:4 * B + 1]
+        self.np_prev_leaf = w[:, 4 * B + 1:].view(np.float64)
         self.event = torch.cuda.Event()
         self.used = False
 
@@ -68,13 +70,19 @@ class UpdateStepDriver(object):
         rb = mu.replay_buffer
         assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
         # static device buffers (their addresses are baked into the captured graphs)
-        self.W = 3 * B + 1
+        self.W = 5 * B + 1
         self.words = torch.zeros(self.K, self.W, dtype=torch.int64, device=dev)
         # step 0's views (what the single-step plan and the checkers read)
         self.idx_p = self.words[0, :B]
         self.idx_a = self.words[0, B:2 * B]
         self.e_start = self.words[0, 2 * B:2 * B + 1]
-        self.u = self.words[0, 2 * B + 1:].view(torch.float64)
+        self.u = self.words[0, 2 * B + 1:3 * B + 1].view(torch.float64)
+        # PER: the previous step's priority update rides in this launch's upload and is applied by the
+        # first kernel of the launch (the host libm pow that produces it is the only host work between
+        # two PER steps, memory.py:376-377)
+        self.prev_idx = self.words[0, 3 * B + 1:4 * B + 1]
+        self.prev_leaf = self.words[0, 4 * B + 1:].view(torch.float64)
+        self._pending = None
         self.iws = torch.zeros(B, dtype=torch.float64, device=dev)
         self.iws32 = torch.zeros(B, **f32)
         hp = d.hps
@@ -141,7 +149,8 @@ class UpdateStepDriver(object):
         mu, d = self.mu, self.d
         if d.hps.rmsify_obs and self.world > 1:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
-        if self.per:  # memory.py:248-309 on the device trees
+        if self.per:  # the pending priority update, then memory.py:248-309 on the device trees
+            mu.replay_buffer.trees.set(self.prev_idx, self.prev_leaf)
             mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
@@ -156,12 +165,12 @@ class UpdateStepDriver(object):
         self._seg_refresh()
 
     def _seg_refresh(self):
-        if self.per:  # TD errors with the POST-update critic (sam_agent.py:693-701)
+        if self.per:  # TD errors with the POST-update critic (sam_agent.py:693-701), rows read in place
             mu = self.mu
             mean, std = mu._mean_std()
-            mu.replay_buffer.batchify_device(self.idx_a, want=('obs0', 'acs'), out=self.gb)
-            ops.td_errors(mu.dc, mu.critic.flat, self.gb['obs0'], self.gb['acs'], self.out.t['targ_q'],
-                          mean, std, mu.ws, out=self.td_post)
+            st = mu.replay_buffer.store
+            ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self.idx_a, self._batch_start,
+                               self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
     def _build_plan(self, K):
@@ -207,6 +216,10 @@ class UpdateStepDriver(object):
             # D batch: uniform pairs (sam.py:372-377 -> memory.py:90), then the PER uniforms
             slot.np_idx_p[0] = np.random.randint(low=0, high=rb.num_entries, size=B)
             slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
+            if self._pending is None:
+                self._pending = self._noop_update()
+            slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._pending
+            self._pending = None
         else:
             # per step: D pairs, then the agent's batch (memory.py:90 twice).  One call of size
             # K*2*B consumes the generator exactly like 2K calls of size B.
@@ -218,6 +231,22 @@ class UpdateStepDriver(object):
                 self.pool.init_pointer()
             slot.np_e[k] = self.pool.pointer
             self.pool.pointer += B
+
+    def _noop_update(self):
+        """A priority update that changes nothing (leaf 0 rewritten with its own value): what the
+        first launch after a flush carries."""
+        cap = self.mu.replay_buffer.st_cap
+        leaf0 = float(self.mu.replay_buffer.trees.sum[cap].item())
+        return np.zeros(self.B, dtype=np.int64), np.full(self.B, leaf0, dtype=np.float64)
+
+    def flush(self):
+        """Apply the priority update still waiting for the next launch (call before reading the trees
+        or sampling from the replay buffer outside the driver)."""
+        if self._pending is not None:
+            idxs, leaf = self._pending
+            rb = self.mu.replay_buffer
+            rb.trees.set(torch.as_tensor(idxs).to(self.dev), torch.as_tensor(leaf).to(self.dev))
+            self._pending = None
 
     def _upload(self, slot, K):
         # ONE packed H2D copy per launch
@@ -257,6 +286,8 @@ class UpdateStepDriver(object):
         slot.np_e[:K] = 0
         if self.per:
             slot.np_u[0] = mu.replay_buffer.draw_uniforms(self.B)
+            self.flush()
+            slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
         torch.cuda.synchronize()
         self.plans[K] = self._build_plan(K)
@@ -288,13 +319,15 @@ class UpdateStepDriver(object):
             self._idx_host.copy_(self.idx_a, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
-            self.mu.replay_buffer.update_priorities(self._idx_host.numpy(), new_priorities)
+            idxs, leaf = self.mu.replay_buffer.leaves_for(self._idx_host.numpy(), new_priorities)
+            self._pending = (idxs.copy(), leaf)   # applied by the first kernel of the next launch
         self.step_no += K
         self.launch_no += 1
 
     def step(self):
-        """One update step (one launch)."""
+        """One update step (one launch); the replay trees are up to date when it returns."""
         self._launch(1)
+        self.flush()
 
     def run(self, n):
         """n consecutive update steps, K per graph launch where the configuration allows it (see
@@ -307,6 +340,7 @@ class UpdateStepDriver(object):
                 K = 1
             self._launch(K)
             n -= K
+        self.flush()
 
     def refresh(self):
         """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""

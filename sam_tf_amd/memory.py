@@ -221,15 +221,21 @@ class PrioritizedRB(RB):
     def sample_uniform(self, batch_size):
         return super().sample(batch_size=batch_size)
 
-    def update_priorities(self, idxs, priorities):
-        """memory.py:344-379 (non-ranked).  Host: asserts + libm pow; device: both trees."""
+    def leaves_for(self, idxs, priorities):
+        """Host half of update_priorities (memory.py:344-379, non-ranked): the asserts, demos_eps,
+        max_priority tracking and leaf = priority ** alpha with the host libm pow.  Returns
+        (idxs int64, leaf float64) ready for the device trees."""
         idxs = np.asarray(idxs, dtype=np.int64).ravel()
         priorities = np.asarray(priorities, dtype=np.float64).ravel()
         assert len(idxs) == len(priorities), "the two arrays must be the same length"
         assert (priorities > 0).all(), "priorities must be positive"
         assert ((0 <= idxs) & (idxs < self.num_entries)).all(), \
             "no element in buffer associated w/ index"
-        leaf = self._leafs(idxs, priorities)
+        return idxs, self._leafs(idxs, priorities)
+
+    def update_priorities(self, idxs, priorities):
+        """memory.py:344-379 (non-ranked).  Host: asserts + libm pow; device: both trees."""
+        idxs, leaf = self.leaves_for(idxs, priorities)
         self.trees.set(torch.as_tensor(idxs).to(self.device), torch.as_tensor(leaf).to(self.device))
 
     # read-back helpers (tests, logging)

@@ -317,6 +317,28 @@ def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None, ret=None):
     return out
 
 
+_TDR_WS = {}
+
+
+def td_errors_rows(dc, pc, obs0_store, acs_store, idx, ring_start, tc1s, mean, std, out, ret=None):
+    """TD errors of the batch rows addressed in place in the replay storages (idx int64[B])."""
+    B = idx.numel()
+    ring_len, ob = obs0_store.shape
+    _chk(obs0_store, F32, (ring_len, ob), 'obs0 store'); _chk(acs_store, F32, (ring_len, dc.in_dim - ob), 'acs store')
+    _chk(idx, I64, (B,), 'idx'); _flat(pc, dc, 'critic params')
+    tc1s = _chk(tc1s.reshape(B), F32, (B,), 'tc1s'); _chk(out, F32, (B,), 'out')
+    mean, std = _ms(mean, std, ob)
+    key = (dc.in_dim, dc.h1, dc.h2, dc.layernorm, B, str(idx.device))
+    if key not in _TDR_WS:
+        _TDR_WS[key] = torch.empty(int(_L().samx_td_errors_rows_ws_bytes(C.byref(dc), B)), dtype=torch.uint8,
+                                   device=idx.device)
+    ws = _TDR_WS[key]
+    check(_L().samx_td_errors_rows(C.byref(dc), ptr(pc), ptr(obs0_store), ptr(acs_store), ptr(idx),
+                                   int(ring_start), int(ring_len), ptr(tc1s), ptr(mean), ptr(std), B, ob,
+                                   ptr(out), _ret(ret), ptr(ws), ws.numel(), stream_ptr()))
+    return out
+
+
 def actor_grad(da, pa, dc, pc, dd, pd, obs0, mean, std, high, q_scale, d_scale, ws, losses=None,
                grad=None, ret=None):
     B, ob = obs0.shape

@@ -114,7 +114,7 @@ class OracleLearner(object):
         self.pa = self.adam('a', self.pa, ga, hp.actor_lr)
         self.pc = self.adam('c', self.pc, gc, hp.critic_lr)
         if self.per:
-            td = NO.td_errors(self.pc, self.dc, b['obs0'], b['acs'], tq, mean, std)
+            td = NO.td_errors(self.pc, self.dc, b['obs0'], b['acs'], tq, mean, std, ret=ret)
             assert relerr(gpu_td, td.ravel()) < 1e-5
             # the new priorities are float32 network outputs (1e-5 class); the TREE arithmetic on
             # them is what must be bit-exact, so both sides get the same float32 priorities
