@@ -44,6 +44,7 @@ class _Slot(object):
         self.np_prev_leaf = w[:, 4 * B + 1:].view(np.float64)
         self.event = torch.cuda.Event()
         self.used = False
+        self.predrawn = False
 
 
 class UpdateStepDriver(object):
@@ -210,16 +211,29 @@ class UpdateStepDriver(object):
         """The reference's host RNG draws for K consecutive steps, in the reference's order."""
         rb = self.mu.replay_buffer
         B = self.B
+        if slot.predrawn:   # the RNG part was done while the previous launch was running
+            slot.predrawn = False
+            self._fill_pending(slot)
+            return
         if slot.used:
             slot.event.synchronize()
+        self._draw_rng(slot, K)
+        self._fill_pending(slot)
+
+    def _fill_pending(self, slot):
         if self.per:
-            # D batch: uniform pairs (sam.py:372-377 -> memory.py:90), then the PER uniforms
-            slot.np_idx_p[0] = np.random.randint(low=0, high=rb.num_entries, size=B)
-            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
             if self._pending is None:
                 self._pending = self._noop_update()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._pending
             self._pending = None
+
+    def _draw_rng(self, slot, K):
+        rb = self.mu.replay_buffer
+        B = self.B
+        if self.per:
+            # D batch: uniform pairs (sam.py:372-377 -> memory.py:90), then the PER uniforms
+            slot.np_idx_p[0] = np.random.randint(low=0, high=rb.num_entries, size=B)
+            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
         else:
             # per step: D pairs, then the agent's batch (memory.py:90 twice).  One call of size
             # K*2*B consumes the generator exactly like 2K calls of size B.
@@ -303,7 +317,7 @@ class UpdateStepDriver(object):
     def plan(self):
         return self.plans.get(1)
 
-    def _launch(self, K):
+    def _launch(self, K, more=False):
         self.prepare(K)
         assert self.mu.replay_buffer.start == self._batch_start, \
             "replay ring moved: call driver.refresh() after appending transitions"
@@ -317,6 +331,13 @@ class UpdateStepDriver(object):
             # sam_agent.py:702), leaves = libm pow on the host, trees updated on the device
             self._td_host.copy_(self.td_post, non_blocking=True)
             self._idx_host.copy_(self.idx_a, non_blocking=True)
+            if more:  # the next step's host RNG draws do not depend on this step: make them now,
+                      # while the GPU works (same generators, same order)
+                nxt = self.slots[(self.launch_no + 1) % len(self.slots)]
+                if nxt.used:
+                    nxt.event.synchronize()
+                self._draw_rng(nxt, 1)
+                nxt.predrawn = True
             torch.cuda.current_stream().synchronize()
             new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
             idxs, leaf = self.mu.replay_buffer.leaves_for(self._idx_host.numpy(), new_priorities)
@@ -338,7 +359,7 @@ class UpdateStepDriver(object):
             # a reshuffle of the expert pool is host work between two steps: keep it out of a launch
             if K > 1 and pool.pointer + K * B >= pool.num_entries:
                 K = 1
-            self._launch(K)
+            self._launch(K, more=n > K)
             n -= K
         self.flush()
 

@@ -273,7 +273,7 @@ def test_d_input_stats_and_randoms():
     assert 0.0 < float(fake.min()) and float(fake.max()) <= 0.3
 
 
-@pytest.mark.parametrize('cfg_name', ['C1', 'C2'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C2', 'C3'])
 def test_multi_step_launch_equals_single_steps(cfg_name):
     """run(n) packs K steps into one graph launch (uniform replay, one process).  It must sample the
     same indices (same host RNG consumption) and leave bit-identical learner state as n x step()."""
@@ -287,8 +287,8 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
     for mode in ('single', 'packed'):
         mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
-        assert drv.K == 4
-        drv.prepare(1); drv.prepare(4)
+        assert drv.K == (1 if cfg['per'] else 4)   # PER: one step per launch, host draws made ahead
+        drv.prepare(1); drv.prepare(drv.K)
         np.random.seed(77); random.seed(77)
         pool.pointer = 0
         if mode == 'single':
@@ -297,8 +297,9 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
         else:
             drv.run(n)   # 4 + 4 + 1 + 1 + 1
         torch.cuda.synchronize()
-        states.append([t.clone() for t in (mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
-                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std)] +
+        extra = [mu.replay_buffer.trees.sum, mu.replay_buffer.trees.min] if cfg['per'] else []
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
+                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std] + extra] +
                       [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer])])
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
