@@ -24,11 +24,12 @@
 // are never stored.  Out-of-range reduction indices (last stage) and the ones row are patched in LDS
 // by the wave that issued the DMA, after its own vmcnt wait and before the barrier.
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace samx {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, NS = 4;
+constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int TILE = BK * 64;            // floats per operand stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) float lds_float;
@@ -120,11 +121,16 @@ __device__ __forceinline__ float frag(const float* S, int base, int kk, int lane
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     if (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    if (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
 }
 
 // KS = 1: 4 waves, wave w owns the 32x32 quadrant w of the tile and runs the whole reduction.
@@ -132,12 +138,12 @@ __device__ __forceinline__ void wait_vm() {
 //         four partial accumulators of a quadrant are added through LDS in slice order at the end.
 //         Used when a launch has too few workgroups to give every SIMD a wave: the serial chain of
 //         dependent MFMAs per wave is what such a launch waits for, and this cuts it by four.
-template <int EPI, bool A_RC, bool B_RC, int KS>
+template <int EPI, bool A_RC, bool B_RC, int KS, int NS>
 __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
     constexpr int NW = 4 * KS;        // waves
     constexpr int DPW = 32 / NW;      // DMAs per wave per operand stage
     constexpr int MPW = (BK / 2) / KS;  // MFMAs per wave per stage
-    __shared__ float lds[NS * 2 * TILE];  // ONE array: [stage][A | B]
+    extern __shared__ float lds[];  // ONE array: [NS stages][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int quad = wave & 3, slice = wave >> 2;
     const int wm = quad >> 1, wn = quad & 1;
@@ -173,9 +179,18 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
         float* Sb = Sa + TILE;
         // stages issued after t and still allowed in flight: t+1 .. min(t+NS-2, T-1)
         const int ahead = min(NS - 2, T - 1 - t);
-        if (ahead >= 2) wait_vm<4 * DPW>();
-        else if (ahead == 1) wait_vm<2 * DPW>();
-        else wait_vm<0>();
+        // 2 * DPW DMAs per stage may stay in flight for each of the `ahead` later stages
+#define SAMX_VM(k) wait_vm<((k) <= NS - 2 ? 2 * (k) * DPW : 0)>()
+        switch (ahead) {
+            case 0: SAMX_VM(0); break;
+            case 1: SAMX_VM(1); break;
+            case 2: SAMX_VM(2); break;
+            case 3: SAMX_VM(3); break;
+            case 4: SAMX_VM(4); break;
+            case 5: SAMX_VM(5); break;
+            default: SAMX_VM(6); break;
+        }
+#undef SAMX_VM
         const int r0 = r_begin + t * BK, rv = r_end - r0;
         if (rv < BK) {  // last, partial stage: this wave zeroes the tail of what it loaded
 #pragma unroll
@@ -262,15 +277,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo
     g.C[(int64_t)i * g.ldc + j] = apply_epi<EPI>(s, i, j, e);
 }
 
-template <int EPI, int KS>
-int launch_ks(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-    const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
-    if (a_rc && !b_rc) gemm_kernel<EPI, true, false, KS><<<grid, 256 * KS, 0, stream>>>(g);
-    else if (a_rc && b_rc) gemm_kernel<EPI, true, true, KS><<<grid, 256 * KS, 0, stream>>>(g);
-    else if (!a_rc && !b_rc) gemm_kernel<EPI, false, false, KS><<<grid, 256 * KS, 0, stream>>>(g);
-    else return fail(SAMX_ERR_UNSUPPORTED, "gemm: operand layout (A free-contiguous, B reduction-contiguous)");
+template <int EPI, bool A_RC, bool B_RC, int KS, int NS>
+int launch_inst(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    constexpr size_t lds = (size_t)NS * 2 * TILE * sizeof(float);
+    static bool attr_done = false;  // per instantiation; > 64 KB of LDS needs the opt-in
+    if (!attr_done && lds > 64 * 1024) {
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI, A_RC, B_RC, KS, NS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    gemm_kernel<EPI, A_RC, B_RC, KS, NS><<<grid, 256 * KS, lds, stream>>>(g);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
+}
+
+template <int EPI, int KS, int NS>
+int launch_ks(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
+    if (a_rc && !b_rc) return launch_inst<EPI, true, false, KS, NS>(g, grid, stream);
+    if (a_rc && b_rc) return launch_inst<EPI, true, true, KS, NS>(g, grid, stream);
+    if (!a_rc && !b_rc) return launch_inst<EPI, false, false, KS, NS>(g, grid, stream);
+    return fail(SAMX_ERR_UNSUPPORTED, "gemm: operand layout (A free-contiguous, B reduction-contiguous)");
 }
 
 template <int EPI>
@@ -279,7 +306,12 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     dim3 grid(cdiv(g.N, BN), cdiv(Mo, BM), g.nsplit);
     // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
     const bool few = (int64_t)grid.x * grid.y * grid.z < 512;
-    int rc = few ? launch_ks<EPI, 4>(g, grid, stream) : launch_ks<EPI, 1>(g, grid, stream);
+    static int ns_small = -1;  // SAMX_GEMM_NS: ring depth of the 16-wave variant (experiment knob)
+    if (ns_small < 0) { const char* e = getenv("SAMX_GEMM_NS"); ns_small = e ? atoi(e) : 4; }
+    int rc;
+    if (few) rc = ns_small == 8 ? launch_ks<EPI, 4, 8>(g, grid, stream)
+                 : ns_small == 6 ? launch_ks<EPI, 4, 6>(g, grid, stream) : launch_ks<EPI, 4, 4>(g, grid, stream);
+    else rc = launch_ks<EPI, 1, 4>(g, grid, stream);
     if (rc != SAMX_OK) return rc;
     if (g.nsplit > 1) {
         int64_t tot = (int64_t)Mo * g.N;

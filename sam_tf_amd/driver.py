@@ -63,7 +63,12 @@ class UpdateStepDriver(object):
         # the host — one process (no collective) and uniform replay (PER's priority refresh computes
         # p ** alpha with the host libm).  The host RNG draws of those steps are made up front, in the
         # reference's order, so the sampled indices are the same as with one launch per step.
-        self.K = int(steps_per_launch) if (self.use_graph and self.world == 1 and not self.per) else 1
+        # N > 1 also packs K steps per host iteration: the D-input sums of all K steps are computed and
+        # all-reduced ONCE (they do not depend on the learner), which leaves one collective per step.
+        self.fused = self.L.fused(B)
+        self.K = int(steps_per_launch) if (self.use_graph and not self.per) else 1
+        if self.world > 1 and not self.fused:
+            self.K = 1   # layer-wise path under N > 1: the three-segment plan, one step per launch
         if self.world > 1 and mu.hps.rmsify_rets and mu.hps.enable_popart:
             raise NotImplementedError('PopArt inside the fused step needs an all-reduce of the return sums '
                                       'between target and loss passes: use SAMAgent.train() for N > 1')
@@ -100,7 +105,6 @@ class UpdateStepDriver(object):
         self.step_no = 0
         self.launch_no = 0
         self.plans = {}
-        self.fused = self.L.fused(B)
         self._make_batch()
 
     def _make_batch(self):
@@ -110,8 +114,9 @@ class UpdateStepDriver(object):
         rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
         B = self.B
         self._batch_start = rb.start
-        # single process + fused path: the d.obs_rms update rides inside the step kernels
-        self.inline_stats = bool(self.fused and self.world == 1 and self.d.hps.rmsify_obs)
+        # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
+        # kernel per launch (all-reduced once per launch when N > 1)
+        self.inline_stats = bool(self.fused and self.d.hps.rmsify_obs)
         r = self.d.obs_rms if self.inline_stats else None
         if r is not None:  # the K batches' [sum, sumsq, count], filled by ONE kernel at the head of a launch
             self.addvecs = torch.zeros(self.K, 2 * self.mu.ob_dim + 1, dtype=torch.float64, device=self.dev)
@@ -148,7 +153,7 @@ class UpdateStepDriver(object):
 
     def _seg_grads(self, k=0):
         mu, d = self.mu, self.d
-        if d.hps.rmsify_obs and self.world > 1:
+        if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
         if self.per:  # the pending priority update, then memory.py:248-309 on the device trees
             mu.replay_buffer.trees.set(self.prev_idx, self.prev_leaf)
@@ -174,36 +179,45 @@ class UpdateStepDriver(object):
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
+    def _capture(self, run):
+        if not self.use_graph:
+            return run
+        # warm-up on a side stream (module loads, LDS attributes, side streams), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run()
+        return g.replay
+
     def _build_plan(self, K):
-        d = self.d
+        """The list of callables one launch of K steps executes in order (graph replays and, for
+        N > 1, the collectives between them)."""
+        d, L = self.d, self.L
         ar = self.comm.allreduce_
         if self.world == 1:
-            segs = [[(lambda: self._seg_sums(K))] +
-                    [(lambda k=k: (self._seg_inputs(k), self._seg_grads(k))) for k in range(K)]]
-            colls = [None]
-        else:
-            segs = [[self._seg_inputs], [self._seg_grads], [self._seg_apply]]
-            colls = [(lambda: ar(d.obs_rms.addvec)) if d.hps.rmsify_obs else None,
-                     lambda: ar(self.L.grads), None]
-        plan = []
-        for fns, coll in zip(segs, colls):
-            run = (lambda fns=fns: [f() for f in fns])
-            if self.use_graph:
-                # warm-up on a side stream (module loads, LDS attributes), then capture
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    run()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    run()
-                plan.append(g.replay)
-            else:
-                plan.append(run)
-            if coll is not None:
-                plan.append(coll)
+            return [self._capture(lambda: [self._seg_sums(K)] +
+                                  [(self._seg_inputs(k), self._seg_grads(k)) for k in range(K)])]
+        if self.inline_stats or (self.fused and not d.hps.rmsify_obs):
+            # N > 1, fused path: [sums of K steps] -> ONE all-reduce of the K float64 sum vectors ->
+            # per step: gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
+            plan = []
+            if self.inline_stats:
+                plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
+            apply_ = self._capture(self._seg_apply)
+            for k in range(K):
+                plan += [self._capture(lambda k=k: self._seg_grads(k)), lambda: ar(L.grads), apply_]
+            return plan
+        assert K == 1
+        # N > 1, layer-wise path: one step per launch, three segments
+        plan = [self._capture(self._seg_inputs)]
+        if d.hps.rmsify_obs:
+            plan.append(lambda: ar(d.obs_rms.addvec))
+        plan += [self._capture(self._seg_grads), lambda: ar(L.grads), self._capture(self._seg_apply)]
         return plan
 
     # ------------------------------------------------------------------ host side of a step

@@ -307,8 +307,8 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
 
 class _TwinComm(object):
     """A 2-rank communicator whose other rank is an identical twin of this process: SUM all-reduce
-    doubles, broadcast is the identity.  Drives the N > 1 plan of the driver (three graph segments
-    around two collectives, local clip copies, 1/N inside the optimiser pass) on one GPU."""
+    doubles, broadcast is the identity.  Drives the N > 1 plans of the driver (graph segments around
+    the collectives, local clip copies, 1/N inside the optimiser pass) on one GPU."""
 
     def Get_rank(self):
         return 0
@@ -340,7 +340,8 @@ def test_two_rank_plan_matches_oracle(cfg_name):
     else:
         cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
     mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
-    assert drv.world == 2 and drv.K == 1 and not drv.inline_stats
+    assert drv.world == 2 and drv.inline_stats == (cfg_name != 'ragged')
+    assert drv.K == (16 if cfg_name == 'C1' else 1)   # uniform replay on the fused path packs K steps
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
     K = 4
@@ -361,6 +362,34 @@ def test_two_rank_plan_matches_oracle(cfg_name):
     assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
     assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
+
+
+def test_two_rank_packed_launch_equals_single_steps():
+    """N > 1, fused path: K steps per host iteration (one all-reduce of the K D-input sum vectors, then
+    one gradient all-reduce per step) leave the learner bit-identical to K single-step launches."""
+    import random
+    import bench
+    from sam_tf_amd.driver import UpdateStepDriver
+    cfg = dict(bench.CONFIGS['C1'], mem=4096)
+    states = []
+    for mode in ('single', 'packed'):
+        mu, d, pool, _ = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 5, True)
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
+        assert drv.K == 4 and drv.world == 2
+        drv.prepare(1); drv.prepare(4)
+        assert len(drv.plans[4]) == 2 + 3 * 4
+        np.random.seed(78); random.seed(78)
+        pool.pointer = 0
+        if mode == 'single':
+            for _ in range(9):
+                drv.step()
+        else:
+            drv.run(9)   # 4 + 4 + 1
+        torch.cuda.synchronize()
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
+                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
+    for a, b in zip(*states):
+        assert torch.equal(a.cpu(), b.cpu())
 
 
 def test_train_with_launcher_options():
