@@ -7,7 +7,8 @@ One "step" = 1 discriminator update + 1 actor/critic update (+ PER refresh) + Po
 one replayed minibatch (sam_tf_amd/driver.py; reference loop body sam.py:323-433 with
 d_steps = g_steps = 1).  Inputs (replay storage, expert pool, weights, optimiser state) are resident
 in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), each rank its
-own replay shard and minibatch (weak scaling), gradients and running-mean sums all-reduced.
+own replay shard and minibatch (weak scaling), gradients and running-mean sums all-reduced (RCCL on
+the launch stream, sam_tf_amd/rccl.py; captured inside the K-step graph when that plan completes).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
   roofline     — the dominant device pass of the step, timed with HIP events on the launch stream
@@ -181,69 +182,127 @@ def main():
         raise SystemExit('bench.py needs a GPU: the update step has no CPU path')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    rehearse = world == 1 and os.environ.get('SAMX_BENCH_REHEARSE') == '1'
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node N for --gpus N'
 
     from sam_tf_amd.comm import TorchComm
-    comm = TorchComm(device)
+    if rehearse:
+        # one-GPU rehearsal of the N > 1 flow below (tools/rehearse_nccl.py): a real 1-rank RCCL group
+        # carries every collective, the communicator reports 2 identical ranks.  Not a scaling number.
+        import torch.distributed as dist
+        from tools.rehearse_nccl import TwinOverRccl
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29617', rank=0, world_size=1,
+                                device_id=device)
+        comm = TwinOverRccl(device, os.environ.get('SAMX_RCCL_DIRECT', '1') != '0')
+        world = 2
+    else:
+        comm = TorchComm(device)
+        if world > 1 and os.environ.get('SAMX_RCCL_DIRECT', '1') != '0':
+            comm.enable_direct()   # all-reduces on the launch stream through librccl (sam_tf_amd/rccl.py)
     cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher,
                nstep=96 if args.launcher and not CONFIGS[args.config]['per'] else 0)
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
-    drv.prepare(1)
-    drv.prepare(drv.K)
-    drv.run(args.warmup)
-    comm.Barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    drv.run(args.steps)   # K consecutive steps per graph launch where nothing needs the host in between
-    torch.cuda.synchronize(); comm.Barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
-    finite = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
 
+    def timed():
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
+        drv.prepare(1)
+        drv.prepare(drv.K)
+        drv.run(args.warmup)
+        torch.cuda.synchronize(); comm.Barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drv.run(args.steps)   # K consecutive steps per graph launch where nothing needs the host in between
+        torch.cuda.synchronize(); comm.Barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    def result_for(el, passes, collectives):
+        finite = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
+        # Dominant kernel: the network passes of the step.  Fused path (64x64 nets): ONE launch of
+        # samx::fused::step_kernel carries every matmul of the step, so its algorithmic work is the whole
+        # F of SURVEY.md 8(d) and `achieved` = F / its launch duration.  Layer-wise path: the same F over
+        # the duration of the three concurrent GEMM chains.
+        dom = passes['network_passes']
+        achieved = flops_per_step(cfg) / dom / 1e12
+        return {
+            'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'],
+            'value': world * args.steps / el, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %s: obs %d, act %d, %dx%d MLPs, batch %d per GPU, %s replay (%d rows '
+                                   'resident), D gradient penalty, rmsify_obs%s' %
+                                   (args.config, cfg['name'], cfg['ob'], cfg['ac'], cfg['h'][0], cfg['h'][1],
+                                    cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
+                                    mu.replay_buffer.num_entries, (', with_layernorm' if cfg.get('ln') else '') +
+                                    (', rmsify_rets+popart' if cfg.get('ret') else '') +
+                                    (', n-step returns n=%d' % cfg['nstep'] if cfg.get('nstep') else '')),
+                       'parallelism': ('dp%d' % world) + (' (one-GPU rehearsal with a twin rank)' if rehearse else ''), 'hip_graph': not args.no_graph,
+                       'steps_per_graph_launch': drv.K, 'collectives': collectives, 'finite_params': finite},
+            'roofline': {'bound': 'mfma',
+                         'kernel': ('samx::fused::step_kernel (whole-network fused, all three roles)' if drv.fused
+                                    else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
+                                         'on three streams'),
+                         'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_TFLOPS,
+                         'traffic': pmc_traffic(args.config + ('-ln' if cfg.get('ln') else '')),
+                         'kernel_us': dom * 1e6, 'flops_per_launch': flops_per_step(cfg),
+                         'note': ('latency-bound: %.1f MFLOP and < 1 MB per launch; neither the MFMA nor the HBM '
+                                  'roofline binds (DESIGN.md 3.1)' % (flops_per_step(cfg) / 1e6)) if drv.fused
+                                 else 'fp32 MFMA (exact f32) peak 157.3 TFLOP/s',
+                         'pass_us': {k: v * 1e6 for k, v in passes.items()}},
+        }
+
+    host_label = 'none' if world == 1 else ('rccl on the launch stream, issued by the host between graph '
+                                            'segments' if comm.capturable else
+                                            'torch.distributed all_reduce between graph segments')
+    want_in_graph = drv.collectives_in_graph
+    # N > 1: first the plan whose collectives the host issues between graph segments ...
+    drv.set_collectives(False)
+    el = timed()
     passes = time_passes(drv, cfg)
-    # Dominant kernel: the network passes of the step.  Fused path (64x64 nets): ONE launch of
-    # samx::fused::step_kernel carries every matmul of the step, so its algorithmic work is the whole
-    # F of SURVEY.md 8(d) and `achieved` = F / its launch duration.  Layer-wise path: the same F over
-    # the duration of the three concurrent GEMM chains.
-    dom = passes['network_passes']
-    achieved = flops_per_step(cfg) / dom / 1e12
-    result = {
-        'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'],
-        'value': world * args.steps / el, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s %s: obs %d, act %d, %dx%d MLPs, batch %d per GPU, %s replay (%d rows '
-                               'resident), D gradient penalty, rmsify_obs%s' %
-                               (args.config, cfg['name'], cfg['ob'], cfg['ac'], cfg['h'][0], cfg['h'][1],
-                                cfg['B'], 'prioritized' if cfg['per'] else 'uniform',
-                                mu.replay_buffer.num_entries, (', with_layernorm' if cfg.get('ln') else '') +
-                                (', rmsify_rets+popart' if cfg.get('ret') else '') +
-                                (', n-step returns n=%d' % cfg['nstep'] if cfg.get('nstep') else '')),
-                   'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
-                   'steps_per_graph_launch': drv.K, 'finite_params': finite},
-        'roofline': {'bound': 'mfma',
-                     'kernel': ('samx::fused::step_kernel (whole-network fused, all three roles)' if drv.fused
-                                else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
-                                     'on three streams'),
-                     'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': pmc_traffic(args.config + ('-ln' if cfg.get('ln') else '')),
-                     'kernel_us': dom * 1e6, 'flops_per_launch': flops_per_step(cfg),
-                     'note': ('latency-bound: %.1f MFLOP and < 1 MB per launch; neither the MFMA nor the HBM '
-                              'roofline binds (DESIGN.md 3.1)' % (flops_per_step(cfg) / 1e6)) if drv.fused
-                             else 'fp32 MFMA (exact f32) peak 157.3 TFLOP/s',
-                     'pass_us': {k: v * 1e6 for k, v in passes.items()}},
-    }
+    result = result_for(el, passes, host_label)
+    if want_in_graph:
+        # ... then the plan with the all-reduces captured INSIDE the K-step graph, under a watchdog: no
+        # multi-GPU box was available while this was written, so if that plan does not come back the
+        # rank reports the measurement it already has instead of hanging the job.
+        import threading
+
+        def bail():
+            if rank == 0:
+                result['config']['collectives'] += ' (in-graph plan did not complete: watchdog)'
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get('SAMX_BENCH_WATCHDOG_S', '90')), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            drv.set_collectives(True)
+            el_g = timed()
+            dog.cancel()
+            if el_g < el:
+                result = result_for(el_g, passes, 'rccl all-reduces captured inside the %d-step hipGraph' % drv.K)
+                result['config']['ms_per_step_host_issued_collectives'] = el / args.steps * 1e3
+            else:
+                result['config']['ms_per_step_in_graph_collectives'] = el_g / args.steps * 1e3
+        except Exception as e:  # noqa: BLE001 - keep the measurement we have; other ranks' watchdogs end them
+            dog.cancel()
+            result['config']['collectives'] += ' (in-graph plan failed: %s)' % (str(e)[:120],)
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
+        if comm.direct is not None:
+            comm.direct.destroy()
         dist.destroy_process_group()
 
 

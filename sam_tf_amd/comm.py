@@ -18,6 +18,25 @@ class TorchComm(object):
     def __init__(self, device=None):
         self.active = dist.is_available() and dist.is_initialized()
         self.device = device
+        self.direct = None   # sam_tf_amd.rccl.RcclComm once enable_direct() succeeded
+
+    def enable_direct(self):
+        """Device all-reduces go through librccl on the caller's stream (capturable into hipGraphs)
+        instead of the process group's side stream.  Returns True on success; on any failure the
+        communicator keeps using torch.distributed."""
+        if not (self.active and self.Get_size() > 1 and dist.get_backend() == 'nccl'):
+            return False
+        try:
+            from .rccl import RcclComm
+            self.direct = RcclComm(self.device if self.device is not None else torch.device('cuda'))
+        except Exception as e:  # noqa: BLE001 - any failure means: stay on torch.distributed
+            print('sam_tf_amd.comm: direct RCCL unavailable (%s); using torch.distributed' % (e,), flush=True)
+            self.direct = None
+        return self.direct is not None
+
+    @property
+    def capturable(self):
+        return self.direct is not None
 
     def Get_rank(self):
         return dist.get_rank() if self.active else 0
@@ -33,6 +52,8 @@ class TorchComm(object):
     def allreduce_(self, t):
         """In-place SUM over ranks of a torch tensor (CUDA -> RCCL, CPU -> gloo)."""
         if self.active and self.Get_size() > 1:
+            if self.direct is not None and t.is_cuda:
+                return self.direct.all_reduce_(t)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 

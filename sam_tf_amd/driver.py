@@ -21,6 +21,8 @@ replay shard and a minibatch; only gradients and running-mean sums are exchanged
 """
 import random as _random
 
+import os
+
 import numpy as np
 import torch
 
@@ -69,6 +71,11 @@ class UpdateStepDriver(object):
         self.K = int(steps_per_launch) if (self.use_graph and not self.per) else 1
         if self.world > 1 and not self.fused:
             self.K = 1   # layer-wise path under N > 1: the three-segment plan, one step per launch
+        # N > 1 with a communicator whose all-reduce runs on the caller's stream (sam_tf_amd.rccl): the
+        # collectives are captured INSIDE the K-step graph, the host issues one launch per K steps
+        self.collectives_in_graph = bool(self.world > 1 and self.fused and self.use_graph and
+                                         getattr(self.comm, 'capturable', False) and
+                                         os.environ.get('SAMX_RCCL_GRAPH', '1') != '0')
         if self.world > 1 and mu.hps.rmsify_rets and mu.hps.enable_popart:
             raise NotImplementedError('PopArt inside the fused step needs an all-reduce of the return sums '
                                       'between target and loss passes: use SAMAgent.train() for N > 1')
@@ -179,8 +186,8 @@ class UpdateStepDriver(object):
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
-    def _capture(self, run):
-        if not self.use_graph:
+    def _capture(self, run, small=False):
+        if not self.use_graph or (small and os.environ.get('SAMX_DIRECT_SEGS') == '1'):
             return run
         # warm-up on a side stream (module loads, LDS attributes, side streams), then capture
         side = torch.cuda.Stream()
@@ -190,7 +197,8 @@ class UpdateStepDriver(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the process group's watchdog thread may touch events while we capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             run()
         return g.replay
 
@@ -202,15 +210,29 @@ class UpdateStepDriver(object):
         if self.world == 1:
             return [self._capture(lambda: [self._seg_sums(K)] +
                                   [(self._seg_inputs(k), self._seg_grads(k)) for k in range(K)])]
+        if self.collectives_in_graph:
+            def run():
+                if self.inline_stats:
+                    self._seg_sums(K)
+                    ar(self.addvecs[:K])
+                for k in range(K):
+                    self._seg_grads(k)
+                    ar(L.grads)
+                    self._seg_apply()
+            return [self._capture(run)]
         if self.inline_stats or (self.fused and not d.hps.rmsify_obs):
             # N > 1, fused path: [sums of K steps] -> ONE all-reduce of the K float64 sum vectors ->
             # per step: gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
             plan = []
             if self.inline_stats:
                 plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
-            apply_ = self._capture(self._seg_apply)
-            for k in range(K):
-                plan += [self._capture(lambda k=k: self._seg_grads(k)), lambda: ar(L.grads), apply_]
+            # the optimiser pass of step k and the gradient pass of step k + 1 share one graph: per
+            # step the host issues ONE graph launch and ONE all-reduce
+            plan += [self._capture(lambda: self._seg_grads(0), True), lambda: ar(L.grads)]
+            for k in range(1, K):
+                plan += [self._capture(lambda k=k: (self._seg_apply(), self._seg_grads(k)), True),
+                         lambda: ar(L.grads)]
+            plan.append(self._capture(self._seg_apply, True))
             return plan
         assert K == 1
         # N > 1, layer-wise path: one step per launch, three segments
@@ -376,6 +398,16 @@ class UpdateStepDriver(object):
             self._launch(K, more=n > K)
             n -= K
         self.flush()
+
+    def set_collectives(self, in_graph):
+        """Choose between collectives captured inside the K-step graph (needs a capturable
+        communicator) and collectives issued by the host between graph segments; re-plans."""
+        in_graph = bool(in_graph and self.world > 1 and self.fused and self.use_graph and
+                        getattr(self.comm, 'capturable', False))
+        if in_graph != self.collectives_in_graph:
+            self.collectives_in_graph = in_graph
+            self.plans = {}
+        return in_graph
 
     def refresh(self):
         """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""

@@ -377,7 +377,7 @@ def test_two_rank_packed_launch_equals_single_steps():
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
         assert drv.K == 4 and drv.world == 2
         drv.prepare(1); drv.prepare(4)
-        assert len(drv.plans[4]) == 2 + 3 * 4
+        assert len(drv.plans[4]) == 2 + 2 * 4 + 1
         np.random.seed(78); random.seed(78)
         pool.pointer = 0
         if mode == 'single':
@@ -390,6 +390,52 @@ def test_two_rank_packed_launch_equals_single_steps():
                                            d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_in_graph_rccl_collectives_equal_host_issued():
+    """sam_tf_amd.rccl: all-reduces through librccl on the launch stream, captured inside the K-step
+    graph.  One-GPU rehearsal (real 1-rank RCCL communicator + twin rank): the in-graph plan, the plan
+    with host-issued collectives and single-step launches leave bit-identical learners."""
+    import random
+    import socket
+    import torch.distributed as dist
+    import bench
+    from tools.rehearse_nccl import TwinOverRccl
+    from sam_tf_amd.driver import UpdateStepDriver
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        cfg = dict(bench.CONFIGS['C1'], mem=4096)
+        states = []
+        for mode in ('single', 'host', 'graph'):
+            comm = TwinOverRccl(dev, True)
+            assert comm.capturable
+            mu, d, pool, _ = bench.build_learner(cfg, comm, dev, 5, True)
+            drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
+            assert drv.collectives_in_graph and drv.K == 4
+            assert drv.set_collectives(mode == 'graph') == (mode == 'graph')
+            drv.prepare(1); drv.prepare(4)
+            assert len(drv.plans[4]) == (1 if mode == 'graph' else 2 + 2 * 4 + 1)
+            np.random.seed(79); random.seed(79)
+            pool.pointer = 0
+            if mode == 'single':
+                for _ in range(9):
+                    drv.step()
+            else:
+                drv.run(9)
+            torch.cuda.synchronize()
+            states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
+                                               d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
+            comm.direct.destroy()
+        for other in states[1:]:
+            for a, b in zip(states[0], other):
+                assert torch.equal(a.cpu(), b.cpu())
+    finally:
+        dist.destroy_process_group()
 
 
 def test_train_with_launcher_options():
