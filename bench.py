@@ -208,8 +208,7 @@ def main():
 
     def timed():
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
-        drv.prepare(1)
-        drv.prepare(drv.K)
+        drv.prepare_all()
         drv.run(args.warmup)
         torch.cuda.synchronize(); comm.Barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()

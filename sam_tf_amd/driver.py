@@ -266,21 +266,29 @@ class UpdateStepDriver(object):
     def _draw_rng(self, slot, K):
         rb = self.mu.replay_buffer
         B = self.B
+        N = rb.num_entries
+        wrap = self.pool.pointer + B >= self.pool.num_entries
+        if wrap:
+            assert K == 1, "a reshuffle of the expert pool cannot fall inside a multi-step launch"
+        # reference order inside one step: D's policy pairs (sam.py:372-377 -> memory.py:90), the
+        # expert batch (demo_dataset.py:33-40: np.random.shuffle when the pool wraps), then the agent's
+        # batch in mu.train() (memory.py:90, or memory.py:278 with `random` for PER)
         if self.per:
-            # D batch: uniform pairs (sam.py:372-377 -> memory.py:90), then the PER uniforms
-            slot.np_idx_p[0] = np.random.randint(low=0, high=rb.num_entries, size=B)
-            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
+            slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
+        elif wrap:
+            slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
         else:
-            # per step: D pairs, then the agent's batch (memory.py:90 twice).  One call of size
-            # K*2*B consumes the generator exactly like 2K calls of size B.
-            slot.np_idx[:K] = np.random.randint(low=0, high=rb.num_entries, size=(K, 2, B))
-        # expert batch pointer arithmetic (demo_dataset.py:33-40)
+            # one call of size K*2*B consumes the generator exactly like 2K calls of size B
+            slot.np_idx[:K] = np.random.randint(low=0, high=N, size=(K, 2, B))
         for k in range(K):
             if self.pool.pointer + B >= self.pool.num_entries:
-                assert k == 0, "a reshuffle of the expert pool cannot fall inside a multi-step launch"
                 self.pool.init_pointer()
             slot.np_e[k] = self.pool.pointer
             self.pool.pointer += B
+        if self.per:
+            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
+        elif wrap:
+            slot.np_idx_a[0] = np.random.randint(low=0, high=N, size=B)
 
     def _noop_update(self):
         """A priority update that changes nothing (leaf 0 rewritten with its own value): what the
@@ -349,6 +357,13 @@ class UpdateStepDriver(object):
         self.pool.pointer = ptr0
         torch.cuda.synchronize()
 
+    def prepare_all(self):
+        """Capture every launch size run() can pick (K, K/2, ..., 1)."""
+        K = self.K
+        while K >= 1:
+            self.prepare(K)
+            K //= 2
+
     @property
     def plan(self):
         return self.plans.get(1)
@@ -391,10 +406,11 @@ class UpdateStepDriver(object):
         __init__); same arithmetic and same sampled indices as n calls of step()."""
         B, pool = self.B, self.pool
         while n > 0:
-            K = self.K if n >= self.K else 1
-            # a reshuffle of the expert pool is host work between two steps: keep it out of a launch
-            if K > 1 and pool.pointer + K * B >= pool.num_entries:
-                K = 1
+            # the largest launch (K, K/2, K/4 ...) that fits the steps left and ends before the next
+            # reshuffle of the expert pool (host work between two steps, kept out of a launch)
+            K = self.K
+            while K > 1 and (K > n or pool.pointer + K * B >= pool.num_entries):
+                K //= 2
             self._launch(K, more=n > K)
             n -= K
         self.flush()

@@ -290,17 +290,19 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
         assert drv.K == (1 if cfg['per'] else 4)   # PER: one step per launch, host draws made ahead
         drv.prepare(1); drv.prepare(drv.K)
         np.random.seed(77); random.seed(77)
-        pool.pointer = 0
+        # the expert pool wraps (host reshuffle, np.random) after 6 of the 11 steps
+        pool.pointer = pool.num_entries - 7 * drv.B
         if mode == 'single':
             for _ in range(n):
                 drv.step()
         else:
-            drv.run(n)   # 4 + 4 + 1 + 1 + 1
+            drv.run(n)   # 4 + 2 | reshuffle + 1 | 4
         torch.cuda.synchronize()
         extra = [mu.replay_buffer.trees.sum, mu.replay_buffer.trees.min] if cfg['per'] else []
         states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
                                            d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std] + extra] +
-                      [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer])])
+                      [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer]),
+                       pool.obs0.clone()])
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
 

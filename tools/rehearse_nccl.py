@@ -54,7 +54,7 @@ def main():
     mu, d, pool, drv = bench.build_learner(cfg, comm, dev, 0, True)
     drv.set_collectives(a.in_graph)
     print('in_graph', drv.collectives_in_graph, 'world', drv.world, 'K', drv.K, 'inline_stats', drv.inline_stats, flush=True)
-    drv.prepare(1); drv.prepare(drv.K)
+    drv.prepare_all()
     drv.run(200)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
