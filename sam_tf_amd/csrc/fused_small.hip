@@ -763,54 +763,129 @@ __global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
 // finalize: grad[i] = sum over slots (fixed order) [+ wd * W for decayed kernels], per-block sums of
 // squares for the clip norm, and the scalar losses.  One launch covers up to three optimiser segments.
 // ------------------------------------------------------------------------------------------------
+// gradient-penalty scalars from the tiles' sums of squares: computed redundantly by every wave (one
+// batch of loads + a fixed shuffle tree, identical everywhere) so that no barrier sits between the
+// slot loads of the caller and their use
+__device__ __forceinline__ void gp_scalars(const FinalizeArgs& f, int lane, float& k, double& gp_loss) {
+    k = 0.f; gp_loss = 0.0;
+    if (!f.gp_part) return;
+    double so = 0.0, sa = 0.0;
+    for (int i = lane; i < f.gp_tiles; i += 64) { so += f.gp_part[2 * i]; sa += f.gp_part[2 * i + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o, 64); sa += __shfl_xor(sa, o, 64); }
+    const double N = sqrt(so / ((double)f.B * f.ob) + sa / ((double)f.B * f.ac));
+    k = (float)((double)f.gp_coeff * 2.0 * (N - 1.0) / N);
+    gp_loss = (N - 1.0) * (N - 1.0);
+}
+
+// scalar losses, the commit of the inline d.obs_rms update and the step counters: one wave of the
+// EXTRA last block, so this serial chain runs beside the gradient blocks instead of after one of them
+__device__ inline void finalize_scalars(const FinalizeArgs& f, int tid) {
+    float kgp; double gp_loss;
+    gp_scalars(f, tid, kgp, gp_loss);
+    auto wsum = [](double x) {
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        return x;
+    };
+    if (f.agent_loss_part) {
+        double h = 0.0, q = 0.0, dd = 0.0;
+        for (int k = tid; k < f.agent_tiles; k += 64) {
+            h += (double)f.agent_loss_part[4 * k];
+            q += (double)f.agent_loss_part[4 * k + 1];
+            dd += (double)f.agent_loss_part[4 * k + 2];
+        }
+        h = wsum(h); q = wsum(q); dd = wsum(dd);
+        if (tid == 0) {
+            const double B = (double)f.B;
+            const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
+            f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl;
+            f.actor_losses[2] = (float)(ql + dl);
+            const double tl = h / B * f.td_scale;
+            const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
+            f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl;
+            f.critic_losses[2] = (float)(tl + wl);
+            f.critic_losses[3] = 0.f;  // no n-step term on this path
+        }
+    }
+    if (f.disc_loss_part) {
+        double pc = 0, ec = 0, pe = 0, ee = 0, pg = 0, eg = 0;
+        const int tb = f.disc_tiles_b;
+        for (int k = tid; k < tb; k += 64) {
+            pc += (double)f.disc_loss_part[4 * k]; pe += (double)f.disc_loss_part[4 * k + 1];
+            pg += (double)f.disc_loss_part[4 * k + 2];
+            ec += (double)f.disc_loss_part[4 * (tb + k)]; ee += (double)f.disc_loss_part[4 * (tb + k) + 1];
+            eg += (double)f.disc_loss_part[4 * (tb + k) + 2];
+        }
+        pc = wsum(pc); ec = wsum(ec); pe = wsum(pe); ee = wsum(ee); pg = wsum(pg); eg = wsum(eg);
+        if (tid == 0) {
+            const double B = (double)f.B;
+            const double pl = pc / B, el = ec / B, em = (pe + ee) / (2.0 * B),
+                         eloss = -(double)f.ent_scale * em;
+            f.disc_losses[0] = (float)pl; f.disc_losses[1] = (float)el; f.disc_losses[2] = (float)em;
+            f.disc_losses[3] = (float)eloss; f.disc_losses[4] = (float)(pg / B);
+            f.disc_losses[5] = (float)(eg / B);
+            f.disc_losses[6] = (float)gp_loss;
+            f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * gp_loss);
+        }
+    }
+    if (f.rms_sums) {  // commit of the inline d.obs_rms.update (mpi_running_mean_std.py:40-45,31-34)
+        const int dim = f.ob;
+        const double add_n = f.rms_addvec[2 * dim];
+        const double cnt = f.rms_sums[2 * dim] + add_n;  // every lane reads the old count first
+        for (int c = tid; c < dim; c += 64) {
+            const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
+                         s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
+            f.rms_sums[c] = s1;
+            f.rms_sums[dim + c] = s2;
+            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+            f.rms_mean[c] = mean;
+            f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+        }
+        if (tid == 0) f.rms_sums[2 * dim] = cnt;
+    }
+    if (tid == 0)
+        for (int k = 0; k < f.nseg; ++k)
+            if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
     __shared__ double shd[4];
-    __shared__ float sh_k;
     const int tid = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {  // the extra block
+        if (tid < 64) finalize_scalars(f, tid);
+        return;
+    }
     // which segment does this block belong to?
     int seg = 0, b = blockIdx.x;
     while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
     const Segment& s = f.seg[seg];
-    if (tid < 64) {
-        // gradient-penalty scalars from the tiles' sums of squares: one wave, one batch of loads,
-        // fixed shuffle tree (identical in every block)
-        double so = 0.0, sa = 0.0;
-        if (f.gp_part)
-            for (int i = tid; i < f.gp_tiles; i += 64) { so += f.gp_part[2 * i]; sa += f.gp_part[2 * i + 1]; }
-        for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o, 64); sa += __shfl_xor(sa, o, 64); }
-        if (tid == 0) {
-            float k = 0.f;
-            if (f.gp_part) {
-                const double N = sqrt(so / ((double)f.B * f.ob) + sa / ((double)f.B * f.ac));
-                k = (float)((double)f.gp_coeff * 2.0 * (N - 1.0) / N);
-                shd[0] = (N - 1.0) * (N - 1.0);
-            }
-            sh_k = k;
-        }
-    }
-    __syncthreads();
-    const double gp_loss = shd[0];
-    __syncthreads();
-    const float kgp = sh_k;
-    // 4 lanes per element: lane q adds slots q, q+4, ... in increasing order, then a fixed 2-level tree
+    // 4 lanes per element: lane q adds slots q, q+4, ... in increasing order (8 loads in flight per
+    // batch), then a fixed 2-level tree.  The GP scalars are computed while the first batch is in flight.
     const int q = tid & 3;
+    const int64_t step = (int64_t)s.nblocks * 64;
+    int64_t i = (int64_t)b * 64 + (tid >> 2);
+    float t[8];
+    auto issue = [&](int64_t e, int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 4 * j;
+            t[j] = (e < s.n && k < s.nslots) ? s.partials[e + (int64_t)k * s.slot_stride] : 0.f;
+        }
+    };
+    issue(i, q);
+    float kgp; double gp_loss;
+    gp_scalars(f, tid & 63, kgp, gp_loss);
     double acc = 0.0;
-    for (int64_t i = (int64_t)b * 64 + (tid >> 2); i < s.n; i += (int64_t)s.nblocks * 64) {
-        const float* src = s.partials + i;
+    for (; i < s.n; i += step) {
         float g0 = 0.f, g1 = 0.f;  // plain slots, gp-scaled slots
-        int k = q;
-        for (; k + 12 < s.scaled_from; k += 16) {
-            const float t0 = src[(int64_t)k * s.slot_stride], t1 = src[(int64_t)(k + 4) * s.slot_stride],
-                        t2 = src[(int64_t)(k + 8) * s.slot_stride], t3 = src[(int64_t)(k + 12) * s.slot_stride];
-            g0 += t0; g0 += t1; g0 += t2; g0 += t3;
+        for (int k0 = q; k0 < s.nslots; k0 += 32) {
+            if (k0 != q) issue(i, k0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool plain = k0 + 4 * j < s.scaled_from;
+                g0 += plain ? t[j] : 0.f;
+                g1 += plain ? 0.f : t[j];
+            }
         }
-        for (; k < s.scaled_from; k += 4) g0 += src[(int64_t)k * s.slot_stride];
-        for (; k + 12 < s.nslots; k += 16) {
-            const float t0 = src[(int64_t)k * s.slot_stride], t1 = src[(int64_t)(k + 4) * s.slot_stride],
-                        t2 = src[(int64_t)(k + 8) * s.slot_stride], t3 = src[(int64_t)(k + 12) * s.slot_stride];
-            g1 += t0; g1 += t1; g1 += t2; g1 += t3;
-        }
-        for (; k < s.nslots; k += 4) g1 += src[(int64_t)k * s.slot_stride];
         g0 += __shfl_xor(g0, 1, 64); g0 += __shfl_xor(g0, 2, 64);
         g1 += __shfl_xor(g1, 1, 64); g1 += __shfl_xor(g1, 2, 64);
         float g = g0 + kgp * g1;
@@ -820,77 +895,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
             s.grad[i] = g;
             acc += (double)g * (double)g;
         }
+        if (i + step < s.n) issue(i + step, q);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) shd[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
-    // scalar losses: the last block's first wave; every lane loads one tile's partial sums
-    if (blockIdx.x == gridDim.x - 1 && tid < 64) {
-        auto wsum = [](double x) {
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-            return x;
-        };
-        if (f.agent_loss_part) {
-            double h = 0.0, q = 0.0, dd = 0.0;
-            for (int k = tid; k < f.agent_tiles; k += 64) {
-                h += (double)f.agent_loss_part[4 * k];
-                q += (double)f.agent_loss_part[4 * k + 1];
-                dd += (double)f.agent_loss_part[4 * k + 2];
-            }
-            h = wsum(h); q = wsum(q); dd = wsum(dd);
-            if (tid == 0) {
-                const double B = (double)f.B;
-                const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
-                f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl;
-                f.actor_losses[2] = (float)(ql + dl);
-                const double tl = h / B * f.td_scale;
-                const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
-                f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl;
-                f.critic_losses[2] = (float)(tl + wl);
-                f.critic_losses[3] = 0.f;  // no n-step term on this path
-            }
-        }
-        if (f.disc_loss_part) {
-            double pc = 0, ec = 0, pe = 0, ee = 0, pg = 0, eg = 0;
-            const int tb = f.disc_tiles_b;
-            for (int k = tid; k < tb; k += 64) {
-                pc += (double)f.disc_loss_part[4 * k]; pe += (double)f.disc_loss_part[4 * k + 1];
-                pg += (double)f.disc_loss_part[4 * k + 2];
-                ec += (double)f.disc_loss_part[4 * (tb + k)]; ee += (double)f.disc_loss_part[4 * (tb + k) + 1];
-                eg += (double)f.disc_loss_part[4 * (tb + k) + 2];
-            }
-            pc = wsum(pc); ec = wsum(ec); pe = wsum(pe); ee = wsum(ee); pg = wsum(pg); eg = wsum(eg);
-            if (tid == 0) {
-                const double B = (double)f.B;
-                const double pl = pc / B, el = ec / B, em = (pe + ee) / (2.0 * B),
-                             eloss = -(double)f.ent_scale * em;
-                f.disc_losses[0] = (float)pl; f.disc_losses[1] = (float)el; f.disc_losses[2] = (float)em;
-                f.disc_losses[3] = (float)eloss; f.disc_losses[4] = (float)(pg / B);
-                f.disc_losses[5] = (float)(eg / B);
-                f.disc_losses[6] = (float)gp_loss;
-                f.disc_losses[7] = (float)(pl + el + eloss + (double)f.gp_coeff * gp_loss);
-            }
-        }
-        if (f.rms_sums) {  // commit of the inline d.obs_rms.update (mpi_running_mean_std.py:40-45,31-34)
-            const int dim = f.ob;
-            const double add_n = f.rms_addvec[2 * dim];
-            const double cnt = f.rms_sums[2 * dim] + add_n;  // every lane reads the old count first
-            for (int c = tid; c < dim; c += 64) {
-                const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
-                             s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
-                f.rms_sums[c] = s1;
-                f.rms_sums[dim + c] = s2;
-                const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
-                f.rms_mean[c] = mean;
-                f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
-            }
-            if (tid == 0) f.rms_sums[2 * dim] = cnt;
-        }
-        if (tid == 0)
-            for (int k = 0; k < f.nseg; ++k)
-                if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -904,32 +914,47 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     int seg = 0, b = blockIdx.x;
     while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
     const ApplySeg& s = f.seg[seg];
+    // this thread's first element is loaded BEFORE the norm / step-size chain below needs anything
+    int64_t i = (int64_t)b * 256 + tid;
+    const int64_t step = (int64_t)s.nblocks * 256;
+    const bool adam = f.mode & 2;
+    float g0 = 0.f, m0 = 0.f, v0 = 0.f, p0 = 0.f, t0 = 0.f;
+    if (i < s.n) {
+        g0 = s.grad[i];
+        if (adam) { m0 = s.m[i]; v0 = s.v[i]; p0 = s.param[i]; if (s.targ) t0 = s.targ[i]; }
+    }
     double acc = 0.0;
-    for (int i = tid; i < s.nsumsq; i += 256) acc += (double)s.sumsq[i];
+    for (int k = tid; k < s.nsumsq; k += 256) acc += (double)s.sumsq[k];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) shd[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) {
         const float nrm = (float)sqrt(shd[0] + shd[1] + shd[2] + shd[3]) * f.grad_scale;
         sh_scale = s.clip > 0.f ? s.clip / fmaxf(nrm, s.clip) : 1.f;
-        // step counter: block 0 of the segment ticks it AFTER every block has read it? no — blocks of
-        // one launch may run in any order, so the counter is advanced by the host-enqueued tick
-        // kernel; here it is only read.
+    }
+    if (tid == 64) {
+        // the step counter was advanced by finalize (or the host-enqueued tick kernel); here it is
+        // only read — blocks of one launch may run in any order
         const double t = (double)s.step_dev[0];
         sh_lr = (float)((double)s.lr * sqrt(1.0 - pow((double)f.beta2, t)) / (1.0 - pow((double)f.beta1, t)));
     }
     __syncthreads();
     const float scale = sh_scale * f.grad_scale, lr_t = sh_lr;
-    for (int64_t i = (int64_t)b * 256 + tid; i < s.n; i += (int64_t)s.nblocks * 256) {
-        const float gi = s.grad[i] * scale;
+    for (; i < s.n; i += step) {
+        const float gi = g0 * scale;
         if (f.mode & 1) s.clipped[i] = gi;
-        if (f.mode & 2) {
-            float mi = s.m[i], vi = s.v[i];
+        if (adam) {
+            float mi = m0, vi = v0;
             mi = mi + (gi - mi) * (1.f - f.beta1);
             vi = vi + (gi * gi - vi) * (1.f - f.beta2);
-            const float pi = s.param[i] - (mi * lr_t) / (sqrtf(vi) + f.eps);
+            const float pi = p0 - (mi * lr_t) / (sqrtf(vi) + f.eps);
             s.m[i] = mi; s.v[i] = vi; s.param[i] = pi;
-            if (s.targ) s.targ[i] = (1.f - f.tau) * s.targ[i] + f.tau * pi;
+            if (s.targ) s.targ[i] = (1.f - f.tau) * t0 + f.tau * pi;
+        }
+        const int64_t nx = i + step;
+        if (nx < s.n) {
+            g0 = s.grad[nx];
+            if (adam) { m0 = s.m[nx]; v0 = s.v[nx]; p0 = s.param[nx]; if (s.targ) t0 = s.targ[nx]; }
         }
     }
 }
@@ -1040,7 +1065,7 @@ int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const 
 int launch_finalize(const FinalizeArgs& f, hipStream_t st) {
     int blocks = 0;
     for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
-    finalize_kernel<<<blocks, 256, 0, st>>>(f);
+    finalize_kernel<<<blocks + 1, 256, 0, st>>>(f);  // + the scalar block
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
