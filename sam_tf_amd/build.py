@@ -13,7 +13,7 @@ SO = os.path.join(HERE, 'libsamx.so')
 SOURCES = ['core.hip', 'tree.hip', 'replay.hip', 'optim.hip', 'gemm.hip', 'nets.hip',
            'fused_small.hip', 'step.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-         '-fno-fast-math', '-Wall', '-Wno-unused-function']
+         '-fno-fast-math', '-Wall', '-Wno-unused-function'] + os.environ.get('SAMX_EXTRA_FLAGS', '').split()
 
 
 def needs_build():
