@@ -37,10 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Phase timestamps of workgroup 0 of each role (profiling builds only: -DSAMX_TRACE; never shipped)
 #ifdef SAMX_TRACE
 __device__ unsigned long long g_trace[64];
-#define TRACE(role, i) do { if (wg == 0 && threadIdx.x == 0) g_trace[(role) * 16 + (i)] = wall_clock64(); } while (0)
+#define TRACEW(w_, role, i) do { if ((w_) == 0 && threadIdx.x == 0) g_trace[(role) * 16 + (i)] = wall_clock64(); } while (0)
 #else
-#define TRACE(role, i) do { } while (0)
+#define TRACEW(w_, role, i) do { } while (0)
 #endif
+#define TRACE(role, i) TRACEW(wg, role, i)
 
 __device__ __forceinline__ float lrelu(float z) { return fmaxf(z, 0.2f * z); }
 __device__ __forceinline__ float dlrelu(float a) { return a >= 0.f ? 1.f : 0.2f; }
@@ -497,6 +498,7 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac;
     const bool use_d = a.d_scale != 0.f;
+    TRACE(0, 0);
     AgentLds L = carve_agent_lds(lds, ob, ac, use_d);
     float* gA = a.partials + (int64_t)wg * a.P;  // actor part of this tile's gradient slot
     const int64_t aW1 = 0, ab1 = aW1 + (int64_t)ob * H, aW2 = ab1 + H, ab2 = aW2 + H * H, aW3 = ab2 + H,
@@ -519,12 +521,14 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     if (use_d) head_commit(L.nD, hD);
     rows_commit(L.XC, x0, a.mean != nullptr, ob, ob);
     stage_wait();
+    TRACE(0, 1);
     layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
     __syncthreads();
     layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
     __syncthreads();
     actor_head(L, ob, ac, a.high);
     __syncthreads();
+    TRACE(0, 2);
     // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
     layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
     __syncthreads();
@@ -546,6 +550,7 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     f32x4 dA = {0.f, 0.f, 0.f, 0.f};
     if (wv == 0) dA = tile_nt64(L.DZb, L.nC.W1, ob, lane);
     __syncthreads();
+    TRACE(0, 3);
     if (use_d) {  // D branch: -d_scale * mean D(obz0, mu(obz0))   (sam_agent.py:421-422)
         layer_fwd(L.XC, L.nD.k4, L.nD.W1, L.nD.b1, L.A1c);
         __syncthreads();
@@ -568,6 +573,7 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     } else if (tid == 0) {
         a.loss_part[wg * 4 + 2] = 0.f;
     }
+    TRACE(0, 4);
     if (wv == 0) {  // through clip (identity inside the range) and tanh
         const int c = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
@@ -605,6 +611,7 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     layer_bwd(L.DZa, L.nA.W2, L.A1a, L.DZb);
     __syncthreads();
     wgrad64(L.XC, ob, L.DZb, gA + aW1, gA + ab1, R);
+    TRACE(0, 5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -708,6 +715,9 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     float* sh = p; p += 96;
     float* ms = p; p += 128;  // mean[64] | std[64] when the statistics are updated inline
     float* s_ = sh; float* dq = sh + 16; float* r0_ = sh + 32; float* r1_ = sh + 48; float* r2_ = sh + 64;
+    // traced tiles: the first policy tile (role 2) and the first interpolate tile (role 3)
+    [[maybe_unused]] const int trole = sect == 2 ? 3 : 2, twg = sect == 2 ? wg - 2 * tiles_b : wg;
+    TRACEW(twg, trole, 0);
     // ---- prologue: all global loads issued before the first wait (see "staged prologue")
     const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
     const int64_t e0 = a.e_start ? a.e_start[0] : 0;
@@ -749,6 +759,7 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     __syncthreads();   // ms is read by other threads below
     disc_rows_commit(XC, xr, a, row0, sect, norm, ms, step);
     stage_wait();
+    TRACEW(twg, trole, 1);
     if (sect == 2) {
         // Interpolate rows.  d(10*GP)/d(theta) = k * sum_rows <V, dg/dtheta> with V = g/(B*dim) and the
         // scalar k = 10*2(N-1)/N known only once every tile has contributed to N.  The slot gets the
@@ -790,6 +801,7 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
             for (int r = 0; r < R; ++r) s2 += A2[r * LD + tid];
             part[oW3 + tid] = s2;                         // sum_r a2dot
         }
+        TRACEW(twg, trole, 2);
         return;
     }
     // ---- policy / expert rows
@@ -837,6 +849,7 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
     layer_bwd(DZa, n.W2, A1, DZb);
     __syncthreads();
     wgrad64(XC, in, DZb, part + oW1, part + ob1, R);
+    TRACEW(twg, trole, 2);
 }
 
 // critic_ops['td_errors'] (sam_agent.py:534-538,693-701) for 16 rows per workgroup: the PER refresh with

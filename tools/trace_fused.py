@@ -26,7 +26,7 @@ for it in range(20):
     torch.cuda.synchronize()
     assert lib.samx_debug_trace(buf) == 0
     acc[it] = np.array(buf[:], dtype=np.float64)
-for role, name in ((0, 'actor'), (1, 'target+critic'), (2, 'disc'), (3, 'target+critic, 2nd pass (warm)')):
+for role, name in ((0, 'actor'), (1, 'target+critic'), (2, 'disc'), (3, 'disc interpolate tile (or 2nd TC pass)')):
     t = acc[5:, role * 16:(role + 1) * 16]
     if t[:, 0].min() == 0:
         continue
