@@ -62,3 +62,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert rc < 0 and b'null' in L.samx_last_error()
     with pytest.raises(_lib.SamxError):
         _lib.check(L.samx_tree_reduce(None, 8, 0, 0, 8, None, None))
+
+
+def test_shipped_library_is_not_a_profiling_build():
+    """-DSAMX_TRACE builds (tools/trace_fused.py) add timestamp stores to the fused step kernel and
+    export samx_debug_trace; the library in the tree must not be one of them."""
+    import ctypes
+    from sam_tf_amd import _lib
+    L = ctypes.CDLL(_lib.SO_PATH)
+    assert not hasattr(L, 'samx_debug_trace')

@@ -10,7 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o c2 -- python3 bench.
 DB=$(ls $O/*c2_results.db $O/*/*c2_results.db 2>/dev/null | head -1)
 python3 profiles/summarize_rocpd.py $DB > $O/${R}_c2_bench_kernel_stats.txt || exit 1
 python3 profiles/timeline_rocpd.py $DB step_kernel 1000 > $O/${R}_c2_step_timeline.txt || exit 1
-tail -1 $O/c2_bench.log > $O/${R}_bench_c2_under_rocprof.json
+grep "^{\"metric\"" $O/c2_bench.log | tail -1 > $O/${R}_bench_c2_under_rocprof.json
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --no-cpu --steps 200 --warmup 50 > $O/pmc_f.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --no-cpu --steps 200 --warmup 50 > $O/pmc_w.log 2>&1 || exit 1
 python3 profiles/collect_pmc.py C2 step_kernel $O/pmc_fetch $O/pmc_write > $O/pmc_collect.log 2>&1 || exit 1
@@ -18,6 +18,6 @@ cp profiles/pmc_C2.json $O/pmc_C2.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o c4 -- python3 bench.py --no-cpu --config C4 --steps 300 --warmup 50 > $O/c4_bench.log 2>&1 || exit 1
 DB4=$(ls $O/*c4_results.db $O/*/*c4_results.db 2>/dev/null | head -1)
 python3 profiles/summarize_rocpd.py $DB4 > $O/${R}_c4_bench_kernel_stats.txt || exit 1
-tail -1 $O/c4_bench.log > $O/${R}_bench_c4_under_rocprof.json
+grep "^{\"metric\"" $O/c4_bench.log | tail -1 > $O/${R}_bench_c4_under_rocprof.json
 rm -f $O/*.db $O/*/*.db
 echo done
