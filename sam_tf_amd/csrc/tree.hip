@@ -71,6 +71,82 @@ __global__ __launch_bounds__(kTreeThreads) void tree_set_kernel(double* __restri
     }
 }
 
+// Large batches (C5: 8192 updates into a 2^22 tree): one workgroup is bound by the number of random
+// 8-byte accesses a single CU can keep in flight (8192 x 4 loads per level, 22 levels: ~460 us measured).
+// Split by SUBTREE instead: workgroup g owns the leaves [g * cap/G, (g+1) * cap/G) and every internal
+// node below that subtree's root, so the workgroups never touch the same node and need no grid-wide
+// synchronisation for the lower `sub_levels` levels.  Each workgroup scans the whole batch, keeps the
+// positions that fall into its leaf range (LDS list), runs the same election / leaf write / bottom-up
+// recompute as the one-workgroup kernel on them.  The top log2(G) levels are then recomputed IN FULL by
+// tree_set_top_kernel (a second launch: G - 1 nodes, every one from its two children, so untouched nodes
+// are rewritten with their own value).  Same arithmetic per node as the reference, hence the same bits.
+constexpr int kSetGroups = 256;        // subtrees (power of two)
+constexpr int kSetMaxBatch = 8192;     // LDS list capacity (positions)
+
+__global__ __launch_bounds__(kTreeThreads) void tree_set_sub_kernel(double* __restrict__ s,
+                                                                    double* __restrict__ m,
+                                                                    int32_t* __restrict__ stamp,
+                                                                    int64_t cap,
+                                                                    const int64_t* __restrict__ idxs,
+                                                                    const double* __restrict__ leaf,
+                                                                    int n, int sub_levels) {
+    __shared__ int list[kSetMaxBatch];
+    __shared__ int cnt;
+    const int tid = threadIdx.x;
+    const int64_t sub = cap / gridDim.x, lo = (int64_t)blockIdx.x * sub, hi = lo + sub;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kTreeThreads) {
+        const int64_t idx = idxs[i];
+        if (idx >= lo && idx < hi) list[atomicAdd(&cnt, 1)] = i;
+    }
+    __syncthreads();
+    const int c = cnt;
+    if (c == 0) return;
+    for (int k = tid; k < c; k += kTreeThreads) {
+        const int i = list[k];
+        atomicMax(&stamp[idxs[i]], i);
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += kTreeThreads) {
+        const int i = list[k];
+        const int64_t idx = idxs[i];
+        const int32_t w = __hip_atomic_load(&stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == i) {
+            const double v = leaf[i];
+            s[cap + idx] = v;
+            m[cap + idx] = v;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += kTreeThreads) stamp[idxs[list[k]]] = -1;
+    for (int l = 1; l <= sub_levels; ++l) {
+        __syncthreads();
+        for (int k = tid; k < c; k += kTreeThreads) {
+            const int64_t node = (cap + idxs[list[k]]) >> l;
+            s[node] = __dadd_rn(s[2 * node], s[2 * node + 1]);
+            const double a = m[2 * node], b = m[2 * node + 1];
+            m[node] = (b < a) ? b : a;
+        }
+    }
+}
+
+// levels sub_levels+1 .. levels (counted from the leaves), every node of each level
+__global__ __launch_bounds__(kTreeThreads) void tree_set_top_kernel(double* __restrict__ s,
+                                                                    double* __restrict__ m, int64_t cap,
+                                                                    int sub_levels, int levels) {
+    for (int l = sub_levels + 1; l <= levels; ++l) {
+        const int64_t count = cap >> l;   // nodes [count, 2 * count) form this level
+        for (int64_t j = threadIdx.x; j < count; j += kTreeThreads) {
+            const int64_t node = count + j;
+            s[node] = __dadd_rn(s[2 * node], s[2 * node + 1]);
+            const double a = m[2 * node], b = m[2 * node + 1];
+            m[node] = (b < a) ? b : a;
+        }
+        __syncthreads();
+    }
+}
+
 // reduce over leaves [lo, hi] (inclusive) with the association order of the reference recursion
 // (segment_tree.py:26-39): descend to the split node, then the left part is a suffix query folded
 // left-nested and the right part a prefix query folded right-nested.
@@ -216,8 +292,21 @@ int samx_tree_set(double* sum_tree, double* min_tree, int32_t* stamp, int64_t ca
                  (long long)cap);
     SAMX_REQUIRE(n >= 0 && n <= (1 << 24), "samx_tree_set: batch %lld out of range", (long long)n);
     if (n == 0) return SAMX_OK;
+    const int levels = levels_of(cap);
+    if (n >= 1024 && n <= kSetMaxBatch && cap >= 16 * (int64_t)kSetGroups) {
+        // out-of-range indices are ignored by both forms (no subtree claims them)
+        int top = 0;
+        while ((1 << top) < kSetGroups) ++top;
+        tree_set_sub_kernel<<<kSetGroups, kTreeThreads, 0, (hipStream_t)stream>>>(
+            sum_tree, min_tree, stamp, cap, idxs, leaf, (int)n, levels - top);
+        SAMX_LAUNCH_CHECK();
+        tree_set_top_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(sum_tree, min_tree, cap, levels - top,
+                                                                        levels);
+        SAMX_LAUNCH_CHECK();
+        return SAMX_OK;
+    }
     tree_set_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(sum_tree, min_tree, stamp, cap, idxs,
-                                                                leaf, (int)n, levels_of(cap));
+                                                                leaf, (int)n, levels);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

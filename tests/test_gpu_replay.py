@@ -113,6 +113,42 @@ def test_per_full_capacity_vs_c_oracle(cap_log2, B):
     assert int((dt.stamp != -1).sum().item()) == 0
 
 
+@pytest.mark.parametrize('pattern', ['uniform', 'one_subtree', 'edges'])
+def test_tree_set_large_batch_subtree_partition(pattern):
+    """Batches of >= 1024 updates take the subtree-partitioned form of samx_tree_set (256 workgroups own
+    disjoint subtrees, the top 8 levels are recomputed in a second launch): every node bit-equal to
+    oracle/per_tree.c, for spread-out updates, updates that all fall into one subtree (one workgroup
+    gets the whole batch) and updates on the first/last leaves, each with duplicates."""
+    from oracle.per_tree_c import PerTreesC
+    from sam_tf_amd import ops
+    cap, B = 1 << 14, 2048
+    rs = np.random.RandomState(5)
+    ct = PerTreesC(cap)
+    ct.fill_range(0, cap, 0.7)
+    dt = ops.DeviceTrees(cap)
+    dt.set(torch.arange(1000, device='cuda'), torch.full((1000,), 0.7, dtype=torch.float64, device='cuda'))
+    dt.set(torch.arange(1000, cap, device='cuda'),
+           torch.full((cap - 1000,), 0.7, dtype=torch.float64, device='cuda'))   # one-workgroup form
+    mp_c = mp_d = 1.0
+    for r in range(3):
+        if pattern == 'uniform':
+            idx = rs.randint(0, cap, size=B)
+        elif pattern == 'one_subtree':
+            idx = rs.randint(5, 40, size=B)          # 35 leaves, ~58 writers each
+        else:
+            idx = np.concatenate([np.zeros(B // 4, dtype=np.int64), np.full(B // 4, cap - 1),
+                                  rs.randint(0, cap, size=B // 2)])
+            rs.shuffle(idx)
+        idx = idx.astype(np.int64)
+        pr = np.abs(rs.standard_cauchy(B)) + 1e-6
+        mp_c = ct.per_update(idx, pr, 0.3, max_priority=mp_c)
+        leaf, mp_d = ops.per_leaf_values_host(idx, pr, 0.3, 0, 0.1, mp_d)
+        dt.set(torch.as_tensor(idx).cuda(), torch.as_tensor(leaf).cuda())
+        assert np.array_equal(dt.sum.cpu().numpy(), ct.sumv), (pattern, r)
+        assert np.array_equal(dt.min.cpu().numpy(), ct.minv), (pattern, r)
+    assert int((dt.stamp != -1).sum().item()) == 0
+
+
 def test_per_rejects_degenerate_sizes():
     from sam_tf_amd import ops, _lib
     dt = ops.DeviceTrees(8)
