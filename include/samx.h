@@ -158,6 +158,19 @@ int samx_perturb_params(const samx_mlp* d, const float* params, float* out, floa
 /* sqrt(mean((a - b)^2)) over n floats (the action-space distance of sam_agent.py:371); out float[1]. */
 int samx_rms_distance(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* The fp32 MFMA GEMM every layer of the layer-wise path is made of, exposed for parity tests and
+ * integration: C[i,j] = epi( sum_r A(i,r) B(r,j) ), A(i,r) = A[i*a_si + r*a_sr], B(r,j) = B[r*b_sr + j*b_sj],
+ * one unit stride per operand.  Replaces tf.layers.dense / tf.matmul and their gradients
+ * (networks.py:45-72,287,365,390; tf.gradients at tf_util.py:141).  The accumulation is the k-ordered fp32
+ * fma chain of v_mfma_f32_32x32x2_f32.  epi: 0 none, 1 +bias[j], 2 lrelu(+bias), 3 alpha*tanh(+bias) clipped,
+ * 4 * lrelu'(aux[i,j]), 5 (acc + add[i,j]) * tanh'(aux), 6 acc + alpha*aux[i,j].  a_ones_rows >= 0 appends a
+ * virtual row M to A with A(M,r) = (r < a_ones_rows) (bias gradient); nsplit > 1 splits r over
+ * workgroups through partials[nsplit][M(+1)][N] with a fixed-order reduce. */
+int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, int64_t b_sr, int64_t b_sj,
+                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t R, int32_t a_ones_rows, int32_t epi,
+                  const float* bias, const float* aux, int64_t ld_aux, const float* add, int64_t ld_add,
+                  float alpha, int32_t nsplit, float* partials, void* stream);
+
 /* ---- network passes ------------------------------------------------------------------------ */
 /* ob_mean/ob_std: float[ob] from samx_rms_commit, or NULL when rmsify_obs is off
  * (sam_agent.py:150-159).  Observations are normalised and clipped to [-5, 5] inside.

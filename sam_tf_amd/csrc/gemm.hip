@@ -2,8 +2,9 @@
 // fmaf loop) with fused bias / activation / mask epilogues.  64x64 output tile per workgroup
 // (2x2 quadrants of 32x32, one accumulator each).
 //
-// Staging runs on the LDS-DMA path (global_load_lds: no VGPR round trip) through a ring of four
-// 32-deep stages: up to three stages are in flight while one is on the matrix cores, retired by
+// Staging runs on the LDS-DMA path (global_load_lds: no VGPR round trip) through a ring of three
+// 32-deep stages (48 KB: three workgroups per CU; a ring of four measured 6 % slower at C5 and 11 % slower on
+// an 8192x8192x2048 product, 86.7 vs 97.7 TFLOP/s): two stages are in flight while one is on the matrix cores, retired by
 // COUNTED s_waitcnt vmcnt(N) and raw s_barrier (a __syncthreads() would drain the DMAs).  What bounds
 // these GEMMs is how many DMA instructions a CU can retire: a dword DMA moves 256 B per instruction and a
 // CU retires one every ~32 cycles (measured: 63 per wave took 3.4 us), i.e. 8 B/clk against the 16 B per
@@ -37,12 +38,24 @@
 namespace samx {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, NS = 4;
+#ifndef SAMX_GEMM_RING
+#define SAMX_GEMM_RING 3
+#endif
+constexpr int BM = 64, BN = 64, BK = 32, NS = SAMX_GEMM_RING;
 constexpr int TILE = BK * 64;            // floats per operand stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_float;
 typedef const __attribute__((address_space(1))) float glb_float;
+
+// Stage timestamps of workgroup (0,0,0), wave 0 (profiling builds only: -DSAMX_TRACE)
+#ifdef SAMX_TRACE
+__device__ unsigned long long g_gemm_trace[64];
+#define GTRACE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (i) < 64) \
+                         g_gemm_trace[(i)] = wall_clock64(); } while (0)
+#else
+#define GTRACE(i) do { } while (0)
+#endif
 
 struct EpiCtx {
     const float* bias;
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
         }
     };
 
-    for (int s = 0; s < NS - 1 && s < T; ++s) issue(r_begin + s * BK, lds + s * 2 * TILE);
-    for (int t = 0; t < T; ++t) {
+    // retire stage t (counted wait on this wave's own DMAs, tail / ones-row patches, barrier)
+    auto retire = [&](int t) {
         float* Sa = lds + (t % NS) * 2 * TILE;
         float* Sb = Sa + TILE;
         // stages issued after t and still allowed in flight: t+1 .. min(t+NS-2, T-1)
@@ -249,14 +262,44 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
                 }
             }
         }
+        // lgkmcnt(0): this wave's own fragment reads of the PREVIOUS stage are complete too, so after
+        // the barrier that stage's slot may be refilled by anyone
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // every wave is past the MFMAs of stage t-1, so that slot is refilled now
-        if (t + NS - 1 < T) issue(r0 + (NS - 1) * BK, lds + ((t + NS - 1) % NS) * 2 * TILE);
-        float fa[MPW], fb[MPW];  // this wave's operand fragments of the stage, read ahead of the MFMAs
+    };
+    auto frags = [&](int t, float (&fa)[MPW], float (&fb)[MPW]) {
+        const float* Sa = lds + (t % NS) * 2 * TILE;
         load_frags<A_RC, A_W, MPW>(Sa, wm * 32, slice * MPW, lane, fa);
-        load_frags<B_RC, B_W, MPW>(Sb, wn * 32, slice * MPW, lane, fb);
+        load_frags<B_RC, B_W, MPW>(Sa + TILE, wn * 32, slice * MPW, lane, fb);
+    };
+    // One step: the MFMAs of stage t run from registers while the fragment reads of stage t+1 (into
+    // the other register set) and the refill DMAs are in flight.
+    auto step = [&](int t, float (&ca)[MPW], float (&cb)[MPW], float (&na)[MPW], float (&nb)[MPW]) {
+        // slot of stage t-1: its fragments were consumed before the barrier of stage t was passed
+        if (t + NS - 1 < T) issue(r_begin + (t + NS - 1) * BK, lds + ((t + NS - 1) % NS) * 2 * TILE);
+        if (t + 1 < T) {
+            retire(t + 1);
+            frags(t + 1, na, nb);
+        }
 #pragma unroll
-        for (int k = 0; k < MPW; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
+        for (int k = 0; k < MPW; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[k], cb[k], acc, 0, 0, 0);
+    };
+
+    GTRACE(0);
+#ifdef SAMX_TRACE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_gemm_trace[61] = clock64();
+#endif
+    for (int s = 0; s < NS - 1 && s < T; ++s) issue(r_begin + s * BK, lds + s * 2 * TILE);
+    GTRACE(1);
+    float fa0[MPW], fb0[MPW], fa1[MPW], fb1[MPW];
+    if (T > 0) {
+        retire(0);
+        GTRACE(2);
+        frags(0, fa0, fb0);
+    }
+    for (int t = 0; t < T; t += 2) {
+        step(t, fa0, fb0, fa1, fb1);
+        GTRACE(3 + t);
+        if (t + 1 < T) { step(t + 1, fa1, fb1, fa0, fb0); GTRACE(4 + t); }
     }
 
     if (KS > 1) {  // add the slices' accumulators (slice order: deterministic)
@@ -286,6 +329,10 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
                 g.C[(int64_t)i * g.ldc + j] = apply_epi(epi, acc[q], i, j, e);
         }
     }
+    GTRACE(63);
+#ifdef SAMX_TRACE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_gemm_trace[62] = clock64();
+#endif
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo) {
@@ -375,3 +422,26 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace samx
+
+#ifdef SAMX_TRACE
+extern "C" int samx_debug_gemm_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::g_gemm_trace), sizeof(unsigned long long) * 64);
+}
+#endif
+
+extern "C" int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, int64_t b_sr, int64_t b_sj,
+                             float* C, int64_t ldc, int32_t M, int32_t N, int32_t R, int32_t a_ones_rows,
+                             int32_t epi, const float* bias, const float* aux, int64_t ld_aux, const float* add,
+                             int64_t ld_add, float alpha, int32_t nsplit, float* partials, void* stream) {
+    samx::GemmArgs g;
+    g.A = A; g.a_si = a_si; g.a_sr = a_sr;
+    g.B = B; g.b_sr = b_sr; g.b_sj = b_sj;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.R = R;
+    g.a_ones_rows = a_ones_rows;
+    g.epi = (samx::Epilogue)epi;
+    g.bias = bias; g.aux = aux; g.ld_aux = ld_aux; g.add = add; g.ld_add = ld_add; g.alpha = alpha;
+    g.nsplit = nsplit; g.partials = partials;
+    SAMX_REQUIRE(epi < samx::EPI_BIAS || epi > samx::EPI_BIAS_TANH || bias, "samx_gemm_f32: epilogue %d needs bias", epi);
+    SAMX_REQUIRE(epi < samx::EPI_MASK || aux, "samx_gemm_f32: epilogue %d needs aux", epi);
+    return samx::gemm(g, (hipStream_t)stream);
+}

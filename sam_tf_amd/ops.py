@@ -579,3 +579,18 @@ def step_apply(L, B, mode, grad_scale=1.0):
     ws = L.ws(B)
     check(_L().samx_step_apply(C.byref(L.c), int(B), int(mode), float(grad_scale), ptr(ws), ws.numel(),
                                stream_ptr()))
+
+
+def gemm_f32(A, a_strides, B, b_strides, M, N, R, epi=0, bias=None, aux=None, add=None, alpha=0.0,
+             a_ones_rows=-1, nsplit=1, out=None):
+    """C[M(+1), N] = epi(sum_r A(i,r) B(r,j)) with explicit (free, reduction) / (reduction, free) element
+    strides — the building block of the layer-wise path (samx_gemm_f32)."""
+    Mo = M + (1 if a_ones_rows >= 0 else 0)
+    C_ = out if out is not None else torch.empty(Mo, N, dtype=torch.float32, device=A.device)
+    partials = torch.empty(nsplit * Mo * N, dtype=torch.float32, device=A.device) if nsplit > 1 else None
+    check(_L().samx_gemm_f32(ptr(A), a_strides[0], a_strides[1], ptr(B), b_strides[0], b_strides[1], ptr(C_),
+                             C_.stride(0), M, N, R, a_ones_rows, epi, ptr(bias), ptr(aux),
+                             aux.stride(0) if aux is not None else 0, ptr(add),
+                             add.stride(0) if add is not None else 0, float(alpha), nsplit, ptr(partials),
+                             stream_ptr()))
+    return C_
