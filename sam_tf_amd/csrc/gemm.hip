@@ -41,7 +41,11 @@ namespace {
 #ifndef SAMX_GEMM_RING
 #define SAMX_GEMM_RING 3
 #endif
-constexpr int BM = 64, BN = 64, BK = 32, NS = SAMX_GEMM_RING;
+#ifndef SAMX_GEMM_RING_FEW
+#define SAMX_GEMM_RING_FEW 3
+#endif
+constexpr int BM = 64, BN = 64, BK = 32;
+template <int KS> constexpr int ring() { return KS == 1 ? SAMX_GEMM_RING : SAMX_GEMM_RING_FEW; }
 constexpr int TILE = BK * 64;            // floats per operand stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -194,6 +198,7 @@ __device__ __forceinline__ void wait_vm() {
 // A_W / B_W: the operand is staged with 16-byte DMAs (see the header).
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
 __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
+    constexpr int NS = ring<KS>();                  // stages in the ring
     constexpr int NW = 4 * KS;                      // waves
     constexpr int DA = ndma<A_W>(), DT = DA + ndma<B_W>();  // DMAs per stage: A's, then B's
     static_assert(DT % NW == 0, "every wave issues the same number of DMAs per stage");
@@ -239,7 +244,11 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
         const int ahead = min(NS - 2, T - 1 - t);
         if (ahead <= 0) wait_vm<0>();
         else if (ahead == 1) wait_vm<CNT>();
-        else wait_vm<2 * CNT>();
+        else if (ahead == 2) wait_vm<2 * CNT>();
+        else if (ahead == 3) wait_vm<3 * CNT>();
+        else if (ahead == 4) wait_vm<(4 * CNT <= 63 ? 4 * CNT : 0)>();
+        else if (ahead == 5) wait_vm<(5 * CNT <= 63 ? 5 * CNT : 0)>();
+        else wait_vm<(6 * CNT <= 63 ? 6 * CNT : 0)>();
         const int r0 = r_begin + t * BK, rv = r_end - r0;
         if (rv < BK) {  // last, partial stage: this wave zeroes the tail of what it loaded
 #pragma unroll
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
         if (t + 1 < T) { step(t + 1, fa1, fb1, fa0, fb0); GTRACE(4 + t); }
     }
 
+    GTRACE(59);
     if (KS > 1) {  // add the slices' accumulators (slice order: deterministic)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (slice > 0) {
@@ -316,17 +326,61 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
             for (int q = 0; q < 16; ++q) acc[q] += lds[((sl * 4 + quad) * 16 + q) * 64 + lane];
     }
 
-    EpiCtx e{g.bias, g.aux, g.ld_aux, g.add, g.ld_add, g.alpha, g.M};
+    GTRACE(60);
+    // Epilogue in two passes so that no load sits between two stores (stores count in vmcnt on this
+    // ISA: a load -> use between them would wait for every earlier store to complete): first every
+    // operand the epilogue needs goes into registers, then the 16 values are finished and stored.
     const int epi = (int)g.epi;
     const int j = j0 + wn * 32 + (lane & 31);
+    const bool jv = j < g.N;
+    if (g.nsplit > 1) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (i < Mo && j < g.N) {
-            if (g.nsplit > 1)
-                g.partials[((int64_t)blockIdx.z * Mo + i) * g.N + j] = acc[q];
-            else
-                g.C[(int64_t)i * g.ldc + j] = apply_epi(epi, acc[q], i, j, e);
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (i < Mo && jv) g.partials[((int64_t)blockIdx.z * Mo + i) * g.N + j] = acc[q];
+        }
+    } else {
+        float bj = 0.f, ax[16], ad[16];
+        if (epi >= EPI_BIAS && epi <= EPI_BIAS_TANH && jv) bj = g.bias[j];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ax[q] = 0.f; ad[q] = 0.f; }
+        if (epi >= EPI_MASK) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (i < g.M && jv) ax[q] = g.aux[(int64_t)i * g.ld_aux + j];   // the ones row has no aux row
+            }
+            if (epi == EPI_ADD_TANHGRAD && g.add) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                    if (i < g.M && jv) ad[q] = g.add[(int64_t)i * g.ld_add + j];
+                }
+            }
+        }
+        const float alpha = g.alpha;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            float v = acc[q];
+            switch (epi) {   // registers only
+                case EPI_BIAS: v += bj; break;
+                case EPI_BIAS_LRELU: { const float x = v + bj; v = fmaxf(x, 0.2f * x); break; }
+                case EPI_BIAS_TANH: {
+                    const float a = alpha * tanhf(v + bj);
+                    v = fminf(fmaxf(a, -alpha), alpha);  // clip_acs (sam_agent.py:97,177)
+                    break;
+                }
+                case EPI_MASK: v *= (ax[q] >= 0.f ? 1.f : 0.2f); break;
+                case EPI_ADD_TANHGRAD: {
+                    const float t = ax[q] / alpha;
+                    v = (v + ad[q]) * (alpha * (1.f - t * t));
+                    break;
+                }
+                case EPI_AXPY: if (i < g.M) v += alpha * ax[q]; break;
+                default: break;
+            }
+            if (i < Mo && jv) g.C[(int64_t)i * g.ldc + j] = v;
         }
     }
     GTRACE(63);
@@ -354,7 +408,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo
 
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
 int launch_inst(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-    constexpr size_t lds = (size_t)NS * 2 * TILE * sizeof(float);
+    constexpr size_t lds = (size_t)ring<KS>() * 2 * TILE * sizeof(float);
+    static bool attr_done = false;  // per instantiation; > 64 KB of LDS needs the opt-in
+    if (!attr_done && lds > 64 * 1024) {
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<A_RC, B_RC, KS, A_W, B_W>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
     gemm_kernel<A_RC, B_RC, KS, A_W, B_W><<<grid, 256 * KS, lds, stream>>>(g);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
@@ -381,7 +441,9 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
     dim3 grid(cdiv(g.N, BN), cdiv(Mo, BM), g.nsplit);
     // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
-    const bool few = (int64_t)grid.x * grid.y * grid.z < 512;
+    static int few_below = -1;  // SAMX_GEMM_FEW (experiment knob)
+    if (few_below < 0) { const char* e = getenv("SAMX_GEMM_FEW"); few_below = e ? atoi(e) : 512; }
+    const bool few = (int64_t)grid.x * grid.y * grid.z < few_below;
     const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
     int rc;
     if (a_rc && !b_rc) rc = launch_layout<true, false>(g, grid, few, stream);
@@ -401,7 +463,9 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 
 int pick_nsplit(int Mo, int N, int R) {
     int tiles = cdiv(Mo, BM) * cdiv(N, BN);
-    int want = 512 / tiles;  // two workgroups per CU
+    static int target = -1;  // SAMX_GEMM_WANT: workgroups a split launch aims for (experiment knob)
+    if (target < 0) { const char* e = getenv("SAMX_GEMM_WANT"); target = e ? atoi(e) : 512; }
+    int want = target / tiles;  // two workgroups per CU
     int most = R / 128;      // keep at least 4 stages per split
     int s = want < most ? want : most;
     if (s < 1) s = 1;
