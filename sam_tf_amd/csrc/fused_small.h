@@ -44,8 +44,8 @@ struct DiscArgs {
     uint64_t rng_seed;
     const int64_t* rng_step;  // device: reward-net update count
     int label_smoothing;
-    // d.obs_rms.update folded into the step (sam.py:389-390; single process only).  rms_sums != NULL:
-    // rms_addvec holds this batch's float64 column sums (computed ahead); every workgroup normalises
+    // d.obs_rms.update folded into the step (sam.py:389-390).  rms_sums != NULL:
+    // rms_addvec holds this batch's float64 column sums (computed ahead, all-reduced when N > 1); every workgroup normalises
     // with the statistics of sums + addvec and finalize commits them (FinalizeArgs::rms_*).
     // mean/stdv are then unused.
     const double* rms_sums;    // [2*ob+1]

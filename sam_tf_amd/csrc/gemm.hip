@@ -441,9 +441,7 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
     dim3 grid(cdiv(g.N, BN), cdiv(Mo, BM), g.nsplit);
     // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
-    static int few_below = -1;  // SAMX_GEMM_FEW (experiment knob)
-    if (few_below < 0) { const char* e = getenv("SAMX_GEMM_FEW"); few_below = e ? atoi(e) : 512; }
-    const bool few = (int64_t)grid.x * grid.y * grid.z < few_below;
+    const bool few = (int64_t)grid.x * grid.y * grid.z < 512;
     const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
     int rc;
     if (a_rc && !b_rc) rc = launch_layout<true, false>(g, grid, few, stream);
@@ -463,9 +461,7 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 
 int pick_nsplit(int Mo, int N, int R) {
     int tiles = cdiv(Mo, BM) * cdiv(N, BN);
-    static int target = -1;  // SAMX_GEMM_WANT: workgroups a split launch aims for (experiment knob)
-    if (target < 0) { const char* e = getenv("SAMX_GEMM_WANT"); target = e ? atoi(e) : 512; }
-    int want = target / tiles;  // two workgroups per CU
+    int want = 512 / tiles;  // two workgroups per CU (1024 and 768 measured the same at C4 and C5)
     int most = R / 128;      // keep at least 4 stages per split
     int s = want < most ? want : most;
     if (s < 1) s = 1;

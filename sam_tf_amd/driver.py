@@ -186,8 +186,8 @@ class UpdateStepDriver(object):
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
 
     # ------------------------------------------------------------------ plan: graphs + collectives
-    def _capture(self, run, small=False):
-        if not self.use_graph or (small and os.environ.get('SAMX_DIRECT_SEGS') == '1'):
+    def _capture(self, run):
+        if not self.use_graph:
             return run
         # warm-up on a side stream (module loads, LDS attributes, side streams), then capture
         side = torch.cuda.Stream()
@@ -228,11 +228,11 @@ class UpdateStepDriver(object):
                 plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
             # the optimiser pass of step k and the gradient pass of step k + 1 share one graph: per
             # step the host issues ONE graph launch and ONE all-reduce
-            plan += [self._capture(lambda: self._seg_grads(0), True), lambda: ar(L.grads)]
+            plan += [self._capture(lambda: self._seg_grads(0)), lambda: ar(L.grads)]
             for k in range(1, K):
-                plan += [self._capture(lambda k=k: (self._seg_apply(), self._seg_grads(k)), True),
+                plan += [self._capture(lambda k=k: (self._seg_apply(), self._seg_grads(k))),
                          lambda: ar(L.grads)]
-            plan.append(self._capture(self._seg_apply, True))
+            plan.append(self._capture(self._seg_apply))
             return plan
         assert K == 1
         # N > 1, layer-wise path: one step per launch, three segments
