@@ -42,7 +42,7 @@ namespace {
 #define SAMX_GEMM_RING 3
 #endif
 #ifndef SAMX_GEMM_RING_FEW
-#define SAMX_GEMM_RING_FEW 3
+#define SAMX_GEMM_RING_FEW 6
 #endif
 constexpr int BM = 64, BN = 64, BK = 32;
 template <int KS> constexpr int ring() { return KS == 1 ? SAMX_GEMM_RING : SAMX_GEMM_RING_FEW; }
@@ -198,12 +198,19 @@ __device__ __forceinline__ void wait_vm() {
 // A_W / B_W: the operand is staged with 16-byte DMAs (see the header).
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
 __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
-    constexpr int NS = ring<KS>();                  // stages in the ring
+    // A "step" covers SPB consecutive 32-deep stages behind ONE barrier: the 16-wave variant has only
+    // four MFMAs per wave and stage, so it takes two stages per barrier (a barrier + wait + issue round
+    // costs ~0.4 us there against 0.44 us of matrix-core time per stage).
+    constexpr int SPB = KS == 1 ? 1 : 2;            // stages per step
+    constexpr int NSU = 3;                          // steps in the ring: one computing, two in flight
+    constexpr int NS = NSU * SPB;                   // stage slots
+    static_assert(NS == ring<KS>(), "launch_inst sizes the LDS from ring<KS>()");
     constexpr int NW = 4 * KS;                      // waves
     constexpr int DA = ndma<A_W>(), DT = DA + ndma<B_W>();  // DMAs per stage: A's, then B's
     static_assert(DT % NW == 0, "every wave issues the same number of DMAs per stage");
     constexpr int CNT = DT / NW;                    // DMAs per wave per stage
     constexpr int MPW = (BK / 2) / KS;              // MFMAs per wave per stage
+    constexpr int FPS = SPB * MPW;                  // fragments per operand per step
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ONE array: [NS stages][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int quad = wave & 3, slice = wave >> 2;
@@ -221,148 +228,174 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
-    const int T = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;  // block-uniform
+    const int T = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;  // stages (block-uniform)
+    const int TU = (T + SPB - 1) / SPB;                                   // steps
     const Operand oa{g.A, g.a_si, g.a_sr, g.M, i0}, ob{g.B, g.b_sj, g.b_sr, g.N, j0};
     const int ones_col = g.M - i0;  // column of the virtual ones row in this tile (A free-contiguous)
     const bool patch_ones = ones && ones_col >= 0 && ones_col < BM;
 
-    // this wave's DMAs of a stage: numbers wave + NW q (q < CNT) of the list [A_0 .. A_DA-1, B_0 ..]
-    auto issue = [&](int r0, float* S) {
+    // this wave's DMAs of stage t: numbers wave + NW q (q < CNT) of the list [A_0 .. A_DA-1, B_0 ..].
+    // A stage past the end of the reduction (the second half of the last step when T is odd) is
+    // issued with clamped addresses and zeroed whole by zero_tail (rv <= 0).
+    auto issue_step = [&](int u) {
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-            const int j = wave + NW * q;   // wave-uniform
-            if (j < DA) dma_one<A_RC, A_W>(oa, j, r0, r_end, S, lane);
-            else dma_one<B_RC, B_W>(ob, j - DA, r0, r_end, S + TILE, lane);
+        for (int h = 0; h < SPB; ++h) {
+            const int t = u * SPB + h;
+            float* S = lds + (t % NS) * 2 * TILE;
+            const int r0 = r_begin + t * BK;
+#pragma unroll
+            for (int q = 0; q < CNT; ++q) {
+                const int j = wave + NW * q;   // wave-uniform
+                if (j < DA) dma_one<A_RC, A_W>(oa, j, r0, r_end, S, lane);
+                else dma_one<B_RC, B_W>(ob, j - DA, r0, r_end, S + TILE, lane);
+            }
         }
     };
 
-    // retire stage t (counted wait on this wave's own DMAs, tail / ones-row patches, barrier)
-    auto retire = [&](int t) {
-        float* Sa = lds + (t % NS) * 2 * TILE;
-        float* Sb = Sa + TILE;
-        // stages issued after t and still allowed in flight: t+1 .. min(t+NS-2, T-1)
-        const int ahead = min(NS - 2, T - 1 - t);
+    // retire step u (counted wait on this wave's own DMAs, tail / ones-row patches, barrier)
+    auto retire = [&](int u) {
+        // steps issued after u and still allowed in flight: u+1 .. min(u+NSU-2, TU-1)
+        const int ahead = min(NSU - 2, TU - 1 - u);
         if (ahead <= 0) wait_vm<0>();
-        else if (ahead == 1) wait_vm<CNT>();
-        else if (ahead == 2) wait_vm<2 * CNT>();
-        else if (ahead == 3) wait_vm<3 * CNT>();
-        else if (ahead == 4) wait_vm<(4 * CNT <= 63 ? 4 * CNT : 0)>();
-        else if (ahead == 5) wait_vm<(5 * CNT <= 63 ? 5 * CNT : 0)>();
-        else wait_vm<(6 * CNT <= 63 ? 6 * CNT : 0)>();
-        const int r0 = r_begin + t * BK, rv = r_end - r0;
-        if (rv < BK) {  // last, partial stage: this wave zeroes the tail of what it loaded
+        else wait_vm<SPB * CNT>();
 #pragma unroll
-            for (int q = 0; q < CNT; ++q) {
-                const int j = wave + NW * q;
-                if (j < DA) zero_tail<A_RC, A_W>(rv, Sa, j, lane);
-                else zero_tail<B_RC, B_W>(rv, Sb, j - DA, lane);
+        for (int h = 0; h < SPB; ++h) {
+            const int t = u * SPB + h;
+            float* Sa = lds + (t % NS) * 2 * TILE;
+            float* Sb = Sa + TILE;
+            const int r0 = r_begin + t * BK, rv = r_end - r0;
+            if (rv < BK) {  // partial (or absent) stage: this wave zeroes the tail of what it loaded
+#pragma unroll
+                for (int q = 0; q < CNT; ++q) {
+                    const int j = wave + NW * q;
+                    if (j < DA) zero_tail<A_RC, A_W>(rv, Sa, j, lane);
+                    else zero_tail<B_RC, B_W>(rv, Sb, j - DA, lane);
+                }
             }
-        }
-        if (patch_ones) {  // A(M, r) = (r < a_ones_rows); A is free-contiguous: S[r][64], column ones_col
+            if (patch_ones) {  // A(M, r) = (r < a_ones_rows); A is free-contiguous: S[r][64], column ones_col
 #pragma unroll
-            for (int q = 0; q < CNT; ++q) {
-                const int j = wave + NW * q;
-                if (j < DA) {
-                    const int row = A_W ? 4 * j + lane : j;   // rows this DMA filled: 4 (wide) or 1
-                    if (lane < (A_W ? 4 : 1)) {
-                        const int gr = r0 + row;
-                        Sa[row * 64 + ones_col] = (gr < r_end && gr < g.a_ones_rows) ? 1.f : 0.f;
+                for (int q = 0; q < CNT; ++q) {
+                    const int j = wave + NW * q;
+                    if (j < DA) {
+                        const int row = A_W ? 4 * j + lane : j;   // rows this DMA filled: 4 (wide) or 1
+                        if (lane < (A_W ? 4 : 1)) {
+                            const int gr = r0 + row;
+                            Sa[row * 64 + ones_col] = (gr < r_end && gr < g.a_ones_rows) ? 1.f : 0.f;
+                        }
                     }
                 }
             }
         }
-        // lgkmcnt(0): this wave's own fragment reads of the PREVIOUS stage are complete too, so after
-        // the barrier that stage's slot may be refilled by anyone
+        // lgkmcnt(0): this wave's own fragment reads of the PREVIOUS step are complete too, so after
+        // the barrier that step's slots may be refilled by anyone
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    auto frags = [&](int t, float (&fa)[MPW], float (&fb)[MPW]) {
-        const float* Sa = lds + (t % NS) * 2 * TILE;
-        load_frags<A_RC, A_W, MPW>(Sa, wm * 32, slice * MPW, lane, fa);
-        load_frags<B_RC, B_W, MPW>(Sa + TILE, wn * 32, slice * MPW, lane, fb);
+    auto frags = [&](int u, float (&fa)[FPS], float (&fb)[FPS]) {
+#pragma unroll
+        for (int h = 0; h < SPB; ++h) {
+            const float* Sa = lds + ((u * SPB + h) % NS) * 2 * TILE;
+            float ta[MPW], tb[MPW];
+            load_frags<A_RC, A_W, MPW>(Sa, wm * 32, slice * MPW, lane, ta);
+            load_frags<B_RC, B_W, MPW>(Sa + TILE, wn * 32, slice * MPW, lane, tb);
+#pragma unroll
+            for (int k = 0; k < MPW; ++k) { fa[h * MPW + k] = ta[k]; fb[h * MPW + k] = tb[k]; }
+        }
     };
-    // One step: the MFMAs of stage t run from registers while the fragment reads of stage t+1 (into
-    // the other register set) and the refill DMAs are in flight.
-    auto step = [&](int t, float (&ca)[MPW], float (&cb)[MPW], float (&na)[MPW], float (&nb)[MPW]) {
-        // slot of stage t-1: its fragments were consumed before the barrier of stage t was passed
-        if (t + NS - 1 < T) issue(r_begin + (t + NS - 1) * BK, lds + ((t + NS - 1) % NS) * 2 * TILE);
-        if (t + 1 < T) {
-            retire(t + 1);
-            frags(t + 1, na, nb);
+    // One step: the MFMAs of step u run from registers while the fragment reads of step u+1 (into the
+    // other register set) and the refill DMAs are in flight.
+    auto step = [&](int u, float (&ca)[FPS], float (&cb)[FPS], float (&na)[FPS], float (&nb)[FPS]) {
+        // slots of step u-1: its fragments were consumed before the barrier of step u was passed
+        if (u + NSU - 1 < TU) issue_step(u + NSU - 1);
+        if (u + 1 < TU) {
+            retire(u + 1);
+            frags(u + 1, na, nb);
         }
 #pragma unroll
-        for (int k = 0; k < MPW; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[k], cb[k], acc, 0, 0, 0);
+        for (int k = 0; k < FPS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[k], cb[k], acc, 0, 0, 0);
     };
 
     GTRACE(0);
 #ifdef SAMX_TRACE
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_gemm_trace[61] = clock64();
 #endif
-    for (int s = 0; s < NS - 1 && s < T; ++s) issue(r_begin + s * BK, lds + s * 2 * TILE);
+    for (int u = 0; u < NSU - 1 && u < TU; ++u) issue_step(u);
     GTRACE(1);
-    float fa0[MPW], fb0[MPW], fa1[MPW], fb1[MPW];
-    if (T > 0) {
+    float fa0[FPS], fb0[FPS], fa1[FPS], fb1[FPS];
+    if (TU > 0) {
         retire(0);
         GTRACE(2);
         frags(0, fa0, fb0);
     }
-    for (int t = 0; t < T; t += 2) {
-        step(t, fa0, fb0, fa1, fb1);
-        GTRACE(3 + t);
-        if (t + 1 < T) { step(t + 1, fa1, fb1, fa0, fb0); GTRACE(4 + t); }
+    for (int u = 0; u < TU; u += 2) {
+        step(u, fa0, fb0, fa1, fb1);
+        GTRACE(3 + u);
+        if (u + 1 < TU) { step(u + 1, fa1, fb1, fa0, fb0); GTRACE(4 + u); }
     }
 
     GTRACE(59);
-    if (KS > 1) {  // add the slices' accumulators (slice order: deterministic)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (slice > 0) {
+    // Epilogue.  KS = 1: a wave finishes its own 16 accumulator rows.  KS = 4: the four slices of a
+    // quadrant put their accumulators in LDS and EACH finishes a quarter of the rows (sum over the
+    // slices in slice order: deterministic), so the tail is spread over all 16 waves.
+    constexpr int NQ = 16 / KS;      // accumulator registers this wave finishes
+    const int q0 = KS > 1 ? slice * NQ : 0;
+    float val[NQ];
+    if (KS > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every fragment read is done
 #pragma unroll
-            for (int q = 0; q < 16; ++q) lds[(((slice - 1) * 4 + quad) * 16 + q) * 64 + lane] = acc[q];
-        }
+        for (int q = 0; q < 16; ++q) lds[((slice * 4 + quad) * 16 + q) * 64 + lane] = acc[q];
         __syncthreads();
-        if (slice > 0) return;
 #pragma unroll
-        for (int sl = 0; sl < KS - 1; ++sl)
+        for (int n = 0; n < NQ; ++n) {
+            float v = lds[((0 * 4 + quad) * 16 + q0 + n) * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] += lds[((sl * 4 + quad) * 16 + q) * 64 + lane];
+            for (int sl = 1; sl < KS; ++sl) v += lds[((sl * 4 + quad) * 16 + q0 + n) * 64 + lane];
+            val[n] = v;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) val[n] = acc[n];
     }
-
     GTRACE(60);
-    // Epilogue in two passes so that no load sits between two stores (stores count in vmcnt on this
-    // ISA: a load -> use between them would wait for every earlier store to complete): first every
-    // operand the epilogue needs goes into registers, then the 16 values are finished and stored.
+    // Two passes so that no load sits between two stores (stores count in vmcnt on this ISA: a
+    // load -> use between them would wait for every earlier store to complete): first every operand
+    // the epilogue needs goes into registers, then the values are finished and stored.
     const int epi = (int)g.epi;
     const int j = j0 + wn * 32 + (lane & 31);
     const bool jv = j < g.N;
+    auto row_of = [&](int n) {
+        const int q = q0 + n;
+        return i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    };
     if (g.nsplit > 1) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            if (i < Mo && jv) g.partials[((int64_t)blockIdx.z * Mo + i) * g.N + j] = acc[q];
+        for (int n = 0; n < NQ; ++n) {
+            const int i = row_of(n);
+            if (i < Mo && jv) g.partials[((int64_t)blockIdx.z * Mo + i) * g.N + j] = val[n];
         }
     } else {
-        float bj = 0.f, ax[16], ad[16];
+        float bj = 0.f, ax[NQ], ad[NQ];
         if (epi >= EPI_BIAS && epi <= EPI_BIAS_TANH && jv) bj = g.bias[j];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { ax[q] = 0.f; ad[q] = 0.f; }
+        for (int n = 0; n < NQ; ++n) { ax[n] = 0.f; ad[n] = 0.f; }
         if (epi >= EPI_MASK) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                if (i < g.M && jv) ax[q] = g.aux[(int64_t)i * g.ld_aux + j];   // the ones row has no aux row
+            for (int n = 0; n < NQ; ++n) {
+                const int i = row_of(n);
+                if (i < g.M && jv) ax[n] = g.aux[(int64_t)i * g.ld_aux + j];   // the ones row has no aux row
             }
             if (epi == EPI_ADD_TANHGRAD && g.add) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                    if (i < g.M && jv) ad[q] = g.add[(int64_t)i * g.ld_add + j];
+                for (int n = 0; n < NQ; ++n) {
+                    const int i = row_of(n);
+                    if (i < g.M && jv) ad[n] = g.add[(int64_t)i * g.ld_add + j];
                 }
             }
         }
         const float alpha = g.alpha;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            float v = acc[q];
+        for (int n = 0; n < NQ; ++n) {
+            const int i = row_of(n);
+            float v = val[n];
             switch (epi) {   // registers only
                 case EPI_BIAS: v += bj; break;
                 case EPI_BIAS_LRELU: { const float x = v + bj; v = fmaxf(x, 0.2f * x); break; }
@@ -371,13 +404,13 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
                     v = fminf(fmaxf(a, -alpha), alpha);  // clip_acs (sam_agent.py:97,177)
                     break;
                 }
-                case EPI_MASK: v *= (ax[q] >= 0.f ? 1.f : 0.2f); break;
+                case EPI_MASK: v *= (ax[n] >= 0.f ? 1.f : 0.2f); break;
                 case EPI_ADD_TANHGRAD: {
-                    const float t = ax[q] / alpha;
-                    v = (v + ad[q]) * (alpha * (1.f - t * t));
+                    const float t = ax[n] / alpha;
+                    v = (v + ad[n]) * (alpha * (1.f - t * t));
                     break;
                 }
-                case EPI_AXPY: if (i < g.M) v += alpha * ax[q]; break;
+                case EPI_AXPY: if (i < g.M) v += alpha * ax[n]; break;
                 default: break;
             }
             if (i < Mo && jv) g.C[(int64_t)i * g.ldc + j] = v;
