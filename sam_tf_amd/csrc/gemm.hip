@@ -201,7 +201,10 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
     // A "step" covers SPB consecutive 32-deep stages behind ONE barrier: the 16-wave variant has only
     // four MFMAs per wave and stage, so it takes two stages per barrier (a barrier + wait + issue round
     // costs ~0.4 us there against 0.44 us of matrix-core time per stage).
-    constexpr int SPB = KS == 1 ? 1 : 2;            // stages per step
+#ifndef SAMX_GEMM_SPB
+#define SAMX_GEMM_SPB 2
+#endif
+    constexpr int SPB = KS == 1 ? 1 : SAMX_GEMM_SPB;   // stages per step
     constexpr int NSU = 3;                          // steps in the ring: one computing, two in flight
     constexpr int NS = NSU * SPB;                   // stage slots
     static_assert(NS == ring<KS>(), "launch_inst sizes the LDS from ring<KS>()");
