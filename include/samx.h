@@ -165,11 +165,13 @@ int samx_rms_distance(const float* a, const float* b, int64_t n, float* out, voi
  * fma chain of v_mfma_f32_32x32x2_f32.  epi: 0 none, 1 +bias[j], 2 lrelu(+bias), 3 alpha*tanh(+bias) clipped,
  * 4 * lrelu'(aux[i,j]), 5 (acc + add[i,j]) * tanh'(aux), 6 acc + alpha*aux[i,j].  a_ones_rows >= 0 appends a
  * virtual row M to A with A(M,r) = (r < a_ones_rows) (bias gradient); nsplit > 1 splits r over
- * workgroups through partials[nsplit][M(+1)][N] with a fixed-order reduce. */
+ * workgroups through partials[nsplit][M(+1)][N] with a fixed-order reduce.  overread_ok != 0: the caller
+ * guarantees 16 readable bytes behind the last element of A and of B, which lets operands whose contiguous
+ * extent is not a multiple of 4 use the 16-byte staging path too (the values read there are never used). */
 int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, int64_t b_sr, int64_t b_sj,
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t R, int32_t a_ones_rows, int32_t epi,
                   const float* bias, const float* aux, int64_t ld_aux, const float* add, int64_t ld_add,
-                  float alpha, int32_t nsplit, float* partials, void* stream);
+                  float alpha, int32_t nsplit, float* partials, int32_t overread_ok, void* stream);
 
 /* ---- network passes ------------------------------------------------------------------------ */
 /* ob_mean/ob_std: float[ob] from samx_rms_commit, or NULL when rmsify_obs is off

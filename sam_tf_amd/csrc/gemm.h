@@ -38,6 +38,12 @@ struct GemmArgs {
     // kernel applies the epilogue; partials must hold nsplit*Mo*N floats (Mo = M or M+1)
     int nsplit = 1;
     float* partials = nullptr;
+    // 16-byte staging of an operand whose contiguous extent is not a multiple of 4 reads up to 12 bytes
+    // past the end of a row (into the next row, or past the matrix after its last row).  Callers that
+    // guarantee 16 readable bytes behind both operands set this (nets.hip: workspace carves are padded,
+    // weight matrices are followed by their bias in the flat vector); otherwise such operands are
+    // staged with dword DMAs.
+    bool overread_ok = false;
 };
 
 int gemm(const GemmArgs& g, hipStream_t stream);

@@ -111,7 +111,7 @@ __device__ __forceinline__ void dma_one(const Operand& o, int d, int r0, int r_e
         const int f = d * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((f >> 1) & 7);   // source chunk that lands at LDS chunk lane & 7
         int gr = r0 + 4 * c;
-        gr = gr < r_end ? gr : r_end - 4;            // R % 4 == 0: chunks are whole
+        gr = gr < r_end ? gr : ((r_end - 1) & ~3);   // a chunk may straddle r_end (GemmArgs::overread_ok)
         int gf = o.f0 + f;
         gf = gf < o.F ? gf : o.F - 1;
         __builtin_amdgcn_global_load_lds((glb_float*)(o.p + (int64_t)gf * o.sf + gr), (lds_float*)(S + d * 256),
@@ -127,7 +127,7 @@ __device__ __forceinline__ void dma_one(const Operand& o, int d, int r0, int r_e
                                          4, 0, 0);
     } else if (W) {
         int gf = o.f0 + 4 * (lane & 15);
-        gf = gf < o.F ? gf : o.F - 4;                // F % 4 == 0
+        gf = gf < o.F ? gf : ((o.F - 1) & ~3);       // a chunk may straddle F (GemmArgs::overread_ok)
         int gr = r0 + 4 * d + (lane >> 4);
         gr = gr < r_end ? gr : r_end - 1;
         __builtin_amdgcn_global_load_lds((glb_float*)(o.p + (int64_t)gr * o.sr + gf), (lds_float*)(S + d * 256),
@@ -148,7 +148,14 @@ __device__ __forceinline__ void zero_tail(int rv, float* S, int d, int lane) {
     if (RC && W) {
         const int f = d * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((f >> 1) & 7);
-        if (4 * c >= rv) *(f32x4*)(S + d * 256 + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * c + 3 >= rv) {
+            f32x4* p = (f32x4*)(S + d * 256 + lane * 4);
+            f32x4 x = *p;   // own words, landed (this wave's vmcnt wait precedes)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * c + e >= rv) x[e] = 0.f;
+            *p = x;
+        }
     } else if (RC) {
         if (((lane & 31) ^ ((2 * d + (lane >> 5)) & 31)) >= rv) S[d * 64 + lane] = 0.f;
     } else if (W) {
@@ -461,8 +468,9 @@ int launch_layout(const GemmArgs& g, dim3 grid, bool few, hipStream_t stream) {
     // 16-byte staging needs whole 4-element chunks along the operand's contiguous index
     static int narrow = -1;  // SAMX_GEMM_NARROW=1: dword staging everywhere (A/B experiments)
     if (narrow < 0) { const char* e = getenv("SAMX_GEMM_NARROW"); narrow = e ? atoi(e) : 0; }
-    const bool aw = !narrow && (A_RC ? g.R % 4 == 0 && g.R >= 4 : g.M % 4 == 0 && g.M >= 4);
-    const bool bw = !narrow && (B_RC ? g.R % 4 == 0 && g.R >= 4 : g.N % 4 == 0 && g.N >= 4);
+    const int ea = A_RC ? g.R : g.M, eb = B_RC ? g.R : g.N;   // extent along the contiguous index
+    const bool aw = !narrow && ea >= 4 && (ea % 4 == 0 || g.overread_ok);
+    const bool bw = !narrow && eb >= 4 && (eb % 4 == 0 || g.overread_ok);
     if (few) {  // 16 waves: both wide or both narrow (every wave issues the same number of DMAs)
         if (aw && bw) return launch_inst<A_RC, B_RC, 4, true, true>(g, grid, stream);
         return launch_inst<A_RC, B_RC, 4, false, false>(g, grid, stream);
@@ -528,7 +536,8 @@ extern "C" int samx_debug_gemm_trace(unsigned long long* host_out) {
 extern "C" int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, int64_t b_sr, int64_t b_sj,
                              float* C, int64_t ldc, int32_t M, int32_t N, int32_t R, int32_t a_ones_rows,
                              int32_t epi, const float* bias, const float* aux, int64_t ld_aux, const float* add,
-                             int64_t ld_add, float alpha, int32_t nsplit, float* partials, void* stream) {
+                             int64_t ld_add, float alpha, int32_t nsplit, float* partials, int32_t overread_ok,
+                             void* stream) {
     samx::GemmArgs g;
     g.A = A; g.a_si = a_si; g.a_sr = a_sr;
     g.B = B; g.b_sr = b_sr; g.b_sj = b_sj;
@@ -537,6 +546,7 @@ extern "C" int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const f
     g.epi = (samx::Epilogue)epi;
     g.bias = bias; g.aux = aux; g.ld_aux = ld_aux; g.add = add; g.ld_add = ld_add; g.alpha = alpha;
     g.nsplit = nsplit; g.partials = partials;
+    g.overread_ok = overread_ok != 0;
     SAMX_REQUIRE(epi < samx::EPI_BIAS || epi > samx::EPI_BIAS_TANH || bias, "samx_gemm_f32: epilogue %d needs bias", epi);
     SAMX_REQUIRE(epi < samx::EPI_MASK || aux, "samx_gemm_f32: epilogue %d needs aux", epi);
     return samx::gemm(g, (hipStream_t)stream);

@@ -581,6 +581,7 @@ int fwd(const float* X, int64_t ldx, int64_t M, int K, const float* W, const flo
     g.C = Y; g.ldc = ldy;
     g.M = (int)M; g.N = N; g.R = K;
     g.epi = epi; g.bias = b; g.alpha = alpha; g.aux = aux; g.ld_aux = ld_aux;
+    g.overread_ok = true;   // X: padded workspace carve; W: followed by its bias in the flat vector
     return gemm(g, st);
 }
 
@@ -594,6 +595,7 @@ int bwd_data(const float* dZ, int64_t ldz, int64_t M, int N, const float* W, int
     g.C = dX; g.ldc = ldx;
     g.M = (int)M; g.N = K; g.R = N;
     g.epi = epi; g.aux = aux; g.ld_aux = ld_aux; g.add = add; g.ld_add = ld_add; g.alpha = alpha;
+    g.overread_ok = true;
     return gemm(g, st);
 }
 
@@ -612,6 +614,7 @@ int wgrad(const float* X, int64_t ldx, int K, const float* dZ, int64_t ldz, int 
     g.nsplit = pick_nsplit(K + 1, N, (int)rows);
     if ((size_t)g.nsplit * (K + 1) * N > partial_floats) g.nsplit = 1;
     g.partials = partials;
+    g.overread_ok = true;
     return gemm(g, st);
 }
 

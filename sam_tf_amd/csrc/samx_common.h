@@ -45,7 +45,7 @@ struct Arena {
     template <typename T>
     T* take(size_t count) {
         size_t o = align_up(off, 256);
-        off = o + count * sizeof(T);
+        off = o + count * sizeof(T) + 16;   // 16 readable bytes behind every carve (GemmArgs::overread_ok)
         if (dry) return nullptr;
         return (T*)(base + o);
     }

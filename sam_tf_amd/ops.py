@@ -582,7 +582,7 @@ def step_apply(L, B, mode, grad_scale=1.0):
 
 
 def gemm_f32(A, a_strides, B, b_strides, M, N, R, epi=0, bias=None, aux=None, add=None, alpha=0.0,
-             a_ones_rows=-1, nsplit=1, out=None):
+             a_ones_rows=-1, nsplit=1, out=None, overread_ok=False):
     """C[M(+1), N] = epi(sum_r A(i,r) B(r,j)) with explicit (free, reduction) / (reduction, free) element
     strides — the building block of the layer-wise path (samx_gemm_f32)."""
     Mo = M + (1 if a_ones_rows >= 0 else 0)
@@ -592,5 +592,5 @@ def gemm_f32(A, a_strides, B, b_strides, M, N, R, epi=0, bias=None, aux=None, ad
                              C_.stride(0), M, N, R, a_ones_rows, epi, ptr(bias), ptr(aux),
                              aux.stride(0) if aux is not None else 0, ptr(add),
                              add.stride(0) if add is not None else 0, float(alpha), nsplit, ptr(partials),
-                             stream_ptr()))
+                             int(bool(overread_ok)), stream_ptr()))
     return C_

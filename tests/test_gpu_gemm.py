@@ -13,23 +13,33 @@ SHAPES = [(64, 64, 32), (37, 70, 33), (1024, 256, 376), (1024, 256, 393), (1000,
           (2048, 400, 376), (2050, 398, 402), (4096, 300, 400), (8192, 400, 100), (3, 5, 7), (256, 256, 4)]
 
 
+def _padded(x):
+    """Device copy of x with 16 readable bytes behind its last element (overread_ok contract)."""
+    buf = torch.full((x.size + 4,), float('nan'), dtype=torch.float32, device='cuda')
+    buf[:x.size] = torch.as_tensor(np.ascontiguousarray(x).ravel()).cuda()
+    return buf[:x.size].view(*x.shape)
+
+
 def _operands(layout, M, N, R, rs):
     a = rs.randn(M, R).astype(np.float32)
     b = rs.randn(R, N).astype(np.float32)
-    A = torch.as_tensor(a if layout != 'TN' else np.ascontiguousarray(a.T)).cuda()
-    B = torch.as_tensor(b if layout != 'NT' else np.ascontiguousarray(b.T)).cuda()
+    A = _padded(a if layout != 'TN' else a.T)
+    B = _padded(b if layout != 'NT' else b.T)
     a_str = (R, 1) if layout != 'TN' else (1, M)
     b_str = (N, 1) if layout != 'NT' else (1, R)
     return a, b, A, B, a_str, b_str
 
 
+@pytest.mark.parametrize('overread', [False, True])
 @pytest.mark.parametrize('layout', ['NN', 'NT', 'TN'])
 @pytest.mark.parametrize('M,N,R', SHAPES)
-def test_gemm_layouts_and_shapes(layout, M, N, R):
+def test_gemm_layouts_and_shapes(layout, M, N, R, overread):
+    """overread=True: 16-byte staging also for extents that are not a multiple of 4 (what nets.hip uses;
+    the bytes behind each operand are NaN here, so any use of an over-read value would show)."""
     from sam_tf_amd import ops
     rs = np.random.RandomState(M + 3 * N + 7 * R)
     a, b, A, B, a_str, b_str = _operands(layout, M, N, R, rs)
-    got = ops.gemm_f32(A, a_str, B, b_str, M, N, R).cpu().numpy()
+    got = ops.gemm_f32(A, a_str, B, b_str, M, N, R, overread_ok=overread).cpu().numpy()
     want = a.astype(np.float64) @ b.astype(np.float64)
     assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
 
@@ -67,13 +77,15 @@ def test_gemm_epilogues(epi, M, N, R):
 @pytest.mark.parametrize('M,N,R,nsplit,ones', [(256, 256, 1024, 8, 1024), (393, 400, 8192, 14, 8192),
                                                  (376, 256, 1000, 4, 600), (17, 300, 2048, 16, -1),
                                                  (64, 64, 4096, 1, 4096)])
-def test_gemm_weight_gradient_form(M, N, R, nsplit, ones):
+@pytest.mark.parametrize('overread', [False, True])
+def test_gemm_weight_gradient_form(M, N, R, nsplit, ones, overread):
     """TN product with the reduction split over workgroups and the virtual ones row (bias gradient =
     column sums of the first `ones` rows of B)."""
     from sam_tf_amd import ops
     rs = np.random.RandomState(M + N)
     a, b, A, B, a_str, b_str = _operands('TN', M, N, R, rs)
-    got = ops.gemm_f32(A, a_str, B, b_str, M, N, R, a_ones_rows=ones, nsplit=nsplit).cpu().numpy()
+    got = ops.gemm_f32(A, a_str, B, b_str, M, N, R, a_ones_rows=ones, nsplit=nsplit,
+                       overread_ok=overread).cpu().numpy()
     want = a.astype(np.float64) @ b.astype(np.float64)
     if ones >= 0:
         want = np.concatenate([want, b[:ones].astype(np.float64).sum(0, keepdims=True)])
