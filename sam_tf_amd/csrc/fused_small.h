@@ -110,6 +110,7 @@ struct ApplyArgs {
 };
 
 bool supported(const samx_mlp* d, int64_t B);
+bool fits_lds(int ob, int ac);
 int seg_blocks(int64_t n);
 struct StepArgs {
     AgentArgs a;

@@ -1150,6 +1150,11 @@ bool supported(const samx_mlp* d, int64_t B) {
            B % R == 0;
 }
 
+// the agent roles keep three networks + their tiles in LDS: wide inputs do not fit (-> layer-wise path)
+bool fits_lds(int ob, int ac) {
+    return agent_lds_bytes(ob, ac, true) <= 150 * 1024 && disc_lds_bytes(ob + ac) <= 150 * 1024;
+}
+
 int seg_blocks(int64_t n) {
     int64_t b = (n + 63) / 64;
     return (int)(b < 1 ? 1 : (b > kMaxSegBlocks ? kMaxSegBlocks : b));

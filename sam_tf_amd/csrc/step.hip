@@ -60,7 +60,7 @@ bool use_fused(const samx_learner* L, int64_t B) {
     if (L->ret_mean || L->n_step > 0) return false;  // return normalisation / n-step: layer-wise path
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
            fused::supported(&L->reward, B) && L->critic.in_dim == L->ob_dim + L->ac_dim &&
-           L->reward.in_dim == L->critic.in_dim;
+           L->reward.in_dim == L->critic.in_dim && fused::fits_lds(L->ob_dim, L->ac_dim);
 }
 
 StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {

@@ -126,16 +126,23 @@ class OracleLearner(object):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'widein', 'edge64'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
     import bench
     from sam_tf_amd.comm import TorchComm
     base, _, opt = cfg_name.partition('-')
-    cfg = dict(bench.CONFIGS[base], mem=2048, ln=opt in ('ln', 'launcher'), ret=opt in ('launcher', 'ret'),
-               nstep=7 if opt == 'launcher' else 0, p_done=0.1)
+    # widein: 64x64 nets whose three resident networks + tiles exceed the LDS budget of the whole-network
+    # kernels (critic input 60 wide) -> must take the layer-wise path, not fail at launch.
+    # edge64: the widest input the whole-network kernels still hold.
+    extra = {'widein': dict(ob=50, ac=10, h=(64, 64), B=32, per=False, name='wide-input'),
+             'edge64': dict(ob=20, ac=4, h=(64, 64), B=32, per=True, name='edge')}
+    cfg = dict(extra.get(base) or bench.CONFIGS[base], mem=2048, ln=opt in ('ln', 'launcher'),
+               ret=opt in ('launcher', 'ret'), nstep=7 if opt == 'launcher' else 0, p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
+    if base in extra:
+        assert drv.fused == (base == 'edge64')
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
     K = 6
@@ -215,7 +222,8 @@ def test_drop_in_surface():
     m, s = mu.obs_rms.mean.cpu().numpy(), mu.obs_rms.std.cpu().numpy()
     dm, ds = d.obs_rms.mean.cpu().numpy(), d.obs_rms.std.cpu().numpy()
     er = NO.reward(d.reward_nn.get_flat(), NO.MLP(7, 64, 64, 1, False), ob[None], ac[None], dm, ds)
-    assert abs(d.get_reward(ob, ac) - float(er)) < 1e-5 * max(1.0, abs(float(er)))
+    er = float(np.asarray(er).ravel()[0])
+    assert abs(d.get_reward(ob, ac) - er) < 1e-5 * max(1.0, abs(er))
     xp = mu.replay_buffer.sample_uniform(16)
     feeds = {d.p_obs: xp['obs0'], d.p_acs: xp['acs'], d.e_obs: rs.randn(16, 5), d.e_acs: rs.rand(16, 2)}
     d.obs_rms.update(np.concatenate((feeds[d.p_obs], feeds[d.e_obs])), comm)
