@@ -98,7 +98,8 @@ def build_learner(cfg, comm, device, seed, use_graph):
         for _ in range(200):
             idx = rs.randint(0, rb.num_entries, size=cfg['B'])
             rb.update_priorities(idx, np.abs(rs.randn(cfg['B'])) + 1e-6)
-    drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph)
+    drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph, d_steps=int(cfg.get('d_steps', 1)),
+                           g_steps=int(cfg.get('g_steps', 1)))
     return mu, d, pool, drv
 
 
@@ -173,6 +174,8 @@ def main():
                     help='the canonical launcher options (mujoco_sam_imitate.sh): layernorm, rmsify_rets, '
                          'popart, n-step returns n=96')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--no-training-step', action='store_true',
+                    help='skip the extra d_steps=1 : g_steps=3 training-step figure (config.training_steps_per_s)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -294,6 +297,20 @@ def main():
             if rank == 0:
                 print(json.dumps(result), flush=True)
             os._exit(0)
+    if world == 1 and not args.no_training_step and not rehearse:
+        # the reference's loop runs d_steps = 1 discriminator update and g_steps = 3 agent
+        # updates per training step (mujoco_sam_imitate.sh:26-27); `value` above is the 1:1 step of the
+        # metric, this is the same learner on that schedule (one D+agent row, two agent-only rows)
+        from sam_tf_amd.driver import UpdateStepDriver
+        drv3 = UpdateStepDriver(mu, d, pool, use_graph=not args.no_graph, d_steps=1, g_steps=3)
+        drv3.prepare_all()
+        n_ts = max(10, args.steps // 4)
+        drv3.run(3 * max(5, args.warmup // 4))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drv3.run(3 * n_ts)
+        torch.cuda.synchronize()
+        result['config']['training_steps_per_s_d1_g3'] = n_ts / (time.perf_counter() - t0)
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline(cfg)

@@ -391,7 +391,11 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
 /* Measurement aid: the same call split in two.  part 1 = the network passes only (fused path: the one
  * whole-network kernel; layer-wise path: the GEMM chains of the three roles), part 2 = the reduction
  * of the per-tile partials / norms / scalar losses / step tick, part 3 = both (= samx_step_grads).
- * bench.py times part 1 alone with HIP events for the roofline line. */
+ * bench.py times part 1 alone with HIP events for the roofline line.
+ * Role subsets (the reference runs d_steps discriminator updates, then g_steps agent updates per training
+ * step, sam.py:323-433; launcher: 1 and 3): part bit 2 (value 4) leaves the discriminator role out, bit 3
+ * (value 8) the agent roles; the optimiser segments, losses, statistics commit and step counters of the
+ * role left out are not touched.  Pass the same subset to samx_step_apply (mode bits 3 and 4). */
 int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const samx_step_out* out,
                          void* ws, size_t ws_bytes, int part, void* stream);
 
@@ -399,7 +403,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const s
  * mode bit 0: write learner.clipped = grads clipped by their own norm (tf_util.py:137-151);
  * mode bit 1: grads * grad_scale -> clip_by_global_norm -> Adam -> Polyak on the agent's targets;
  * mode bit 2: recompute the norms first (set it when grads changed after samx_step_grads, i.e. after
- * the all-reduce).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
+ * the all-reduce); mode bit 3 (value 8): leave the reward-net segment out, bit 4 (value 16): leave the
+ * actor and critic segments out (role subsets, see samx_step_grads_part).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
  * grad_scale = 1/N.  `ws` must be the workspace samx_step_grads used, B the same batch size. */
 int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale, void* ws,
                     size_t ws_bytes, void* stream);

@@ -117,18 +117,20 @@ int check_learner(const samx_learner* L, const char* who) {
     return SAMX_OK;
 }
 
-fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale) {
+// segs: bit k set = optimiser segment k (0 actor, 1 critic, 2 reward net) takes part
+fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale, int segs = 7) {
     const int64_t Pa = samx_mlp_param_count(&L->actor), Pc = samx_mlp_param_count(&L->critic),
                   Pd = samx_mlp_param_count(&L->reward);
     const int64_t off[3] = {0, Pa, Pa + Pc}, n[3] = {Pa, Pc, Pd};
     const float lr[3] = {L->actor_lr, L->critic_lr, L->d_lr};
     fused::ApplyArgs f;
-    f.nseg = 3;
+    f.nseg = 0;
     f.mode = mode;
     f.grad_scale = grad_scale;
     f.beta1 = L->beta1; f.beta2 = L->beta2; f.eps = L->adam_eps; f.tau = L->polyak;
     for (int k = 0; k < 3; ++k) {
-        fused::ApplySeg& s = f.seg[k];
+        if (!(segs & (1 << k))) continue;
+        fused::ApplySeg& s = f.seg[f.nseg++];
         s.param = L->params + off[k];
         s.m = L->adam_m + off[k];
         s.v = L->adam_v + off[k];
@@ -472,7 +474,10 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
 int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                          size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
-    SAMX_REQUIRE(part >= 1 && part <= 3, "samx_step_grads_part: part must be 1, 2 or 3");
+    SAMX_REQUIRE((part & ~15) == 0 && (part & 3) != 0 && (part & 12) != 12,
+                 "samx_step_grads_part: part uses bits 0-3, needs bit 0 or 1, and cannot skip both roles");
+    const bool do_d = !(part & 4), do_a = !(part & 8);   // roles of this call
+    const int segs = (do_a ? 3 : 0) | (do_d ? 4 : 0);
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(b && o && ws, "samx_step_grads: null argument");
     SAMX_REQUIRE(b->B > 0, "samx_step_grads: empty batch");
@@ -507,10 +512,11 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         SAMX_REQUIRE(L->d_mean && L->d_std, "samx_step_grads: inline statistics need learner.d_mean/d_std");
     }
     if (!use_fused(L, B) && !(part & 1)) {  // reduction part only
-        fused::ApplyArgs f = make_apply(L, w, 0, 1.f);
+        fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;
-        return fused::launch_tick(L->steps, L->steps + 1, L->steps + 2, st);
+        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
+                                  do_d ? L->steps + 2 : nullptr, st);
     }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense
@@ -518,18 +524,18 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         samx_batch dense = *b;
         const samx_batch* orig = b;
         const int ob = L->ob_dim, ac = L->ac_dim;
-        if (b->p_idx) {
+        if (b->p_idx && do_d) {
             rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
                                     ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
             if (rc != SAMX_OK) return rc;
             dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
         }
-        if (b->e_start) {
+        if (b->e_start && do_d) {
             expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
             SAMX_LAUNCH_CHECK();
             dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
         }
-        if (b->a_idx) {
+        if (b->a_idx && do_a) {
             rc = samx_replay_gather(b->obs0, b->acs, b->rews, b->dones1, b->obs1, b->ring_len, b->ring_start,
                                     ob, ac, b->a_idx, B, w.g_obs0, w.g_acs, w.g_rews, w.g_dones, w.g_obs1,
                                     stream);
@@ -537,7 +543,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             dense.obs0 = w.g_obs0; dense.acs = w.g_acs; dense.rews = w.g_rews; dense.dones1 = w.g_dones;
             dense.obs1 = w.g_obs1;
         }
-        if (!b->eps_ob) {
+        if (!b->eps_ob && do_d) {
             const int64_t n = B * (ob + ac + 2);
             randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
                 b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
@@ -553,7 +559,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (serial < 0) { const char* e = getenv("SAMX_SERIAL_ROLES"); serial = e ? atoi(e) : 0; }
         hipStream_t s_tc = st, s_a = st;
         SideStreams* ss = nullptr;
-        if (!serial) {
+        if (!serial && do_a) {
             rc = side_streams(&ss);
             if (rc != SAMX_OK) return rc;
             SAMX_CHECK_HIP(hipEventRecord(ss->fork, st));
@@ -567,6 +573,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         const bool popart_or_stats = L->ret_mean && L->enable_popart;  // sam_agent.py:662 (update only then)
         // ---- target + critic role (side 0)
         const float* tcns = nullptr;
+        if (do_a) {
         if (L->n_step > 0) {  // n-step lookahead from the sampled indices (memory.py:113-160)
             SAMX_REQUIRE(orig->a_idx && orig->num_entries > 0,
                          "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
@@ -599,7 +606,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, tcns ? w.ret_add2 : nullptr, L->ret_mean,
                                         L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
-            if (!serial) {  // the actor role reads the rescaled critic head and the new statistics
+            if (ss) {  // the actor role reads the rescaled critic head and the new statistics
                 SAMX_CHECK_HIP(hipEventRecord(ss->mid, s_tc));
                 SAMX_CHECK_HIP(hipStreamWaitEvent(s_a, ss->mid, 0));
             }
@@ -615,22 +622,26 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                              L->d_actor_loss_scale, o->actor_losses, L->grads, ret, w.nets_ws2, w.nets_bytes,
                              (void*)s_a);
         if (rc != SAMX_OK) return rc;
+        }  // do_a
+        if (do_d) {
         rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
                             b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,
                             L->ent_reg_scale, o->d_losses, L->grads + Pa + Pc, w.disc_ws, w.disc_bytes,
                             stream);
         if (rc != SAMX_OK) return rc;
-        if (!serial) {  // join
+        }  // do_d
+        if (ss) {  // join
             for (int i = 0; i < 2; ++i) {
                 SAMX_CHECK_HIP(hipEventRecord(ss->join[i], ss->s[i]));
                 SAMX_CHECK_HIP(hipStreamWaitEvent(st, ss->join[i], 0));
             }
         }
         if (!(part & 2)) return SAMX_OK;
-        fused::ApplyArgs f = make_apply(L, w, 0, 1.f);
+        fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;
-        return fused::launch_tick(L->steps, L->steps + 1, L->steps + 2, st);
+        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
+                                  do_d ? L->steps + 2 : nullptr, st);
     }
 
     const int tiles = (int)(B / fused::kRows);
@@ -657,17 +668,18 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     a.partials = w.agent_part; a.P = Pa + Pc; a.Pa = Pa; a.loss_part = w.agent_loss;
     a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
     if (part & 1) {
-        rc = fused::launch_step(&a, &d, st);
+        rc = fused::launch_step(do_a ? &a : nullptr, do_d ? &d : nullptr, st);
         if (rc != SAMX_OK) return rc;
     }
     if (!(part & 2)) return SAMX_OK;
 
     fused::FinalizeArgs f;
-    f.nseg = 3;
+    f.nseg = 0;
     f.B = B;
     const int64_t off[3] = {0, Pa, Pa + Pc}, n[3] = {Pa, Pc, Pd};
     for (int k = 0; k < 3; ++k) {
-        fused::Segment& s = f.seg[k];
+        if (!(segs & (1 << k))) continue;
+        fused::Segment& s = f.seg[f.nseg++];
         s.partials = k < 2 ? w.agent_part + off[k] : w.disc_part;
         s.slot_stride = k < 2 ? Pa + Pc : Pd;
         s.nslots = k < 2 ? tiles : 3 * tiles;
@@ -679,21 +691,21 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         s.wd = 0.f; s.param = nullptr; s.wd0_lo = s.wd0_hi = s.wd1_lo = s.wd1_hi = 0;
         s.step_dev = L->steps + k;
     }
-    {   // weight decay on the critic's two hidden kernels (networks.py:385-386,406-412)
+    if (do_a) {   // weight decay on the critic's two hidden kernels (networks.py:385-386,406-412)
         fused::Segment& s = f.seg[1];
         const int64_t inc = L->critic.in_dim, h = 64;
         s.wd = L->wd_scale; s.param = pc;
         s.wd0_lo = 0; s.wd0_hi = inc * h;
         s.wd1_lo = inc * h + h; s.wd1_hi = s.wd1_lo + h * h;
     }
-    f.agent_loss_part = w.agent_loss; f.agent_tiles = tiles;
+    f.agent_loss_part = do_a ? w.agent_loss : nullptr; f.agent_tiles = tiles;
     f.q_scale = L->q_actor_loss_scale; f.d_scale = L->d_actor_loss_scale;
     f.td_scale = L->td_loss_scale; f.wd_scale = L->wd_scale;
     f.actor_losses = o->actor_losses; f.critic_losses = o->critic_losses;
-    f.disc_loss_part = w.disc_loss; f.disc_tiles_b = tiles;
+    f.disc_loss_part = do_d ? w.disc_loss : nullptr; f.disc_tiles_b = tiles;
     f.ent_scale = L->ent_reg_scale; f.gp_coeff = 10.f; f.gp = w.gp_out; f.disc_losses = o->d_losses;
-    f.gp_part = w.gp_part; f.gp_tiles = tiles; f.ob = L->ob_dim; f.ac = L->ac_dim;
-    f.rms_sums = b->d_rms_sums; f.rms_addvec = b->d_rms_addvec;
+    f.gp_part = do_d ? w.gp_part : nullptr; f.gp_tiles = tiles; f.ob = L->ob_dim; f.ac = L->ac_dim;
+    f.rms_sums = do_d ? b->d_rms_sums : nullptr; f.rms_addvec = do_d ? b->d_rms_addvec : nullptr;
     f.rms_mean = const_cast<float*>(L->d_mean); f.rms_std = const_cast<float*>(L->d_std);
     return fused::launch_finalize(f, st);
 }
@@ -703,13 +715,15 @@ int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale
     int rc = check_learner(L, "samx_step_apply");
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(ws && B > 0, "samx_step_apply: null workspace or bad batch");
-    SAMX_REQUIRE((mode & ~7) == 0 && (mode & 3) != 0, "samx_step_apply: mode must use bits 0-2");
+    SAMX_REQUIRE((mode & ~31) == 0 && (mode & 3) != 0 && (mode & 24) != 24,
+                 "samx_step_apply: mode uses bits 0-4, needs bit 0 or 1, and cannot skip every segment");
+    const int segs = ((mode & 16) ? 0 : 3) | ((mode & 8) ? 0 : 4);
     SAMX_REQUIRE(!(mode & 1) || L->clipped, "samx_step_apply: mode bit 0 needs learner.clipped");
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     StepWs w = carve(ar, L, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_step_apply: workspace %zu < %zu", ws_bytes, ar.off);
-    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale);
+    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs);
     if (mode & 4) {  // gradients changed since samx_step_grads (all-reduce): recompute the norms
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;

@@ -1,5 +1,5 @@
-"""Host driver for one "SAM update step" — the body of the reference's training loop
-(imitation_algorithms/sam.py:323-433) with d_steps = g_steps = 1:
+"""Host driver for the body of the reference's training loop (imitation_algorithms/sam.py:323-433).
+One "SAM update step" (d_steps = g_steps = 1, the bench metric) is:
 
     discriminator update : uniform replay pairs + expert pairs -> d.obs_rms.update -> D loss/grad
                            (+GP) -> all-reduce -> clip -> Adam                 (sam.py:369-406)
@@ -18,6 +18,13 @@ random tensors are drawn inside the kernels (Philox keyed by seed and update cou
 step: the reference's RNG draws (np.random.randint / random.random, same generators, same order), ONE
 packed pinned H2D copy, the graph launches, and for N > 1 the RCCL calls.  Data-parallel ranks each own a
 replay shard and a minibatch; only gradients and running-mean sums are exchanged.
+
+d_steps / g_steps other than 1 (the launcher runs 1 discriminator and 3 agent updates per training step):
+a training step becomes a sequence of ROWS, each with a role subset — D-only rows first, then rows that
+carry a D and an agent update side by side, then agent-only rows.  The two updates do not read each other's
+parameters (d_actor_loss_scale = 0, or an untied reward-net copy), so this is the reference's
+"all D updates, then all agent updates" with every update sequence in its own order; the host RNG draws
+keep the reference's order.  `step()` / `run(n)` count rows.
 """
 import random as _random
 
@@ -51,8 +58,19 @@ class _Slot(object):
 
 class UpdateStepDriver(object):
 
-    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16):
+    D, A = 1, 2   # role bits of a row
+
+    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16, d_steps=1, g_steps=1):
         self.mu, self.d, self.pool = mu, d, expert_pool
+        assert d_steps >= 1 and g_steps >= 1
+        if mu.hps.d_actor_loss_scale != 0 and mu.hps.tie_actor_reward_net:
+            raise NotImplementedError('a reward net shared between the discriminator and the actor loss makes '
+                                      'the agent update read the discriminator update of the same step: '
+                                      'use SAMAgent.train() / Discriminator.optimize() in sequence')
+        both = min(d_steps, g_steps)
+        self.d_steps, self.g_steps = int(d_steps), int(g_steps)
+        self.sched = [self.D] * (d_steps - both) + [self.D | self.A] * both + [self.A] * (g_steps - both)
+        self.S = len(self.sched)
         self.L = mu.L
         self.comm = mu.comm
         self.world = self.comm.Get_size()
@@ -68,7 +86,10 @@ class UpdateStepDriver(object):
         # N > 1 also packs K steps per host iteration: the D-input sums of all K steps are computed and
         # all-reduced ONCE (they do not depend on the learner), which leaves one collective per step.
         self.fused = self.L.fused(B)
-        self.K = int(steps_per_launch) if (self.use_graph and not self.per) else 1
+        m = 1
+        while 2 * m * self.S <= int(steps_per_launch):
+            m *= 2
+        self.K = m * self.S if (self.use_graph and not self.per) else 1   # rows per launch: whole training steps
         if self.world > 1 and not self.fused:
             self.K = 1   # layer-wise path under N > 1: the three-segment plan, one step per launch
         # N > 1 with a communicator whose all-reduce runs on the caller's stream (sam_tf_amd.rccl): the
@@ -109,7 +130,7 @@ class UpdateStepDriver(object):
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
         self.slots = [_Slot(B, self.K) for _ in range(n_slots)]
-        self.step_no = 0
+        self.step_no = 0     # rows done
         self.launch_no = 0
         self.plans = {}
         self._make_batch()
@@ -141,10 +162,10 @@ class UpdateStepDriver(object):
         self.batch = self.batches[0]
 
     # ------------------------------------------------------------------ device segments
-    def _seg_inputs(self, k=0):
+    def _seg_inputs(self, k=0, role=3):
         """d.obs_rms.update on the D batch (sam.py:389-390); single process: sums + commit at once."""
         d, rb = self.d, self.mu.replay_buffer
-        if d.hps.rmsify_obs and not self.inline_stats:
+        if d.hps.rmsify_obs and not self.inline_stats and role & self.D:
             r = d.obs_rms
             w = self.words[k]
             ops.d_input_stats(rb.store['obs0'], self._batch_start, w[:self.B], self.pool.obs0,
@@ -152,38 +173,53 @@ class UpdateStepDriver(object):
                               sums=r.sums, mean=r.mean, std=r.std)
 
     def _seg_sums(self, K):
-        """The D-input sums of all K steps of the launch (they do not depend on the learner)."""
+        """The D-input sums of all K rows of the launch (they do not depend on the learner; rows
+        without a D update carry index words 0 and their sums are not used)."""
         if self.inline_stats:
             rb = self.mu.replay_buffer
             ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], self.B,
                                   self.pool.obs0, self.addvecs[:K])
 
-    def _seg_grads(self, k=0):
+    def _masks(self, role):
+        """(part bits, apply-mode bits) that leave out the roles a row does not carry (samx.h)."""
+        return ((0 if role & self.D else 4) | (0 if role & self.A else 8),
+                (0 if role & self.D else 8) | (0 if role & self.A else 16))
+
+    def _seg_grads(self, k=0, role=3):
         mu, d = self.mu, self.d
-        if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats:
+        part, mode = self._masks(role)
+        if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats and role & self.D:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
-        if self.per:  # the pending priority update, then memory.py:248-309 on the device trees
+        if self.per and role & self.A:  # the pending priority update, then memory.py:248-309 on the device trees
             mu.replay_buffer.trees.set(self.prev_idx, self.prev_leaf)
             mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
-        ops.step_grads(self.L, self.batches[k], self.out)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part)
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
-        ops.step_apply(self.L, self.B, 3 if self.world == 1 else 1, 1.0)
+        ops.step_apply(self.L, self.B, (3 if self.world == 1 else 1) | mode, 1.0)
         if self.world == 1:
-            self._seg_refresh()
+            self._seg_refresh(role)
 
-    def _seg_apply(self):
-        ops.step_apply(self.L, self.B, 6, 1.0 / self.world)
-        self._seg_refresh()
+    def _seg_apply(self, role=3):
+        ops.step_apply(self.L, self.B, 6 | self._masks(role)[1], 1.0 / self.world)
+        self._seg_refresh(role)
 
-    def _seg_refresh(self):
-        if self.per:  # TD errors with the POST-update critic (sam_agent.py:693-701), rows read in place
+    def _seg_refresh(self, role=3):
+        if self.per and role & self.A:  # TD errors with the POST-update critic (sam_agent.py:693-701), rows read in place
             mu = self.mu
             mean, std = mu._mean_std()
             st = mu.replay_buffer.store
             ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self.idx_a, self._batch_start,
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
+
+    def _grads_of(self, role):
+        """The slice of the flat gradient a row with these roles fills (what is all-reduced)."""
+        L = self.L
+        if role == self.D | self.A:
+            return L.grads
+        n_agent = L.seg(L.grads, 0).numel() + L.seg(L.grads, 1).numel()
+        return L.grads[:n_agent] if role == self.A else L.grads[n_agent:]
 
     # ------------------------------------------------------------------ plan: graphs + collectives
     def _capture(self, run):
@@ -202,93 +238,121 @@ class UpdateStepDriver(object):
             run()
         return g.replay
 
-    def _build_plan(self, K):
-        """The list of callables one launch of K steps executes in order (graph replays and, for
-        N > 1, the collectives between them)."""
+    def _build_plan(self, K, phase=0):
+        """The list of callables one launch of K rows executes in order (graph replays and, for N > 1,
+        the collectives between them).  phase = position of the first row inside a training step."""
         d, L = self.d, self.L
         ar = self.comm.allreduce_
+        roles = [self.sched[(phase + k) % self.S] for k in range(K)]
+        any_d = any(r & self.D for r in roles)
         if self.world == 1:
-            return [self._capture(lambda: [self._seg_sums(K)] +
-                                  [(self._seg_inputs(k), self._seg_grads(k)) for k in range(K)])]
+            return [self._capture(lambda: [self._seg_sums(K) if any_d else None] +
+                                  [(self._seg_inputs(k, roles[k]), self._seg_grads(k, roles[k]))
+                                   for k in range(K)])]
         if self.collectives_in_graph:
             def run():
-                if self.inline_stats:
+                if self.inline_stats and any_d:
                     self._seg_sums(K)
                     ar(self.addvecs[:K])
                 for k in range(K):
-                    self._seg_grads(k)
-                    ar(L.grads)
-                    self._seg_apply()
+                    self._seg_grads(k, roles[k])
+                    ar(self._grads_of(roles[k]))
+                    self._seg_apply(roles[k])
             return [self._capture(run)]
         if self.inline_stats or (self.fused and not d.hps.rmsify_obs):
-            # N > 1, fused path: [sums of K steps] -> ONE all-reduce of the K float64 sum vectors ->
-            # per step: gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
+            # N > 1, fused path: [sums of K rows] -> ONE all-reduce of the K float64 sum vectors ->
+            # per row: gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
             plan = []
-            if self.inline_stats:
+            if self.inline_stats and any_d:
                 plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
-            # the optimiser pass of step k and the gradient pass of step k + 1 share one graph: per
-            # step the host issues ONE graph launch and ONE all-reduce
-            plan += [self._capture(lambda: self._seg_grads(0)), lambda: ar(L.grads)]
+            # the optimiser pass of row k and the gradient pass of row k + 1 share one graph: per
+            # row the host issues ONE graph launch and ONE all-reduce
+            plan += [self._capture(lambda: self._seg_grads(0, roles[0])), lambda: ar(self._grads_of(roles[0]))]
             for k in range(1, K):
-                plan += [self._capture(lambda k=k: (self._seg_apply(), self._seg_grads(k))),
-                         lambda: ar(L.grads)]
-            plan.append(self._capture(self._seg_apply))
+                plan += [self._capture(lambda k=k: (self._seg_apply(roles[k - 1]), self._seg_grads(k, roles[k]))),
+                         lambda k=k: ar(self._grads_of(roles[k]))]
+            plan.append(self._capture(lambda: self._seg_apply(roles[K - 1])))
             return plan
         assert K == 1
-        # N > 1, layer-wise path: one step per launch, three segments
-        plan = [self._capture(self._seg_inputs)]
-        if d.hps.rmsify_obs:
+        # N > 1, layer-wise path: one row per launch, three segments
+        role = roles[0]
+        plan = [self._capture(lambda: self._seg_inputs(0, role))]
+        if d.hps.rmsify_obs and role & self.D:
             plan.append(lambda: ar(d.obs_rms.addvec))
-        plan += [self._capture(self._seg_grads), lambda: ar(L.grads), self._capture(self._seg_apply)]
+        plan += [self._capture(lambda: self._seg_grads(0, role)), lambda: ar(self._grads_of(role)),
+                 self._capture(lambda: self._seg_apply(role))]
         return plan
 
     # ------------------------------------------------------------------ host side of a step
-    def _draw(self, slot, K):
-        """The reference's host RNG draws for K consecutive steps, in the reference's order."""
-        rb = self.mu.replay_buffer
-        B = self.B
+    def _roles(self, K, phase):
+        return [self.sched[(phase + k) % self.S] for k in range(K)]
+
+    def _draw(self, slot, K, phase):
+        """The reference's host RNG draws for K consecutive rows, in the reference's order."""
         if slot.predrawn:   # the RNG part was done while the previous launch was running
             slot.predrawn = False
-            self._fill_pending(slot)
+            self._fill_pending(slot, phase)
             return
         if slot.used:
             slot.event.synchronize()
-        self._draw_rng(slot, K)
-        self._fill_pending(slot)
+        self._draw_rng(slot, K, phase)
+        self._fill_pending(slot, phase)
 
-    def _fill_pending(self, slot):
-        if self.per:
+    def _fill_pending(self, slot, phase):
+        if self.per and self.sched[phase] & self.A:
             if self._pending is None:
                 self._pending = self._noop_update()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._pending
             self._pending = None
 
-    def _draw_rng(self, slot, K):
+    def _expert_rows(self, slot, k):
+        """demo_dataset.py:33-40: reshuffle when fewer than a batch is left, hand out the next slice."""
+        if self.pool.pointer + self.B >= self.pool.num_entries:
+            self.pool.init_pointer()
+        slot.np_e[k] = self.pool.pointer
+        self.pool.pointer += self.B
+
+    def _draw_rng(self, slot, K, phase):
         rb = self.mu.replay_buffer
-        B = self.B
-        N = rb.num_entries
-        wrap = self.pool.pointer + B >= self.pool.num_entries
-        if wrap:
-            assert K == 1, "a reshuffle of the expert pool cannot fall inside a multi-step launch"
-        # reference order inside one step: D's policy pairs (sam.py:372-377 -> memory.py:90), the
-        # expert batch (demo_dataset.py:33-40: np.random.shuffle when the pool wraps), then the agent's
-        # batch in mu.train() (memory.py:90, or memory.py:278 with `random` for PER)
-        if self.per:
-            slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
-        elif wrap:
-            slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
-        else:
-            # one call of size K*2*B consumes the generator exactly like 2K calls of size B
-            slot.np_idx[:K] = np.random.randint(low=0, high=N, size=(K, 2, B))
-        for k in range(K):
-            if self.pool.pointer + B >= self.pool.num_entries:
-                self.pool.init_pointer()
-            slot.np_e[k] = self.pool.pointer
-            self.pool.pointer += B
-        if self.per:
-            slot.np_u[0] = rb.draw_uniforms(B)                                     # memory.py:278
-        elif wrap:
-            slot.np_idx_a[0] = np.random.randint(low=0, high=N, size=B)
+        B, N = self.B, rb.num_entries
+        roles = self._roles(K, phase)
+        if K == 1:
+            # one row, drawn in the reference's order inside a step: D's policy pairs (sam.py:372-377 ->
+            # memory.py:90), the expert batch (np.random.shuffle when the pool wraps), then the agent's
+            # batch in mu.train() (memory.py:90, or memory.py:278 with `random` for PER)
+            slot.np_e[0] = 0
+            if roles[0] & self.D:
+                slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
+                self._expert_rows(slot, 0)
+            else:
+                slot.np_idx_p[0] = 0
+            if roles[0] & self.A:
+                if self.per:
+                    slot.np_u[0] = rb.draw_uniforms(B)                             # memory.py:278
+                else:
+                    slot.np_idx_a[0] = np.random.randint(low=0, high=N, size=B)
+            return
+        # whole training steps, no reshuffle inside (run() guarantees it) and uniform replay: per training
+        # step the reference draws d_steps D batches, then g_steps agent batches, all from np.random —
+        # one call of that total size consumes the generator exactly like the separate calls
+        assert phase == 0 and K % self.S == 0 and not self.per
+        T, d, g = K // self.S, self.d_steps, self.g_steps
+        draws = np.random.randint(low=0, high=N, size=(T, d + g, B))
+        k = 0
+        for t in range(T):
+            nd = na = 0
+            for role in self.sched:
+                slot.np_idx_p[k] = draws[t, nd] if role & self.D else 0
+                slot.np_e[k] = 0
+                if role & self.D:
+                    assert self.pool.pointer + B < self.pool.num_entries, \
+                        "a reshuffle of the expert pool cannot fall inside a multi-row launch"
+                    self._expert_rows(slot, k)
+                    nd += 1
+                if role & self.A:
+                    slot.np_idx_a[k] = draws[t, d + na]
+                    na += 1
+                k += 1
 
     def _noop_update(self):
         """A priority update that changes nothing (leaf 0 rewritten with its own value): what the
@@ -321,11 +385,12 @@ class UpdateStepDriver(object):
                                 want_real=self.label_mode >= 1, want_fake=self.label_mode == 2,
                                 device=self.dev)
 
-    def prepare(self, K=1):
-        """Build (and, with use_graph, capture) the device plan for launches of K steps.  Capturing
-        executes the segments — learner state, running sums and host RNG positions are snapshotted
-        and restored, so prepare() leaves the learner exactly as it found it."""
-        if K in self.plans:
+    def prepare(self, K=1, phase=0):
+        """Build (and, with use_graph, capture) the device plan for launches of K rows starting at
+        position `phase` of a training step.  Capturing executes the segments — learner state, running
+        sums and host RNG positions are snapshotted and restored, so prepare() leaves the learner
+        exactly as it found it."""
+        if (K, phase) in self.plans:
             return
         mu, d, L = self.mu, self.d, self.L
         keep = [L.params, L.targets, L.m, L.v, L.steps]
@@ -348,7 +413,7 @@ class UpdateStepDriver(object):
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
         torch.cuda.synchronize()
-        self.plans[K] = self._build_plan(K)
+        self.plans[(K, phase)] = self._build_plan(K, phase)
         torch.cuda.synchronize()
         for t, sv in zip(keep, saved):
             t.copy_(sv)
@@ -358,65 +423,75 @@ class UpdateStepDriver(object):
         torch.cuda.synchronize()
 
     def prepare_all(self):
-        """Capture every launch size run() can pick (K, K/2, ..., 1)."""
+        """Capture every launch run() can pick: K, K/2, ... whole training steps, and single rows at
+        every position of a training step."""
         K = self.K
-        while K >= 1:
+        while K > 1 and K % self.S == 0:
             self.prepare(K)
             K //= 2
+        for phase in range(self.S):
+            self.prepare(1, phase)
 
     @property
     def plan(self):
-        return self.plans.get(1)
+        return self.plans.get((1, 0))
 
     def _launch(self, K, more=False):
-        self.prepare(K)
+        phase = self.step_no % self.S
+        role = self.sched[phase]
+        self.prepare(K, phase)
         assert self.mu.replay_buffer.start == self._batch_start, \
             "replay ring moved: call driver.refresh() after appending transitions"
         slot = self.slots[self.launch_no % len(self.slots)]
-        self._draw(slot, K)
+        self._draw(slot, K, phase)
         self._upload(slot, K)
-        for run in self.plans[K]:
+        for run in self.plans[(K, phase)]:
             run()
         if self.per:
-            # |td| + 1e-6 in float32 (numpy: float32 array + python float stays float32,
-            # sam_agent.py:702), leaves = libm pow on the host, trees updated on the device
-            self._td_host.copy_(self.td_post, non_blocking=True)
-            self._idx_host.copy_(self.idx_a, non_blocking=True)
-            if more:  # the next step's host RNG draws do not depend on this step: make them now,
+            refresh = bool(role & self.A)
+            if refresh:
+                # |td| + 1e-6 in float32 (numpy: float32 array + python float stays float32,
+                # sam_agent.py:702), leaves = libm pow on the host, trees updated on the device
+                self._td_host.copy_(self.td_post, non_blocking=True)
+                self._idx_host.copy_(self.idx_a, non_blocking=True)
+            if more:  # the next row's host RNG draws do not depend on this row: make them now,
                       # while the GPU works (same generators, same order)
                 nxt = self.slots[(self.launch_no + 1) % len(self.slots)]
                 if nxt.used:
                     nxt.event.synchronize()
-                self._draw_rng(nxt, 1)
+                self._draw_rng(nxt, 1, (phase + 1) % self.S)
                 nxt.predrawn = True
-            torch.cuda.current_stream().synchronize()
-            new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
-            idxs, leaf = self.mu.replay_buffer.leaves_for(self._idx_host.numpy(), new_priorities)
-            self._pending = (idxs.copy(), leaf)   # applied by the first kernel of the next launch
+            if refresh:
+                torch.cuda.current_stream().synchronize()
+                new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
+                idxs, leaf = self.mu.replay_buffer.leaves_for(self._idx_host.numpy(), new_priorities)
+                self._pending = (idxs.copy(), leaf)   # applied by the first kernel of the next agent row
         self.step_no += K
         self.launch_no += 1
 
     def step(self):
-        """One update step (one launch); the replay trees are up to date when it returns."""
+        """One row (with d_steps = g_steps = 1: one update step); the replay trees are up to date when
+        it returns."""
         self._launch(1)
         self.flush()
 
     def run(self, n):
-        """n consecutive update steps, K per graph launch where the configuration allows it (see
-        __init__); same arithmetic and same sampled indices as n calls of step()."""
-        B, pool = self.B, self.pool
+        """n consecutive rows, whole training steps packed K per graph launch where the configuration
+        allows it (see __init__); same arithmetic and same sampled indices as n calls of step()."""
+        B, pool, S = self.B, self.pool, self.S
         while n > 0:
-            # the largest launch (K, K/2, K/4 ...) that fits the steps left and ends before the next
-            # reshuffle of the expert pool (host work between two steps, kept out of a launch)
-            K = self.K
-            while K > 1 and (K > n or pool.pointer + K * B >= pool.num_entries):
-                K //= 2
+            # the largest launch (K, K/2, ... whole training steps) that fits the rows left and ends before
+            # the next reshuffle of the expert pool (host work between two rows, kept out of a launch)
+            K = self.K if self.step_no % S == 0 else 1
+            while K > 1 and (K > n or K % S or
+                             pool.pointer + (K // S) * self.d_steps * B >= pool.num_entries):
+                K = K // 2 if (K // 2) % S == 0 else 1
             self._launch(K, more=n > K)
             n -= K
         self.flush()
 
     def set_collectives(self, in_graph):
-        """Choose between collectives captured inside the K-step graph (needs a capturable
+        """Choose between collectives captured inside the K-row graph (needs a capturable
         communicator) and collectives issued by the host between graph segments; re-plans."""
         in_graph = bool(in_graph and self.world > 1 and self.fused and self.use_graph and
                         getattr(self.comm, 'capturable', False))
@@ -429,7 +504,7 @@ class UpdateStepDriver(object):
         """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""
         self.plans = {}
         self._make_batch()
-        self.prepare()
+        self.prepare(1, self.step_no % self.S)
 
     def outputs(self):
         """What the reference's loop logs per step (sam.py:398-431), still in HBM."""

@@ -65,7 +65,16 @@ class OracleLearner(object):
         self.opt[key] = [m, v, t + 1]
         return th
 
-    def step(self, idx_p, e_obs, e_acs, eps_ob, eps_ac, real, idx_a=None, u=None, gpu_td=None):
+    def step(self, idx_p, e_obs, e_acs, eps_ob, eps_ac, real, idx_a=None, u=None, gpu_td=None, role=3):
+        """role bit 0: the discriminator update, bit 1: the agent update (a row of the driver)."""
+        out = {}
+        if role & 1:
+            out['d_losses'] = self.d_step(idx_p, e_obs, e_acs, eps_ob, eps_ac, real)
+        if role & 2:
+            out.update(self.a_step(idx_a, u, gpu_td))
+        return out
+
+    def d_step(self, idx_p, e_obs, e_acs, eps_ob, eps_ac, real):
         NO, hp = self.NO, self.hps
         ob = self.da.in_dim
         p = self.rows(idx_p)
@@ -75,6 +84,11 @@ class OracleLearner(object):
         dl, g = NO.disc_loss_grad(self.pd, self.dc, p['obs0'], p['acs'], e_obs, e_acs, eps_ob, eps_ac,
                                   real, np.zeros(len(real)), mean, std)
         self.pd = self.adam('d', self.pd, g, hp.d_lr)
+        return dl
+
+    def a_step(self, idx_a=None, u=None, gpu_td=None):
+        NO, hp = self.NO, self.hps
+        ob = self.da.in_dim
         iws = None
         if self.per:
             idx_a = self.rb.sample_idxs(len(u), u)
@@ -122,7 +136,7 @@ class OracleLearner(object):
             self.rb.update_priorities(idx_a, pr.astype(np.float64))
         self.pa_t = NO.polyak(self.pa_t, self.pa, hp.polyak)
         self.pc_t = NO.polyak(self.pc_t, self.pc, hp.polyak)
-        return dict(d_losses=dl, actor_losses=al, critic_losses=cl, idx_a=idx_a)
+        return dict(actor_losses=al, critic_losses=cl, idx_a=idx_a)
 
 
 @pytest.mark.parametrize('graph', [False, True])
@@ -315,6 +329,103 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
         assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize('cfg_name,d_steps,g_steps', [('C1', 1, 3), ('C3', 1, 3), ('C1', 2, 1), ('ragged', 1, 2)])
+def test_training_step_schedule_matches_oracle(cfg_name, d_steps, g_steps):
+    """d_steps discriminator updates and g_steps agent updates per training step (sam.py:323-433; the
+    launcher runs 1 and 3): rows with role subsets, each row checked against the oracle, weights after
+    two training steps, and the host RNG consumed exactly as the reference's loop consumes it."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    if cfg_name == 'ragged':  # layer-wise path
+        cfg = dict(ob=5, ac=2, h=(33, 70), B=37, per=False, mem=2048, name='ragged')
+    else:
+        cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+    mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, True)
+    drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=d_steps, g_steps=g_steps)
+    both = min(d_steps, g_steps)
+    assert drv.sched == [1] * (d_steps - both) + [3] * both + [2] * (g_steps - both)
+    ref = OracleLearner(mu, d, pool, cfg['per'])
+    np.random.seed(11); random.seed(11)
+    pool.pointer = 0
+    B, N = drv.B, mu.replay_buffer.num_entries
+    h = lambda t: t.cpu().numpy()
+    n_d = 0
+    for row in range(2 * drv.S):
+        role = drv.sched[row % drv.S]
+        counts = (int(mu.L.steps[0].item()), int(mu.L.steps[2].item()))
+        drv.step()
+        torch.cuda.synchronize()
+        assert (int(mu.L.steps[0].item()), int(mu.L.steps[2].item())) == \
+            (counts[0] + (1 if role & 2 else 0), counts[1] + (1 if role & 1 else 0))
+        kw = {}
+        if role & 1:
+            e0 = int(drv.e_start.item())
+            eps_ob, eps_ac, real, _ = drv.step_randoms(n_d)
+            n_d += 1
+            kw = dict(idx_p=h(drv.idx_p), e_obs=h(pool.obs0[e0:e0 + B]), e_acs=h(pool.acs[e0:e0 + B]),
+                      eps_ob=h(eps_ob), eps_ac=h(eps_ac), real=h(real))
+        else:
+            kw = dict(idx_p=None, e_obs=None, e_acs=None, eps_ob=None, eps_ac=None, real=None)
+        out = ref.step(idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post), role=role, **kw)
+        o = drv.outputs()
+        for name in out:
+            if name == 'idx_a':
+                continue
+            got, exp = h(o[name]).astype(np.float64), out[name]
+            assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-5, (name, row, got, exp)
+    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
+    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
+    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
+    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
+    if cfg['per']:
+        assert np.array_equal(mu.replay_buffer.tree_values('sum'), ref.rb.sum_tree.v)
+    # the generators stand where the reference's loop leaves them: per training step d_steps draws of B
+    # replay indices (D), then g_steps draws of B (agent; `random` for PER)
+    after_np, after_py = np.random.randint(0, 1 << 30, 4), random.random()
+    np.random.seed(11); random.seed(11)
+    for _ in range(2):
+        for _ in range(d_steps):
+            np.random.randint(low=0, high=N, size=B)
+        for _ in range(g_steps):
+            if cfg['per']:
+                [random.random() for _ in range(B)]
+            else:
+                np.random.randint(low=0, high=N, size=B)
+    assert np.array_equal(after_np, np.random.randint(0, 1 << 30, 4)) and after_py == random.random()
+
+
+def test_schedule_packed_launch_equals_single_rows():
+    """(1, 3) schedule on the fused path: whole training steps packed into graph launches leave the
+    learner bit-identical to row-by-row launches, across an expert-pool reshuffle."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    cfg = dict(bench.CONFIGS['C1'], mem=4096)
+    states = []
+    for mode in ('single', 'packed'):
+        mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=8, d_steps=1, g_steps=3)
+        assert drv.S == 3 and drv.K == 6
+        drv.prepare_all()
+        np.random.seed(80); random.seed(80)
+        pool.pointer = pool.num_entries - 4 * drv.B   # the pool wraps at the fourth D row
+        n = 27
+        if mode == 'single':
+            for _ in range(n):
+                drv.step()
+        else:
+            drv.run(n)
+        torch.cuda.synchronize()
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
+                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std, pool.obs0]] +
+                      [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer])])
+    assert int(states[0][4][0].item()) == 27 and int(states[0][4][2].item()) == 9
+    for a, b in zip(*states):
+        assert torch.equal(a.cpu(), b.cpu())
+
+
 class _TwinComm(object):
     """A 2-rank communicator whose other rank is an identical twin of this process: SUM all-reduce
     doubles, broadcast is the identity.  Drives the N > 1 plans of the driver (graph segments around
@@ -387,7 +498,7 @@ def test_two_rank_packed_launch_equals_single_steps():
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
         assert drv.K == 4 and drv.world == 2
         drv.prepare(1); drv.prepare(4)
-        assert len(drv.plans[4]) == 2 + 2 * 4 + 1
+        assert len(drv.plans[(4, 0)]) == 2 + 2 * 4 + 1
         np.random.seed(78); random.seed(78)
         pool.pointer = 0
         if mode == 'single':
@@ -429,7 +540,7 @@ def test_in_graph_rccl_collectives_equal_host_issued():
             assert drv.collectives_in_graph and drv.K == 4
             assert drv.set_collectives(mode == 'graph') == (mode == 'graph')
             drv.prepare(1); drv.prepare(4)
-            assert len(drv.plans[4]) == (1 if mode == 'graph' else 2 + 2 * 4 + 1)
+            assert len(drv.plans[(4, 0)]) == (1 if mode == 'graph' else 2 + 2 * 4 + 1)
             np.random.seed(79); random.seed(79)
             pool.pointer = 0
             if mode == 'single':
