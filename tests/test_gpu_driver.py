@@ -485,9 +485,11 @@ def test_two_rank_plan_matches_oracle(cfg_name):
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
 
 
-def test_two_rank_packed_launch_equals_single_steps():
-    """N > 1, fused path: K steps per host iteration (one all-reduce of the K D-input sum vectors, then
-    one gradient all-reduce per step) leave the learner bit-identical to K single-step launches."""
+@pytest.mark.parametrize('g_steps', [1, 3])
+def test_two_rank_packed_launch_equals_single_steps(g_steps):
+    """N > 1, fused path: K rows per host iteration (one all-reduce of the K D-input sum vectors, then
+    one gradient all-reduce per row — of the segments the row's roles fill) leave the learner
+    bit-identical to single-row launches; also with the launcher's 1:3 schedule."""
     import random
     import bench
     from sam_tf_amd.driver import UpdateStepDriver
@@ -495,17 +497,20 @@ def test_two_rank_packed_launch_equals_single_steps():
     states = []
     for mode in ('single', 'packed'):
         mu, d, pool, _ = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 5, True)
-        drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
-        assert drv.K == 4 and drv.world == 2
-        drv.prepare(1); drv.prepare(4)
-        assert len(drv.plans[(4, 0)]) == 2 + 2 * 4 + 1
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4 if g_steps == 1 else 6,
+                               g_steps=g_steps)
+        assert drv.K == (4 if g_steps == 1 else 6) and drv.world == 2
+        drv.prepare_all()
+        if g_steps == 1:
+            assert len(drv.plans[(4, 0)]) == 2 + 2 * 4 + 1
         np.random.seed(78); random.seed(78)
         pool.pointer = 0
+        n = 9 if g_steps == 1 else 15
         if mode == 'single':
-            for _ in range(9):
+            for _ in range(n):
                 drv.step()
         else:
-            drv.run(9)   # 4 + 4 + 1
+            drv.run(n)   # 4 + 4 + 1  /  6 + 6 + 3
         torch.cuda.synchronize()
         states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
                                            d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
