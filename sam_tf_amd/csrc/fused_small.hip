@@ -340,7 +340,7 @@ __device__ __forceinline__ void rows_commit(float* XC, const RowRegs& x, bool no
 // ------------------------------------------------------------------------------------------------
 struct AgentLds {
     NetL nA, nC, nD;
-    float *XC, *XC0, *A1a, *A2a, *A1c, *A2c, *DZa, *DZb, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl;
+    float *XC, *XC0, *A1a, *A2a, *A1c, *A2c, *DZa, *DZb, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl, *son;
 };
 
 __device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d) {
@@ -359,7 +359,7 @@ __device__ inline AgentLds carve_agent_lds(float* p, int ob, int ac, bool use_d)
     L.DZb = p; p += R * LD;
     L.PRE = p; p += R * LD3;
     L.s_ = p; L.tq = p + 16; L.dq = p + 32; L.red = p + 48;
-    L.rw = p + 64; L.dn = p + 80; L.iw = p + 96; L.tl = p + 112;
+    L.rw = p + 64; L.dn = p + 80; L.iw = p + 96; L.tl = p + 112; L.son = p + 128;
     return L;
 }
 
@@ -424,51 +424,45 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds, int
     TRACE(trole, 1);
     stage_wait();
     TRACE(trole, 2);
+    // The online critic's forward (obs0, batch actions) does not depend on the target: it runs side by
+    // side with the target actor's forward, two 16x64 tiles per wave and barrier.
     layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
+    layer_fwd(L.XC0, L.nD.k4, L.nD.W1, L.nD.b1, L.A1c);
     __syncthreads();
     layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
+    layer_fwd(L.A1c, H, L.nD.W2, L.nD.b2, L.A2c);
     __syncthreads();
     actor_head(L, ob, ac, a.high);
+    head_dot(L.A2c, L.nD, L.son);            // Q(obz0, acs), online critic
     __syncthreads();
     TRACE(trole, 3);
-    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
-    __syncthreads();
-    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
-    __syncthreads();
-    head_dot(L.A2c, L.nC, L.s_);
-    __syncthreads();
-    TRACE(trole, 4);
-    if (tid < R) {
-        const int64_t g = row0 + tid;
-        const float gam = a.td_len ? powf(a.gamma, L.tl[tid]) : a.gamma;
-        const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * L.s_[tid]);
-        L.tq[tid] = t;
-        a.targ_q_out[g] = t;
-    }
-    // ---- critic loss + gradient (sam_agent.py:457-520)
-    L.nC = L.nD;    // switch to the online critic staged at kernel start
-    L.XC = L.XC0;   // ... and to the [obz0 | acs] rows fetched at kernel start
-    __syncthreads();
+    // target critic on [obz1 | mu'(obz1)]; its activations reuse the target actor's tiles
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1a);
     if (wg == 0) {
         // sum of squares of the decayed critic kernels for the weight-decay loss term
         // (network_util.py:43-56); padded LDS rows are zero
         double acc = 0.0;
-        for (int t = tid; t < L.nC.k4 * H; t += NT) { const float w = L.nC.W1[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
-        for (int t = tid; t < H * H; t += NT) { const float w = L.nC.W2[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int t = tid; t < L.nD.k4 * H; t += NT) { const float w = L.nD.W1[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int t = tid; t < H * H; t += NT) { const float w = L.nD.W2[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) L.red[wv] = (float)acc;
     }
-    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
     __syncthreads();
     if (wg == 0 && tid == 0) a.loss_part[3] = L.red[0] + L.red[1] + L.red[2] + L.red[3];
-    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    layer_fwd(L.A1a, H, L.nC.W2, L.nC.b2, L.A2a);
     __syncthreads();
-    head_dot(L.A2c, L.nC, L.s_);
+    head_dot(L.A2a, L.nC, L.s_);
     __syncthreads();
-    TRACE(trole, 5);
+    TRACE(trole, 4);
+    // ---- TD target, critic loss + gradient (sam_agent.py:196-205,457-520)
+    L.nC = L.nD;    // from here on: the online critic ...
+    L.XC = L.XC0;   // ... and the [obz0 | acs] rows
     if (tid < R) {
         const int64_t g = row0 + tid;
-        const float td = L.s_[tid] - L.tq[tid];
+        const float gam = a.td_len ? powf(a.gamma, L.tl[tid]) : a.gamma;
+        const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * L.s_[tid]);
+        a.targ_q_out[g] = t;
+        const float td = L.son[tid] - t;
         const float iw = L.iw[tid];
         const float ad = fabsf(td);
         const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;         // math_util.py:22-29
@@ -478,6 +472,7 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds, int
         if (a.td_out) a.td_out[g] = td;
     }
     __syncthreads();
+    TRACE(trole, 5);
     if (tid == 0) {
         float s = 0.f;
         for (int r = 0; r < R; ++r) s += L.red[r];
@@ -1135,7 +1130,7 @@ __global__ __launch_bounds__(256) void seg_sumsq_kernel(ApplyArgs f) {
 size_t agent_lds_bytes(int ob, int ac, bool use_d) {
     (void)use_d;  // the target+critic role always keeps three networks resident
     size_t f = net_lds_floats(ob, ac) + 2 * net_lds_floats(ob + ac, 1);
-    f += 8 * R * LD + R * LD3 + 128;
+    f += 8 * R * LD + R * LD3 + 144;
     return f * sizeof(float);
 }
 size_t disc_lds_bytes(int in) {
