@@ -185,16 +185,22 @@ class UpdateStepDriver(object):
         return ((0 if role & self.D else 4) | (0 if role & self.A else 8),
                 (0 if role & self.D else 8) | (0 if role & self.A else 16))
 
-    def _seg_grads(self, k=0, role=3):
-        mu, d = self.mu, self.d
-        part, mode = self._masks(role)
-        if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats and role & self.D:
-            ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
-        if self.per and role & self.A:  # the pending priority update, then memory.py:248-309 on the device trees
+    def _seg_trees(self, role=3):
+        """PER: the pending priority update, then memory.py:248-309 on the device trees."""
+        mu = self.mu
+        if self.per and role & self.A:
             mu.replay_buffer.trees.set(self.prev_idx, self.prev_leaf)
             mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
+
+    def _seg_grads(self, k=0, role=3, trees_done=False):
+        mu, d = self.mu, self.d
+        part, mode = self._masks(role)
+        if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats and role & self.D:
+            ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
+        if not trees_done:
+            self._seg_trees(role)
         ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part)
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
         ops.step_apply(self.L, self.B, (3 if self.world == 1 else 1) | mode, 1.0)
@@ -246,6 +252,8 @@ class UpdateStepDriver(object):
         roles = [self.sched[(phase + k) % self.S] for k in range(K)]
         any_d = any(r & self.D for r in roles)
         if self.world == 1:
+            # (forking the D-input sums beside the PER tree work as a second graph branch was measured:
+            # 8.1 k -> 7.1 k steps/s at C3 — a two-branch hipGraph costs more to launch than it overlaps)
             return [self._capture(lambda: [self._seg_sums(K) if any_d else None] +
                                   [(self._seg_inputs(k, roles[k]), self._seg_grads(k, roles[k]))
                                    for k in range(K)])]

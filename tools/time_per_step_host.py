@@ -15,9 +15,9 @@ N = 1000
 for _ in range(N):
     t = time.perf_counter()
     slot = drv.slots[drv.launch_no % len(drv.slots)]
-    drv._draw(slot, 1); t = tick('draw(+pending)', t)
+    drv._draw(slot, 1, 0); t = tick('draw(+pending)', t)
     drv._upload(slot, 1); t = tick('upload H2D', t)
-    for run in drv.plans[1]:
+    for run in drv.plans[(1, 0)]:
         run()
     t = tick('graph launch', t)
     drv._td_host.copy_(drv.td_post, non_blocking=True)
@@ -25,7 +25,7 @@ for _ in range(N):
     nxt = drv.slots[(drv.launch_no + 1) % len(drv.slots)]
     if nxt.used:
         nxt.event.synchronize()
-    drv._draw_rng(nxt, 1); nxt.predrawn = True; t = tick('predraw next', t)
+    drv._draw_rng(nxt, 1, 0); nxt.predrawn = True; t = tick('predraw next', t)
     torch.cuda.current_stream().synchronize(); t = tick('wait GPU', t)
     pr = np.abs(drv._td_host.numpy()) + np.float32(1e-6)
     idxs, leaf = mu.replay_buffer.leaves_for(drv._idx_host.numpy(), pr)
