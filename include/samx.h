@@ -86,6 +86,14 @@ int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host
                               double alpha, int64_t num_demos, double demos_eps,
                               double* leaf_out_host, double* max_priority_host);
 
+/* The PER refresh of SAMAgent.train() in one host call (sam_agent.py:693-703 -> memory.py:344-379):
+ * priority = |td| + 1e-6 in float32 (as numpy computes it), the reference's asserts (positive priority,
+ * index < num_entries), demos_eps, max_priority tracking and leaf = priority ** alpha with the host libm
+ * pow.  Host pointers; the leaves then go to samx_tree_set. */
+int samx_per_leaves_from_td_host(const float* td_host, const int64_t* idxs_host, int64_t n,
+                                 int64_t num_entries, double alpha, int64_t num_demos, double demos_eps,
+                                 double* leaf_out_host, double* max_priority_host);
+
 /* ---- replay storage ------------------------------------------------------------------------ */
 /* RingBuffer.get_batch for the five atoms at once (memory.py:33-34,74-84): row = (start+idx)%maxlen.
  * Any output may be NULL. */

@@ -197,12 +197,12 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
     const int64_t e0 = e_start ? e_start[0] : 0;
     double a = 0.0, q = 0.0;
     if (col < dim) {
-        // rows in batches of 8: all index loads, then all data loads, then the adds in row order
-        for (int64_t rb = lane; rb < 2 * B; rb += (int64_t)lanes * 8) {
-            const float* src[8];
-            float v[8];
+        // rows in batches of 16 (C3: every row lane's 16 rows in ONE round of index loads + one of data loads): all index loads, then all data loads, then the adds in row order
+        for (int64_t rb = lane; rb < 2 * B; rb += (int64_t)lanes * 16) {
+            const float* src[16];
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int64_t r = rb + (int64_t)u * lanes;
                 src[u] = nullptr;
                 if (r < B) {
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[u] ? *src[u] : 0.f;
+            for (int u = 0; u < 16; ++u) v[u] = src[u] ? *src[u] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (src[u]) {
                     const double x = (double)v[u];
                     a = __dadd_rn(a, x);

@@ -409,4 +409,27 @@ int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host
     return SAMX_OK;
 }
 
+int samx_per_leaves_from_td_host(const float* td_host, const int64_t* idxs_host, int64_t n,
+                                 int64_t num_entries, double alpha, int64_t num_demos, double demos_eps,
+                                 double* leaf_out_host, double* max_priority_host) {
+    SAMX_REQUIRE(td_host && idxs_host && leaf_out_host && max_priority_host,
+                 "samx_per_leaves_from_td_host: null pointer");
+    double mp = *max_priority_host;
+    for (int64_t i = 0; i < n; ++i) {
+        // new priority = |td| + 1e-6 in FLOAT32 (numpy: float32 array + python float stays float32,
+        // sam_agent.py:702), then float64 for the tree (memory.py:344-379)
+        const float p32 = fabsf(td_host[i]) + 1e-6f;
+        double p = (double)p32;
+        SAMX_REQUIRE(p > 0, "samx_per_leaves_from_td_host: priority %lld is not positive", (long long)i);
+        SAMX_REQUIRE(idxs_host[i] >= 0 && idxs_host[i] < num_entries,
+                     "samx_per_leaves_from_td_host: no element in buffer associated w/ index %lld",
+                     (long long)idxs_host[i]);   // memory.py:372
+        if (num_demos > 0 && idxs_host[i] < num_demos) p += demos_eps;
+        leaf_out_host[i] = pow(p, alpha);
+        if (p > mp) mp = p;
+    }
+    *max_priority_host = mp;
+    return SAMX_OK;
+}
+
 }  // extern "C"

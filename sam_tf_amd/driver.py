@@ -129,6 +129,12 @@ class UpdateStepDriver(object):
         self.gb = {k: torch.zeros(B, st[k].shape[1], **f32) for k in ('obs0', 'acs')}  # PER refresh rows
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
+        self._leaf_np = np.empty(B, dtype=np.float64)
+        # PER, one process: the row's H2D upload and the D2H of the refreshed TD errors are nodes of the
+        # captured graph (fixed pinned buffers; the host waits for every row anyway), which leaves ONE
+        # host call — the graph launch — between two rows' host arithmetic
+        self.per_graph_io = bool(self.per and self.use_graph and self.world == 1)
+        self._launch_words = torch.zeros(1, self.W, dtype=torch.int64).pin_memory()
         self.slots = [_Slot(B, self.K) for _ in range(n_slots)]
         self.step_no = 0     # rows done
         self.launch_no = 0
@@ -254,9 +260,18 @@ class UpdateStepDriver(object):
         if self.world == 1:
             # (forking the D-input sums beside the PER tree work as a second graph branch was measured:
             # 8.1 k -> 7.1 k steps/s at C3 — a two-branch hipGraph costs more to launch than it overlaps)
-            return [self._capture(lambda: [self._seg_sums(K) if any_d else None] +
-                                  [(self._seg_inputs(k, roles[k]), self._seg_grads(k, roles[k]))
-                                   for k in range(K)])]
+            def run():
+                if self.per_graph_io:
+                    self.words[:1].copy_(self._launch_words, non_blocking=True)
+                if any_d:
+                    self._seg_sums(K)
+                for k in range(K):
+                    self._seg_inputs(k, roles[k])
+                    self._seg_grads(k, roles[k])
+                if self.per_graph_io and roles[0] & self.A:
+                    self._td_host.copy_(self.td_post, non_blocking=True)
+                    self._idx_host.copy_(self.idx_a, non_blocking=True)
+            return [self._capture(run)]
         if self.collectives_in_graph:
             def run():
                 if self.inline_stats and any_d:
@@ -420,6 +435,7 @@ class UpdateStepDriver(object):
             self.flush()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
+        self._launch_words.copy_(slot.words[:1])
         torch.cuda.synchronize()
         self.plans[(K, phase)] = self._build_plan(K, phase)
         torch.cuda.synchronize()
@@ -452,14 +468,15 @@ class UpdateStepDriver(object):
             "replay ring moved: call driver.refresh() after appending transitions"
         slot = self.slots[self.launch_no % len(self.slots)]
         self._draw(slot, K, phase)
-        self._upload(slot, K)
+        if self.per_graph_io:
+            self._launch_words.copy_(slot.words[:1])   # host memcpy pinned -> pinned; the graph uploads it
+        else:
+            self._upload(slot, K)
         for run in self.plans[(K, phase)]:
             run()
         if self.per:
             refresh = bool(role & self.A)
-            if refresh:
-                # |td| + 1e-6 in float32 (numpy: float32 array + python float stays float32,
-                # sam_agent.py:702), leaves = libm pow on the host, trees updated on the device
+            if refresh and not self.per_graph_io:
                 self._td_host.copy_(self.td_post, non_blocking=True)
                 self._idx_host.copy_(self.idx_a, non_blocking=True)
             if more:  # the next row's host RNG draws do not depend on this row: make them now,
@@ -471,9 +488,11 @@ class UpdateStepDriver(object):
                 nxt.predrawn = True
             if refresh:
                 torch.cuda.current_stream().synchronize()
-                new_priorities = np.abs(self._td_host.numpy()) + np.float32(1e-6)
-                idxs, leaf = self.mu.replay_buffer.leaves_for(self._idx_host.numpy(), new_priorities)
-                self._pending = (idxs.copy(), leaf)   # applied by the first kernel of the next agent row
+                # |td| + 1e-6 in float32 (sam_agent.py:702), the reference's asserts, leaves = libm pow on
+                # the host (one C call); the trees are updated on the device by the next agent row
+                idxs = self._idx_host.numpy().copy()
+                leaf = self.mu.replay_buffer.leaves_from_td(idxs, self._td_host.numpy(), self._leaf_np).copy()
+                self._pending = (idxs, leaf)
         self.step_no += K
         self.launch_no += 1
 

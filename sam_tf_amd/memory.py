@@ -246,6 +246,13 @@ class PrioritizedRB(RB):
             "no element in buffer associated w/ index"
         return idxs, self._leafs(idxs, priorities)
 
+    def leaves_from_td(self, idxs, td, out):
+        """leaves_for for the driver's refresh: priorities = |td| + 1e-6 (float32, sam_agent.py:702) ->
+        asserts -> libm pow, one host call on staging arrays; `out` float64[n] receives the leaves."""
+        self.max_priority = ops.per_leaves_from_td_host(td, idxs, self.num_entries, self.alpha, self.num_demos,
+                                                        self.demos_eps, self.max_priority, out)
+        return out
+
     def update_priorities(self, idxs, priorities):
         """memory.py:344-379 (non-ranked).  Host: asserts + libm pow; device: both trees."""
         idxs, leaf = self.leaves_for(idxs, priorities)

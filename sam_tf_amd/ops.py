@@ -105,6 +105,16 @@ def per_leaf_values_host(idxs, prios, alpha, num_demos, demos_eps, max_priority)
     return leaf, mp.value
 
 
+def per_leaves_from_td_host(td, idxs, num_entries, alpha, num_demos, demos_eps, max_priority, out):
+    """td float32[n], idxs int64[n], out float64[n]: host numpy arrays (pinned staging is fine).  Returns
+    the new max_priority; `out` receives the leaves (samx_per_leaves_from_td_host)."""
+    mp = C.c_double(float(max_priority))
+    check(_L().samx_per_leaves_from_td_host(td.ctypes.data, idxs.ctypes.data, td.size, int(num_entries),
+                                            float(alpha), int(num_demos), float(demos_eps), out.ctypes.data,
+                                            C.byref(mp)))
+    return mp.value
+
+
 # ------------------------------------------------------------------ replay rows
 
 def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None):
