@@ -380,6 +380,20 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
 /* Scratch for samx_d_input_stats (large inputs are summed by many workgroups into per-group float64
  * partials that are then added in a fixed order); ws may be NULL when 2*B*ob_dim <= 16384. */
 size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
+/* Head of a prioritized-replay row in ONE launch: workgroup 0 applies the pending priority update to both
+ * trees (= samx_tree_set with n_upd < 1024: memory.py:373-379 of the PREVIOUS agent update), workgroup 1
+ * computes the D-input sums of this row (= samx_d_input_stats with commit = 0: sam.py:389-390).  The two
+ * do not depend on each other. */
+int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                          const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
+                          const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
+                          const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
+                          void* stream);
+
+/* a[n] (float) and b[n] (int64) to PINNED HOST memory (device-accessible) in one launch: the refreshed TD
+ * errors and the sampled indices a prioritized-replay row hands back to the host (sam_agent.py:693-703). */
+int samx_to_host_pair(const float* a, float* a_host, const int64_t* b, int64_t* b_host, int64_t n, void* stream);
+
 /* The batch sums (no commit) of K consecutive steps in ONE launch: step k reads its index words at
  * p_idx + k*idx_stride and e_start + k*idx_stride (int64 words) and writes addvec + k*addvec_stride
  * (doubles).  The sums of a batch do not depend on the learner, so a multi-step launch computes them

@@ -4,6 +4,7 @@
 //   reference sequence: sam.py:369-433 (D update, then mu.train(), then update_target_net())
 #include "samx_common.h"
 #include "fused_small.h"
+#include "tree_dev.h"
 #include "rng.h"
 #include <stdlib.h>
 #include "../../include/samx.h"
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(256) void expert_slice_kernel(const float* __restri
 // float64 column sums of the discriminator's 2B input rows read in place, one workgroup.
 // threads = rowlanes x dimpad; every row lane adds its rows in increasing order, lanes are then
 // combined by a fixed binary tree (deterministic).
-__global__ __launch_bounds__(1024) void d_input_stats_kernel(
+__device__ __forceinline__ void d_input_stats_body(int blk,
+   
     const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
     const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
     extern __shared__ double shd[];  // [2][1024]
     const int tid = threadIdx.x;
     // one workgroup per step of a multi-step launch (blockIdx.x = step; a single step has stride 0)
-    if (p_idx) p_idx += blockIdx.x * idx_stride;
-    if (e_start) e_start += blockIdx.x * idx_stride;
-    addvec += blockIdx.x * addvec_stride;
+    if (p_idx) p_idx += blk * idx_stride;
+    if (e_start) e_start += blk * idx_stride;
+    addvec += blk * addvec_stride;
     const int col = tid % dimpad, lane = tid / dimpad, lanes = 1024 / dimpad;
     const int64_t e0 = e_start ? e_start[0] : 0;
     double a = 0.0, q = 0.0;
@@ -253,6 +255,40 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
         addvec[2 * dim] = (double)(2 * B);
         if (commit) sums[2 * dim] = sums[2 * dim] + (double)(2 * B);
     }
+}
+
+__global__ __launch_bounds__(1024) void d_input_stats_kernel(
+    const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
+    const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
+    const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
+    int commit, double* __restrict__ sums, float* __restrict__ mean_out, float* __restrict__ std_out,
+    int64_t idx_stride, int64_t addvec_stride) {
+    d_input_stats_body(blockIdx.x, replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, dim, dimpad,
+                       addvec, commit, sums, mean_out, std_out, idx_stride, addvec_stride);
+}
+
+// PER row prologue: the pending priority update of the trees (workgroup 0) and the D-input sums of the
+// row (workgroup 1) do not depend on each other — one launch instead of two dependent ones.
+__global__ __launch_bounds__(1024) void per_row_prologue_kernel(
+    double* __restrict__ ts, double* __restrict__ tm, int32_t* __restrict__ stamp, int64_t cap,
+    const int64_t* __restrict__ upd_idx, const double* __restrict__ upd_leaf, int n_upd, int levels,
+    const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
+    const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
+    const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec) {
+    if (blockIdx.x == 0) {
+        samx::tree_set_body(ts, tm, stamp, cap, upd_idx, upd_leaf, n_upd, levels);
+    } else {
+        d_input_stats_body(0, replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, dim, dimpad, addvec,
+                           0, nullptr, nullptr, nullptr, 0, 0);
+    }
+}
+
+// two device arrays -> pinned host memory in one launch (the TD errors and sampled indices a PER row
+// hands back; a graph memcpy node costs 4-5 us each)
+__global__ void to_host_pair_kernel(const float* __restrict__ a, float* __restrict__ a_host,
+                                    const int64_t* __restrict__ b, int64_t* __restrict__ b_host, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) { a_host[i] = a[i]; b_host[i] = b[i]; }
 }
 
 // Large inputs (Humanoid-shaped: 2B x 376): the same sums in two launches.  Stage 1: workgroup g adds
@@ -397,6 +433,39 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
     d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), st>>>(
         replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
         mean_out, std_out, 0, 0);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                          const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
+                          const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
+                          const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
+                          void* stream) {
+    SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && upd_leaf, "samx_per_row_prologue: null tree argument");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_row_prologue: cap %lld is not a power of two",
+                 (long long)cap);
+    SAMX_REQUIRE(n_upd > 0 && n_upd < 1024, "samx_per_row_prologue: 1..1023 priority updates (got %lld)",
+                 (long long)n_upd);
+    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "samx_per_row_prologue: bad arguments");
+    SAMX_REQUIRE(2 * B * (int64_t)ob_dim <= 16384, "samx_per_row_prologue: batch too large (2*B*ob = %lld)",
+                 (long long)(2 * B * ob_dim));
+    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
+                 "samx_per_row_prologue: bad ring geometry");
+    int levels = 0;
+    while ((int64_t(1) << levels) < cap) ++levels;
+    int dimpad = 1;
+    while (dimpad < ob_dim) dimpad *= 2;
+    per_row_prologue_kernel<<<2, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
+        sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, (int)n_upd, levels, replay_obs0, ring_start, ring_len,
+        p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_to_host_pair(const float* a, float* a_host, const int64_t* b, int64_t* b_host, int64_t n, void* stream) {
+    SAMX_REQUIRE(a && a_host && b && b_host && n > 0, "samx_to_host_pair: bad arguments");
+    to_host_pair_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, a_host, b, b_host, n);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -2,12 +2,13 @@
 //   helpers/segment_tree.py:26-97 ; imitation_algorithms/memory.py:248-309,337-379
 // HBM/latency-bound pointer chasing over a 2*cap double array (16 MiB at cap 2^20); no MFMA here.
 #include "samx_common.h"
+#include "tree_dev.h"
 #include "../../include/samx.h"
 #include <math.h>
 
 namespace {
 
-constexpr int kTreeThreads = 1024;
+using samx::kTreeThreads;
 constexpr int kMaxLevels = 48;
 
 __device__ __forceinline__ double tree_op(int kind, double a, double b) {
@@ -25,10 +26,6 @@ __global__ void tree_init_kernel(double* s, double* m, int32_t* stamp, int64_t c
     if (i < cap) stamp[i] = -1;
 }
 
-// One workgroup. Phase 1 elects, per distinct leaf, the LAST position in the batch (the reference
-// loop is sequential, so the last write survives); phase 2 writes the elected leaves; then every
-// level is recomputed bottom-up as value[2i] + value[2i+1] (or min), one barrier per level.
-// Threads that share an ancestor compute and store the same value, which is harmless.
 __global__ __launch_bounds__(kTreeThreads) void tree_set_kernel(double* __restrict__ s,
                                                                 double* __restrict__ m,
                                                                 int32_t* __restrict__ stamp,
@@ -36,39 +33,7 @@ __global__ __launch_bounds__(kTreeThreads) void tree_set_kernel(double* __restri
                                                                 const int64_t* __restrict__ idxs,
                                                                 const double* __restrict__ leaf,
                                                                 int n, int levels) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += kTreeThreads) {
-        int64_t idx = idxs[i];
-        if (idx >= 0 && idx < cap) atomicMax(&stamp[idx], i);
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += kTreeThreads) {
-        int64_t idx = idxs[i];
-        if (idx >= 0 && idx < cap) {
-            int32_t w = __hip_atomic_load(&stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (w == i) {
-                double v = leaf[i];
-                s[cap + idx] = v;
-                m[cap + idx] = v;
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += kTreeThreads) {
-        int64_t idx = idxs[i];
-        if (idx >= 0 && idx < cap) stamp[idx] = -1;
-    }
-    for (int l = 1; l <= levels; ++l) {
-        __syncthreads();
-        for (int i = tid; i < n; i += kTreeThreads) {
-            int64_t idx = idxs[i];
-            if (idx < 0 || idx >= cap) continue;
-            int64_t node = (cap + idx) >> l;
-            s[node] = __dadd_rn(s[2 * node], s[2 * node + 1]);
-            double a = m[2 * node], b = m[2 * node + 1];
-            m[node] = (b < a) ? b : a;
-        }
-    }
+    samx::tree_set_body(s, m, stamp, cap, idxs, leaf, n, levels);   // tree_dev.h
 }
 
 // Large batches (C5: 8192 updates into a 2^22 tree): one workgroup is bound by the number of random

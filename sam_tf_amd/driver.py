@@ -263,14 +263,23 @@ class UpdateStepDriver(object):
             def run():
                 if self.per_graph_io:
                     self.words[:1].copy_(self._launch_words, non_blocking=True)
-                if any_d:
-                    self._seg_sums(K)
-                for k in range(K):
-                    self._seg_inputs(k, roles[k])
-                    self._seg_grads(k, roles[k])
-                if self.per_graph_io and roles[0] & self.A:
-                    self._td_host.copy_(self.td_post, non_blocking=True)
-                    self._idx_host.copy_(self.idx_a, non_blocking=True)
+                rb = self.mu.replay_buffer
+                if (self.per_graph_io and K == 1 and roles[0] == self.D | self.A and self.inline_stats
+                        and self.B < 1024):
+                    # pending priority update and this row's D-input sums: one launch, two workgroups
+                    ops.per_row_prologue(rb.trees, self.prev_idx, self.prev_leaf, rb.store['obs0'],
+                                         self._batch_start, self.words[0], self.B, self.pool.obs0, self.addvecs[0])
+                    rb.trees.per_sample(rb.num_entries, self.u, self.mu.hps.beta, idxs_out=self.idx_a,
+                                        iws_out=self.iws, iws32_out=self.iws32)
+                    self._seg_grads(0, roles[0], trees_done=True)
+                else:
+                    if any_d:
+                        self._seg_sums(K)
+                    for k in range(K):
+                        self._seg_inputs(k, roles[k])
+                        self._seg_grads(k, roles[k])
+                if self.per_graph_io and roles[0] & self.A:   # TD errors + sampled indices -> pinned host
+                    ops.to_host_pair(self.td_post, self._td_host, self.idx_a, self._idx_host)
             return [self._capture(run)]
         if self.collectives_in_graph:
             def run():

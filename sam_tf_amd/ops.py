@@ -560,6 +560,28 @@ def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
                                       ptr(addvecs), 2 * ob + 1, K, stream_ptr()))
 
 
+def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec):
+    """Pending priority update (trees.set) + the row's D-input sums in one launch (samx_per_row_prologue).
+    words_row: int64 [W] with idx_p at [:B] and e_start at [2B]; addvec: float64 [2*ob+1]."""
+    ring_len, ob = replay_obs0.shape
+    n = upd_idx.numel()
+    _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_leaf, F64, (n,), 'upd_leaf')
+    _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+    check(_L().samx_per_row_prologue(ptr(trees.sum), ptr(trees.min), ptr(trees.stamp), trees.cap, ptr(upd_idx),
+                                     ptr(upd_leaf), n, ptr(replay_obs0), int(ring_start), int(ring_len),
+                                     C.c_void_p(words_row.data_ptr()), ptr(pool_obs0),
+                                     C.c_void_p(words_row.data_ptr() + 8 * 2 * B), int(B), int(ob), ptr(addvec),
+                                     stream_ptr()))
+
+
+def to_host_pair(a, a_host, b, b_host):
+    """a (float32, device) -> a_host, b (int64, device) -> b_host; the *_host tensors are pinned."""
+    n = a.numel()
+    assert a_host.is_pinned() and b_host.is_pinned() and b.numel() == n
+    check(_L().samx_to_host_pair(ptr(a), C.c_void_p(a_host.data_ptr()), ptr(b), C.c_void_p(b_host.data_ptr()), n,
+                                 stream_ptr()))
+
+
 def make_step_out(B, device='cuda'):
     o = _lib.StepOut()
     o.t = dict(d_losses=torch.zeros(8, dtype=F32, device=device),
