@@ -370,6 +370,11 @@ class UpdateStepDriver(object):
         assert phase == 0 and K % self.S == 0 and not self.per
         T, d, g = K // self.S, self.d_steps, self.g_steps
         draws = np.random.randint(low=0, high=N, size=(T, d + g, B))
+        if self.S == 1:   # one D + agent row per training step: the draws ARE the rows' index words
+            slot.np_idx[:K] = draws
+            for k in range(K):
+                self._expert_rows(slot, k)
+            return
         k = 0
         for t in range(T):
             nd = na = 0
