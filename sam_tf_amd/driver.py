@@ -148,6 +148,7 @@ class UpdateStepDriver(object):
         rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
         B = self.B
         self._batch_start = rb.start
+        self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
         self.inline_stats = bool(self.fused and self.d.hps.rmsify_obs)
@@ -477,9 +478,12 @@ class UpdateStepDriver(object):
     def _launch(self, K, more=False):
         phase = self.step_no % self.S
         role = self.sched[phase]
+        rb = self.mu.replay_buffer
+        if rb.start != self._batch_start or rb.num_entries != self._batch_entries:
+            # transitions were appended since the plans were captured (the ring start and the entry
+            # count are baked into them): re-read the geometry and capture again
+            self.refresh()
         self.prepare(K, phase)
-        assert self.mu.replay_buffer.start == self._batch_start, \
-            "replay ring moved: call driver.refresh() after appending transitions"
         slot = self.slots[self.launch_no % len(self.slots)]
         self._draw(slot, K, phase)
         if self.per_graph_io:
@@ -543,9 +547,9 @@ class UpdateStepDriver(object):
 
     def refresh(self):
         """Re-read the replay ring geometry (after rollouts appended transitions) and re-capture."""
+        self.flush()
         self.plans = {}
         self._make_batch()
-        self.prepare(1, self.step_no % self.S)
 
     def outputs(self):
         """What the reference's loop logs per step (sam.py:398-431), still in HBM."""

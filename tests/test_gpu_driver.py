@@ -426,6 +426,41 @@ def test_schedule_packed_launch_equals_single_rows():
         assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3'])
+def test_appending_transitions_between_runs(cfg_name):
+    """Rollouts append transitions between training phases (sam.py:305-321): the driver notices that the
+    ring geometry / entry count changed and re-captures.  Same learner state as a driver built AFTER the
+    append (bit for bit, PER trees included)."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
+    states = []
+    for mode in ('same-driver', 'fresh-driver'):
+        mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
+        rb = mu.replay_buffer
+        assert rb.num_entries == 4096   # the ring is full: every append moves its start
+        rs = np.random.RandomState(3)
+        np.random.seed(81); random.seed(81)
+        pool.pointer = 0
+        drv.run(5)
+        for phase in range(2):
+            for t in range(40):
+                mu.store_transition(rs.randn(mu.ob_dim).astype(np.float32),
+                                    rs.uniform(-1, 1, mu.ac_dim).astype(np.float32), float(rs.rand()),
+                                    rs.randn(mu.ob_dim).astype(np.float32), float(t % 13 == 12))
+            if mode == 'fresh-driver':
+                drv = UpdateStepDriver(mu, d, pool, use_graph=True)
+                drv.step_no = 5 * (phase + 1)
+            drv.run(5)
+        torch.cuda.synchronize()
+        extra = [rb.trees.sum, rb.trees.min] if cfg['per'] else []
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
+                                           d.obs_rms.sums] + extra])
+    for a, b in zip(*states):
+        assert torch.equal(a.cpu(), b.cpu())
+
+
 class _TwinComm(object):
     """A 2-rank communicator whose other rank is an identical twin of this process: SUM all-reduce
     doubles, broadcast is the identity.  Drives the N > 1 plans of the driver (graph segments around
