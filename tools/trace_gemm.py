@@ -12,6 +12,7 @@ from sam_tf_amd import ops, _lib  # noqa: E402
 
 M, N, R = (int(x) for x in sys.argv[1:4])
 layout = sys.argv[4] if len(sys.argv) > 4 else 'NN'
+nsplit = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 dev = 'cuda'
 g = torch.Generator(device=dev); g.manual_seed(0)
 if layout == 'NN':
@@ -24,7 +25,7 @@ elif layout == 'NT':
     ref = lambda: A @ B.t()
 else:
     A = torch.randn(R, M, generator=g, device=dev); B = torch.randn(R, N, generator=g, device=dev)
-    call = lambda: ops.gemm_f32(A, (1, M), B, (N, 1), M, N, R)
+    call = lambda: ops.gemm_f32(A, (1, M), B, (N, 1), M, N, R, nsplit=nsplit)
     ref = lambda: A.t() @ B
 out = call()
 err = (out - ref()).abs().max().item() / ref().abs().max().item()
@@ -37,7 +38,7 @@ for _ in range(20):
     call()
 e1.record(); e1.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-print('%s %dx%dx%d: %.1f us, %.1f TFLOP/s, max rel err %.2e' % (layout, M, N, R, us, 2.0 * M * N * R / us / 1e6, err))
+print('%s nsplit %d %dx%dx%d: %.1f us, %.1f TFLOP/s, max rel err %.2e' % (layout, nsplit, M, N, R, us, 2.0 * M * N * R / us / 1e6, err))
 lib = _lib.lib()
 if hasattr(lib, 'samx_debug_gemm_trace'):
     buf = (C.c_ulonglong * 64)()
