@@ -27,6 +27,8 @@ struct StepWs {
     int64_t* n_end;
     float *n_rews, *n_dones, *n_len, *n_obs1, *n_tq;
     double *ret_add1, *ret_add2;
+    void* stats_ws;  // layer-wise path: samx_d_input_stats scratch (inline d.obs_rms update)
+    size_t stats_bytes;
 };
 
 // Two side streams per device for the layer-wise path: the discriminator, target+critic and actor
@@ -94,6 +96,8 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.n_rews = ar.take<float>(nn); w.n_dones = ar.take<float>(nn); w.n_len = ar.take<float>(nn);
     w.n_obs1 = ar.take<float>(nn * ob); w.n_tq = ar.take<float>(nn);
     w.ret_add1 = ar.take<double>(4); w.ret_add2 = ar.take<double>(4);
+    w.stats_bytes = f ? 0 : samx_d_input_stats_ws_bytes(B, L->ob_dim);
+    w.stats_ws = ar.take<char>(w.stats_bytes);
     return w;
 }
 
@@ -576,9 +580,11 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     SAMX_REQUIRE((b->d_rms_sums == nullptr) == (b->d_rms_addvec == nullptr),
                  "samx_step_grads: d_rms_sums/d_rms_addvec go together");
     if (b->d_rms_sums) {
-        if (!use_fused(L, B))
-            return fail(SAMX_ERR_UNSUPPORTED, "samx_step_grads: inline statistics need the fused path");
         SAMX_REQUIRE(L->d_mean && L->d_std, "samx_step_grads: inline statistics need learner.d_mean/d_std");
+        // fused path: d_rms_addvec holds the row's sums (computed ahead).  Layer-wise path: the sums are
+        // computed HERE, on the discriminator's stream, and d_rms_addvec receives them.
+        SAMX_REQUIRE(use_fused(L, B) || (b->p_idx && b->e_start),
+                     "samx_step_grads: inline statistics on the layer-wise path need p_idx and e_start");
     }
     if (!use_fused(L, B) && !(part & 1)) {  // reduction part only
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
@@ -593,17 +599,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         samx_batch dense = *b;
         const samx_batch* orig = b;
         const int ob = L->ob_dim, ac = L->ac_dim;
-        if (b->p_idx && do_d) {
-            rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
-                                    ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
-            if (rc != SAMX_OK) return rc;
-            dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
-        }
-        if (b->e_start && do_d) {
-            expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
-            SAMX_LAUNCH_CHECK();
-            dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
-        }
+        // agent rows first, then fork: the target+critic and actor roles start while the caller's
+        // stream still prepares the discriminator's inputs (statistics, gathers, randoms)
         if (b->a_idx && do_a) {
             rc = samx_replay_gather(b->obs0, b->acs, b->rews, b->dones1, b->obs1, b->ring_len, b->ring_start,
                                     ob, ac, b->a_idx, B, w.g_obs0, w.g_acs, w.g_rews, w.g_dones, w.g_obs1,
@@ -612,18 +609,6 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             dense.obs0 = w.g_obs0; dense.acs = w.g_acs; dense.rews = w.g_rews; dense.dones1 = w.g_dones;
             dense.obs1 = w.g_obs1;
         }
-        if (!b->eps_ob && do_d) {
-            const int64_t n = B * (ob + ac + 2);
-            randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
-                b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
-                b->label_smoothing >= 1 ? w.r_real : nullptr, b->label_smoothing == 2 ? w.r_fake : nullptr);
-            SAMX_LAUNCH_CHECK();
-            dense.eps_ob = w.r_eob; dense.eps_ac = w.r_eac;
-            dense.real_labels = b->label_smoothing >= 1 ? w.r_real : nullptr;
-            dense.fake_labels = b->label_smoothing == 2 ? w.r_fake : nullptr;
-        }
-        b = &dense;
-        // fork: D role stays on the caller's stream, target+critic on side 0, actor on side 1
         static int serial = -1;  // SAMX_SERIAL_ROLES=1: everything on the caller's stream (profiling aid)
         if (serial < 0) { const char* e = getenv("SAMX_SERIAL_ROLES"); serial = e ? atoi(e) : 0; }
         hipStream_t s_tc = st, s_a = st;
@@ -637,6 +622,35 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             s_tc = ss->s[0];
             s_a = ss->s[1];
         }
+        if (b->d_rms_sums && do_d) {  // d.obs_rms.update on this row's D batch (sam.py:389-390), committed
+            rc = samx_d_input_stats(b->p_obs, b->ring_start, b->ring_len, b->p_idx, b->e_obs, b->e_start, B, ob,
+                                    const_cast<double*>(b->d_rms_addvec), 1, b->d_rms_sums,
+                                    const_cast<float*>(L->d_mean), const_cast<float*>(L->d_std), w.stats_ws,
+                                    w.stats_bytes, stream);
+            if (rc != SAMX_OK) return rc;
+        }
+        if (b->p_idx && do_d) {
+            rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
+                                    ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
+            if (rc != SAMX_OK) return rc;
+            dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
+        }
+        if (b->e_start && do_d) {
+            expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
+            SAMX_LAUNCH_CHECK();
+            dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
+        }
+        if (!b->eps_ob && do_d) {
+            const int64_t n = B * (ob + ac + 2);
+            randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
+                b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
+                b->label_smoothing >= 1 ? w.r_real : nullptr, b->label_smoothing == 2 ? w.r_fake : nullptr);
+            SAMX_LAUNCH_CHECK();
+            dense.eps_ob = w.r_eob; dense.eps_ac = w.r_eac;
+            dense.real_labels = b->label_smoothing >= 1 ? w.r_real : nullptr;
+            dense.fake_labels = b->label_smoothing == 2 ? w.r_fake : nullptr;
+        }
+        b = &dense;
         samx_retnorm retv{L->ret_mean, L->ret_std};
         const samx_retnorm* ret = L->ret_mean ? &retv : nullptr;
         const bool popart_or_stats = L->ret_mean && L->enable_popart;  // sam_agent.py:662 (update only then)

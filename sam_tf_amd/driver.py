@@ -152,7 +152,10 @@ class UpdateStepDriver(object):
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
         self.inline_stats = bool(self.fused and self.d.hps.rmsify_obs)
-        r = self.d.obs_rms if self.inline_stats else None
+        # layer-wise path, one process: samx_step_grads computes and commits the row's D statistics itself,
+        # on the discriminator's stream, while the agent roles already run (no separate stats segment)
+        self.inline_stats_lw = bool(not self.fused and self.world == 1 and self.d.hps.rmsify_obs)
+        r = self.d.obs_rms if (self.inline_stats or self.inline_stats_lw) else None
         if r is not None:  # the K batches' [sum, sumsq, count], filled by ONE kernel at the head of a launch
             self.addvecs = torch.zeros(self.K, 2 * self.mu.ob_dim + 1, dtype=torch.float64, device=self.dev)
         self.batches = []
@@ -172,7 +175,7 @@ class UpdateStepDriver(object):
     def _seg_inputs(self, k=0, role=3):
         """d.obs_rms.update on the D batch (sam.py:389-390); single process: sums + commit at once."""
         d, rb = self.d, self.mu.replay_buffer
-        if d.hps.rmsify_obs and not self.inline_stats and role & self.D:
+        if d.hps.rmsify_obs and not (self.inline_stats or self.inline_stats_lw) and role & self.D:
             r = d.obs_rms
             w = self.words[k]
             ops.d_input_stats(rb.store['obs0'], self._batch_start, w[:self.B], self.pool.obs0,
