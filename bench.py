@@ -311,6 +311,22 @@ def main():
         drv3.run(3 * n_ts)
         torch.cuda.synchronize()
         result['config']['training_steps_per_s_d1_g3'] = n_ts / (time.perf_counter() - t0)
+    if world > 1:
+        # all-reduce latency vs bucket bytes, back to back on the launch stream (what a
+        # step pays in series is the first entry at or above this config's gradient bucket)
+        lat = {}
+        for nbytes in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+            buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+            for _ in range(10):
+                comm.allreduce_(buf)
+            torch.cuda.synchronize(); comm.Barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                comm.allreduce_(buf)
+            torch.cuda.synchronize()
+            lat[str(nbytes)] = (time.perf_counter() - t0) / 50 * 1e6
+        result['config']['allreduce_us_by_bytes'] = lat
+        result['config']['grad_bucket_bytes'] = int(mu.L.grads.numel() * 4)
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline(cfg)
