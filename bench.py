@@ -173,6 +173,9 @@ def main():
     ap.add_argument('--launcher', action='store_true',
                     help='the canonical launcher options (mujoco_sam_imitate.sh): layernorm, rmsify_rets, '
                          'popart, n-step returns n=96')
+    ap.add_argument('--argparse-defaults', action='store_true',
+                    help="the reference's argparse defaults (argparsers.py:279-309): rmsify_rets, popart, n-step "
+                         'returns n=10, no layernorm')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-training-step', action='store_true',
                     help='skip the extra d_steps=1 : g_steps=3 training-step figure (config.training_steps_per_s)')
@@ -205,8 +208,9 @@ def main():
         comm = TorchComm(device)
         if world > 1 and os.environ.get('SAMX_RCCL_DIRECT', '1') != '0':
             comm.enable_direct()   # all-reduces on the launch stream through librccl (sam_tf_amd/rccl.py)
-    cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher,
-               nstep=96 if args.launcher and not CONFIGS[args.config]['per'] else 0)
+    nstep = 96 if args.launcher else (10 if args.argparse_defaults else 0)
+    cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher or args.argparse_defaults,
+               nstep=nstep if not CONFIGS[args.config]['per'] else 0)
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
 
     def timed():

@@ -21,10 +21,23 @@ struct AgentArgs {
     float *targ_q_out, *td_out;
     float* partials;  // [B/16][P] slots, P = Pa + Pc
     int64_t P, Pa;
-    float* loss_part;  // [B/16][4]: sum huber*iw, sum Q, sum D, (block 0) sum W1^2 + W2^2 of the critic
+    float* loss_part;  // [B/16][8]: sum huber*iw, sum Q, sum D, (block 0) sum W1^2 + W2^2 of the critic, sum huber_n*iw
     // optional row indirection into ring storage (memory.py:33-34); idx == nullptr: direct rows
     const int64_t* idx;
     int64_t ring_start, ring_len;
+    // Return normalisation (sam_agent.py:161-201): device scalars, nullptr = off.  The critic outputs
+    // normalised Q; predictions are de-normalised (s * std + mean), targets normalised.
+    const float *ret_mean, *ret_std;
+    // External targets: with return normalisation + PopArt or n-step returns the TD targets come from
+    // launch_targets (the return statistics / critic heads change between target and loss passes).
+    // ext_tq != nullptr: the target+critic role runs critic-only against ext_tq [B] (and ext_tqn [B]).
+    const float *ext_tq, *ext_tqn;
+    float tdn_scale;
+    // launch_targets only: the n-step rows (memory.py:113-160): obs1 rows through n_idx (ring), dense
+    // n_rews / n_dones / n_len [B]; targ_qn_out [B]
+    const int64_t* n_idx;
+    const float *n_rews, *n_dones, *n_len;
+    float* targ_qn_out;
 };
 
 struct DiscArgs {
@@ -76,6 +89,9 @@ struct FinalizeArgs {
     const float* agent_loss_part;
     int agent_tiles;
     float q_scale, d_scale, td_scale, wd_scale;
+    const float *ret_mean, *ret_std;   // return normalisation (device scalars), nullptr = off
+    float tdn_scale;                   // n-step loss scale; agent_loss_part[.][4] holds its per-tile sums
+    int has_tdn;
     float *actor_losses, *critic_losses;
     // discriminator losses
     const float* disc_loss_part;
@@ -119,10 +135,13 @@ struct StepArgs {
 };
 // agent roles + discriminator first kernel in ONE launch, then the discriminator's second kernel
 int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
+// TD targets of B rows (and the n-step targets when a->n_idx) with the target nets: one launch
+int launch_targets(const AgentArgs* a, hipStream_t st);
+constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
               const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
-              int64_t ring_len, float* td_out, hipStream_t st);
+              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, hipStream_t st);
 int launch_finalize(const FinalizeArgs& f, hipStream_t st);
 int launch_apply(const ApplyArgs& f, hipStream_t st);
 int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st);

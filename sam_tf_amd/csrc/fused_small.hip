@@ -476,7 +476,7 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds, int
     if (tid == 0) {
         float s = 0.f;
         for (int r = 0; r < R; ++r) s += L.red[r];
-        a.loss_part[wg * 4 + 0] = s;  // sum of huber*iw over this tile's rows
+        a.loss_part[wg * kLossStride + 0] = s;  // sum of huber*iw over this tile's rows
     }
     head_bwd(L.dq, L.nC, L.A2c, L.DZa);
     wgrad_head1(L.A2c, L.dq, gC + cW3, gC + cb3, R);
@@ -486,6 +486,139 @@ __device__ inline void agent_tc_body(const AgentArgs& a, int wg, float* lds, int
     __syncthreads();
     wgrad64(L.XC, in_c, L.DZb, gC + cW1, gC + cb1, R);
     TRACE(trole, 6);
+}
+
+// TD targets only (return normalisation + PopArt / n-step: the statistics and the critic heads change
+// between the target pass and the loss pass, sam_agent.py:651-672).  pass 0: the 1-step target of the
+// sampled rows; pass 1: the n-step target (rows n_idx, dense n_rews / n_dones / n_len).
+__device__ inline void agent_t_body(const AgentArgs& a, int wg, float* lds, int pass) {
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac;
+    AgentLds L = carve_agent_lds(lds, ob, ac, false);
+    const int64_t* idx = pass ? a.n_idx : a.idx;
+    const int64_t pr = ring_row(idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    const int64_t prs = ring_row(idx, a.ring_start, a.ring_len, row0 + (tid & 15));
+    NetRegs wA, wC;
+    net_issue(wA, L.nA, a.targ_actor);
+    net_issue(wC, L.nC, a.targ_critic);
+    const HeadRegs hA = head_issue(L.nA, a.targ_actor), hC = head_issue(L.nC, a.targ_critic);
+    float rw = 0.f, dn = 0.f, tl = 1.f;
+    if (tid < R) {
+        if (pass) { rw = a.n_rews[row0 + tid]; dn = a.n_dones[row0 + tid]; tl = a.n_len[row0 + tid]; }
+        else if (a.td_len) tl = a.td_len[row0 + tid];
+    }
+    RowRegs x1;
+    rows_issue(x1, pr, a.obs1, nullptr, a.mean, a.stdv, ob, 0, ob);
+    if (tid < R && !pass) { rw = a.rews[prs]; dn = a.dones1[prs]; }
+    net_commit(wA, L.nA);
+    net_commit(wC, L.nC);
+    head_commit(L.nA, hA);
+    head_commit(L.nC, hC);
+    rows_commit(L.XC, x1, a.mean != nullptr, ob, ob);
+    if (tid < R) { L.rw[tid] = rw; L.dn[tid] = dn; L.tl[tid] = tl; }
+    stage_wait();
+    layer_fwd(L.XC, L.nA.k4, L.nA.W1, L.nA.b1, L.A1a);
+    __syncthreads();
+    layer_fwd(L.A1a, H, L.nA.W2, L.nA.b2, L.A2a);
+    __syncthreads();
+    actor_head(L, ob, ac, a.high);
+    __syncthreads();
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
+    __syncthreads();
+    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    __syncthreads();
+    head_dot(L.A2c, L.nC, L.s_);
+    __syncthreads();
+    if (tid < R) {
+        const bool lens = pass || a.td_len;
+        const float gam = lens ? powf(a.gamma, L.tl[tid]) : a.gamma;
+        float qp = L.s_[tid];
+        if (a.ret_mean) qp = qp * a.ret_std[0] + a.ret_mean[0];              // sam_agent.py:199-201
+        const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * qp);
+        (pass ? a.targ_qn_out : a.targ_q_out)[row0 + tid] = t;
+    }
+}
+
+// Critic loss + gradient against EXTERNAL targets (a.ext_tq, a.ext_tqn), with return normalisation:
+// pred = s * std + mean, td = pred - (target - mean) / std   (sam_agent.py:161-182,457-520)
+__device__ inline void agent_c_body(const AgentArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac, in_c = ob + ac;
+    AgentLds L = carve_agent_lds(lds, ob, ac, false);
+    float* gC = a.partials + (int64_t)wg * a.P + a.Pa;
+    const int64_t cW1 = 0, cb1 = cW1 + (int64_t)in_c * H, cW2 = cb1 + H, cb2 = cW2 + H * H, cW3 = cb2 + H,
+                  cb3 = cW3 + H;
+    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    NetRegs wC;
+    net_issue(wC, L.nC, a.critic);
+    const HeadRegs hC = head_issue(L.nC, a.critic);
+    float iw = 1.f, t1 = 0.f, tn = 0.f;
+    if (tid < R) {
+        if (a.iws) iw = a.iws[row0 + tid];
+        t1 = a.ext_tq[row0 + tid];
+        if (a.ext_tqn) tn = a.ext_tqn[row0 + tid];
+    }
+    const float rmean = a.ret_mean ? a.ret_mean[0] : 0.f, rstd = a.ret_std ? a.ret_std[0] : 1.f;
+    RowRegs x0;
+    rows_issue(x0, pr, a.obs0, a.acs, a.mean, a.stdv, ob, ac, in_c);
+    net_commit(wC, L.nC);
+    head_commit(L.nC, hC);
+    rows_commit(L.XC, x0, a.mean != nullptr, ob, in_c);
+    if (tid < R) { L.iw[tid] = iw; L.tq[tid] = t1; L.tl[tid] = tn; }
+    stage_wait();
+    layer_fwd(L.XC, L.nC.k4, L.nC.W1, L.nC.b1, L.A1c);
+    if (wg == 0) {   // weight-decay loss term (network_util.py:43-56)
+        double acc = 0.0;
+        for (int t = tid; t < L.nC.k4 * H; t += NT) { const float w = L.nC.W1[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int t = tid; t < H * H; t += NT) { const float w = L.nC.W2[(t >> 6) * LD + (t & 63)]; acc += (double)w * w; }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) L.red[wv] = (float)acc;
+    }
+    __syncthreads();
+    if (wg == 0 && tid == 0) a.loss_part[3] = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
+    __syncthreads();
+    head_dot(L.A2c, L.nC, L.s_);
+    __syncthreads();
+    if (tid < R) {
+        const int64_t g = row0 + tid;
+        const float pred = a.ret_mean ? L.s_[tid] * rstd + rmean : L.s_[tid];
+        const float w = L.iw[tid];
+        auto hub = [](float td, float& dh) {                              // math_util.py:22-29
+            const float ad = fabsf(td);
+            dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
+            return ad < 1.f ? 0.5f * td * td : ad - 0.5f;
+        };
+        const float td1 = pred - (a.ret_mean ? (L.tq[tid] - rmean) / rstd : L.tq[tid]);
+        float dh1, dhn = 0.f, hn = 0.f;
+        const float h1 = hub(td1, dh1);
+        float dq = (a.td_scale / (float)a.B) * dh1;
+        if (a.ext_tqn) {                                                  // sam_agent.py:483-498
+            const float tdn = pred - (a.ret_mean ? (L.tl[tid] - rmean) / rstd : L.tl[tid]);
+            hn = hub(tdn, dhn);
+            dq += (a.tdn_scale / (float)a.B) * dhn;
+        }
+        L.dq[tid] = dq * w * rstd;
+        L.red[tid] = h1 * w;
+        L.son[tid] = hn * w;
+        if (a.td_out) a.td_out[g] = td1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f, sn = 0.f;
+        for (int r = 0; r < R; ++r) { s += L.red[r]; sn += L.son[r]; }
+        a.loss_part[wg * kLossStride + 0] = s;
+        a.loss_part[wg * kLossStride + 4] = sn;
+    }
+    head_bwd(L.dq, L.nC, L.A2c, L.DZa);
+    wgrad_head1(L.A2c, L.dq, gC + cW3, gC + cb3, R);
+    __syncthreads();
+    wgrad64(L.A1c, H, L.DZa, gC + cW2, gC + cb2, R);
+    layer_bwd(L.DZa, L.nC.W2, L.A1c, L.DZb);
+    __syncthreads();
+    wgrad64(L.XC, in_c, L.DZb, gC + cW1, gC + cb1, R);
 }
 
 __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
@@ -530,12 +663,13 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
     layer_fwd(L.A1c, H, L.nC.W2, L.nC.b2, L.A2c);
     __syncthreads();
     head_dot(L.A2c, L.nC, L.s_);
-    if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+    const float rstd_ = a.ret_std ? a.ret_std[0] : 1.f;   // d(de-normalised Q)/d(critic output)
+    if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B * rstd_;
     __syncthreads();
     if (tid == 0) {
         float s = 0.f;
         for (int r = 0; r < R; ++r) s += L.s_[r];
-        a.loss_part[wg * 4 + 1] = s;  // sum of Q(s, mu(s))
+        a.loss_part[wg * kLossStride + 1] = s;  // sum of Q(s, mu(s))
     }
     head_bwd(L.dq, L.nC, L.A2c, L.DZa);
     __syncthreads();
@@ -552,12 +686,12 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
         layer_fwd(L.A1c, H, L.nD.W2, L.nD.b2, L.A2c);
         __syncthreads();
         head_dot(L.A2c, L.nD, L.s_);
-        if (tid < R) L.dq[tid] = -a.d_scale / (float)a.B;
+        if (tid < R) L.dq[tid] = -a.d_scale / (float)a.B * rstd_;
         __syncthreads();
         if (tid == 0) {
             float s = 0.f;
             for (int r = 0; r < R; ++r) s += L.s_[r];
-            a.loss_part[wg * 4 + 2] = s;
+            a.loss_part[wg * kLossStride + 2] = s;
         }
         head_bwd(L.dq, L.nD, L.A2c, L.DZa);
         __syncthreads();
@@ -566,7 +700,7 @@ __device__ inline void agent_a_body(const AgentArgs& a, int wg, float* lds) {
         if (wv == 0) dA += tile_nt64(L.DZb, L.nD.W1, ob, lane);
         __syncthreads();
     } else if (tid == 0) {
-        a.loss_part[wg * 4 + 2] = 0.f;
+        a.loss_part[wg * kLossStride + 2] = 0.f;
     }
     TRACE(0, 4);
     if (wv == 0) {  // through clip (identity inside the range) and tanh
@@ -850,6 +984,7 @@ __device__ inline void disc1_body(const DiscArgs& a, int wg, float* lds) {
 // critic_ops['td_errors'] (sam_agent.py:534-538,693-701) for 16 rows per workgroup: the PER refresh with
 // the post-update critic, rows read in place through the index words.
 struct TdArgs {
+    const float *ret_mean, *ret_std;   // return normalisation (device scalars) or nullptr
     const float *obs0, *acs, *tc1s, *mean, *stdv, *critic;
     float* td_out;
     int ob, ac;
@@ -882,7 +1017,15 @@ __global__ __launch_bounds__(NT) void td_kernel(TdArgs a) {
     __syncthreads();
     head_dot(A2, n, s_);
     __syncthreads();
-    if (tid < R) a.td_out[row0 + tid] = s_[tid] - a.tc1s[row0 + tid];
+    if (tid < R) {
+        float q = s_[tid], t = a.tc1s[row0 + tid];
+        if (a.ret_mean) {   // sam_agent.py:161-182: de-normalised prediction minus normalised target
+            const float rm = a.ret_mean[0], rs = a.ret_std[0];
+            q = q * rs + rm;
+            t = (t - rm) / rs;
+        }
+        a.td_out[row0 + tid] = q - t;
+    }
 }
 
 // One launch for every gradient pass of the step that needs no grid-wide value: the two agent roles
@@ -899,9 +1042,18 @@ __global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
         return;
     }
 #endif
-    if (b < s.n_tc) { agent_tc_body(s.a, b, lds); return; }
+    if (b < s.n_tc) {
+        if (s.a.ext_tq) agent_c_body(s.a, b, lds); else agent_tc_body(s.a, b, lds);
+        return;
+    }
     b -= s.n_tc;
     disc1_body(s.d, b, lds);
+}
+
+__global__ __launch_bounds__(NT) void targets_kernel(AgentArgs a, int tiles) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.x;
+    agent_t_body(a, b % tiles, lds, b / tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -932,23 +1084,29 @@ __device__ inline void finalize_scalars(const FinalizeArgs& f, int tid) {
         return x;
     };
     if (f.agent_loss_part) {
-        double h = 0.0, q = 0.0, dd = 0.0;
+        double h = 0.0, q = 0.0, dd = 0.0, hn = 0.0;
         for (int k = tid; k < f.agent_tiles; k += 64) {
-            h += (double)f.agent_loss_part[4 * k];
-            q += (double)f.agent_loss_part[4 * k + 1];
-            dd += (double)f.agent_loss_part[4 * k + 2];
+            h += (double)f.agent_loss_part[kLossStride * k];
+            q += (double)f.agent_loss_part[kLossStride * k + 1];
+            dd += (double)f.agent_loss_part[kLossStride * k + 2];
+            if (f.has_tdn) hn += (double)f.agent_loss_part[kLossStride * k + 4];
         }
-        h = wsum(h); q = wsum(q); dd = wsum(dd);
+        h = wsum(h); q = wsum(q); dd = wsum(dd); hn = wsum(hn);
         if (tid == 0) {
             const double B = (double)f.B;
-            const double ql = -q / B * f.q_scale, dl = -dd / B * f.d_scale;
+            // with return normalisation the actor loss is on the DE-normalised prediction
+            // (sam_agent.py:184-194): mean(s * std + mean) = mean(s) * std + mean
+            const double rm = f.ret_mean ? (double)f.ret_mean[0] : 0.0, rs = f.ret_std ? (double)f.ret_std[0] : 1.0;
+            const double ql = -(q / B * rs + rm) * f.q_scale;
+            const double dl = f.d_scale != 0.f ? -(dd / B * rs + rm) * f.d_scale : 0.0;
             f.actor_losses[0] = (float)ql; f.actor_losses[1] = (float)dl;
             f.actor_losses[2] = (float)(ql + dl);
             const double tl = h / B * f.td_scale;
+            const double tn = f.has_tdn ? hn / B * f.tdn_scale : 0.0;
             const double wl = 0.5 * (double)f.wd_scale * (double)f.agent_loss_part[3];
             f.critic_losses[0] = (float)tl; f.critic_losses[1] = (float)wl;
-            f.critic_losses[2] = (float)(tl + wl);
-            f.critic_losses[3] = 0.f;  // no n-step term on this path
+            f.critic_losses[2] = (float)(tl + wl + tn);
+            f.critic_losses[3] = (float)tn;
         }
     }
     if (f.disc_loss_part) {
@@ -1193,10 +1351,26 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
     return SAMX_OK;
 }
 
+int launch_targets(const AgentArgs* a, hipStream_t st) {
+    const int tiles = (int)(a->B / R);
+    const size_t lds = agent_lds_bytes(a->ob, a->ac, false);
+    SAMX_REQUIRE(lds <= 150 * 1024, "fused targets kernel needs %zu bytes of LDS", lds);
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)targets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+        attr_set = lds;
+    }
+    targets_kernel<<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
               const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
-              int64_t ring_len, float* td_out, hipStream_t st) {
+              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, hipStream_t st) {
     TdArgs a;
+    a.ret_mean = ret_mean; a.ret_std = ret_std;
     a.obs0 = obs0; a.acs = acs; a.tc1s = tc1s; a.mean = mean; a.stdv = stdv; a.critic = critic;
     a.td_out = td_out; a.ob = ob; a.ac = dc->in_dim - ob; a.idx = idx; a.ring_start = ring_start;
     a.ring_len = ring_len;

@@ -60,7 +60,6 @@ int side_streams(SideStreams** out) {
 }
 
 bool use_fused(const samx_learner* L, int64_t B) {
-    if (L->ret_mean || L->n_step > 0) return false;  // return normalisation / n-step: layer-wise path
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
            fused::supported(&L->reward, B) && L->critic.in_dim == L->ob_dim + L->ac_dim &&
            L->reward.in_dim == L->critic.in_dim && fused::fits_lds(L->ob_dim, L->ac_dim);
@@ -74,7 +73,7 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     const bool f = use_fused(L, B);
     w.agent_part = ar.take<float>(f ? tiles * (Pa + Pc) : 1);
     w.disc_part = ar.take<float>(f ? 3 * tiles * Pd : 1);
-    w.agent_loss = ar.take<float>(tiles * 4);
+    w.agent_loss = ar.take<float>(tiles * fused::kLossStride);
     w.disc_loss = ar.take<float>(2 * tiles * 4);
     w.gp_out = ar.take<float>(4);
     w.sumsq = ar.take<float>(3 * fused::kMaxSegBlocks);
@@ -91,7 +90,8 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.g_rews = ar.take<float>(n); w.g_dones = ar.take<float>(n); w.g_obs1 = ar.take<float>(n * ob);
     w.r_eob = ar.take<float>(n * ob); w.r_eac = ar.take<float>(n * ac);
     w.r_real = ar.take<float>(n); w.r_fake = ar.take<float>(n);
-    const int64_t nn = (!f && L->n_step > 0) ? B : 0;
+    const int64_t nn = L->n_step > 0 ? B : 0;   // both paths: lookahead outputs (the gathered n_obs1 rows
+                                                // are only used by the layer-wise path)
     w.n_end = ar.take<int64_t>(nn);
     w.n_rews = ar.take<float>(nn); w.n_dones = ar.take<float>(nn); w.n_len = ar.take<float>(nn);
     w.n_obs1 = ar.take<float>(nn * ob); w.n_tq = ar.take<float>(nn);
@@ -504,9 +504,10 @@ int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, 
     SAMX_REQUIRE(!idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_td_errors_rows: bad ring geometry");
     const bool ret_on = ret && ret->mean;
-    if (fused::supported(dc, B) && dc->out_dim == 1 && !ret_on)
+    if (fused::supported(dc, B) && dc->out_dim == 1 && fused::fits_lds(ob_dim, dc->in_dim - ob_dim))
         return fused::launch_td(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, idx, ring_start, ring_len,
-                                td_out, (hipStream_t)stream);
+                                td_out, ret_on ? ret->mean : nullptr, ret_on ? ret->std : nullptr,
+                                (hipStream_t)stream);
     // general path: gather the rows, then the layer-wise pass
     const int ac = dc->in_dim - ob_dim;
     SAMX_REQUIRE(ws, "samx_td_errors_rows: this configuration needs a workspace");
@@ -750,6 +751,42 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     a.targ_q_out = o->targ_q; a.td_out = o->td;
     a.partials = w.agent_part; a.P = Pa + Pc; a.Pa = Pa; a.loss_part = w.agent_loss;
     a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
+    a.ret_mean = L->ret_mean; a.ret_std = L->ret_std;
+    a.ext_tq = a.ext_tqn = nullptr; a.tdn_scale = L->td_loss_n_scale;
+    a.n_idx = nullptr; a.n_rews = a.n_dones = a.n_len = nullptr; a.targ_qn_out = nullptr;
+    const bool ext = L->ret_mean || L->n_step > 0;   // targets from their own launch
+    if ((part & 1) && do_a && ext) {
+        // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
+        // ret_rms.update + PopArt -> losses with the new ones
+        float* tqn = nullptr;
+        if (L->n_step > 0) {
+            SAMX_REQUIRE(b->a_idx && b->num_entries > 0,
+                         "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
+            rc = samx_nstep_lookahead(b->rews, b->dones1, b->ring_len, b->ring_start, b->num_entries, b->a_idx, B,
+                                      L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr, w.n_dones, w.n_len,
+                                      stream);
+            if (rc != SAMX_OK) return rc;
+            tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
+            a.n_idx = w.n_end; a.n_rews = w.n_rews; a.n_dones = w.n_dones; a.n_len = w.n_len;
+            a.targ_qn_out = tqn;
+        }
+        rc = fused::launch_targets(&a, st);
+        if (rc != SAMX_OK) return rc;
+        if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
+            rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, stream);
+            if (rc != SAMX_OK) return rc;
+            if (tqn) {
+                rc = samx_rms_batch_sums(tqn, B, nullptr, 0, 1, w.ret_add2, stream);
+                if (rc != SAMX_OK) return rc;
+            }
+            rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, tqn ? w.ret_add2 : nullptr, L->ret_mean,
+                                        L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, stream);
+            if (rc != SAMX_OK) return rc;
+        }
+        a.ext_tq = o->targ_q; a.ext_tqn = tqn;
+    } else if (ext) {
+        a.ext_tq = o->targ_q; a.ext_tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;
+    }
     if (part & 1) {
         rc = fused::launch_step(do_a ? &a : nullptr, do_d ? &d : nullptr, st);
         if (rc != SAMX_OK) return rc;
@@ -784,6 +821,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     f.agent_loss_part = do_a ? w.agent_loss : nullptr; f.agent_tiles = tiles;
     f.q_scale = L->q_actor_loss_scale; f.d_scale = L->d_actor_loss_scale;
     f.td_scale = L->td_loss_scale; f.wd_scale = L->wd_scale;
+    f.ret_mean = L->ret_mean; f.ret_std = L->ret_std;
+    f.tdn_scale = L->td_loss_n_scale; f.has_tdn = L->n_step > 0 ? 1 : 0;
     f.actor_losses = o->actor_losses; f.critic_losses = o->critic_losses;
     f.disc_loss_part = do_d ? w.disc_loss : nullptr; f.disc_tiles_b = tiles;
     f.ent_scale = L->ent_reg_scale; f.gp_coeff = 10.f; f.gp = w.gp_out; f.disc_losses = o->d_losses;

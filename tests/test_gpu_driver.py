@@ -140,7 +140,8 @@ class OracleLearner(object):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'widein', 'edge64'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
+                                      'C1-nstep', 'widein', 'edge64'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
@@ -152,11 +153,16 @@ def test_k_steps_match_oracle(cfg_name, graph):
     # edge64: the widest input the whole-network kernels still hold.
     extra = {'widein': dict(ob=50, ac=10, h=(64, 64), B=32, per=False, name='wide-input'),
              'edge64': dict(ob=20, ac=4, h=(64, 64), B=32, per=True, name='edge')}
+    # ret / retn / nstep: the argparse-default options (rmsify_rets + PopArt, n-step returns) WITHOUT
+    # LayerNorm: whole-network path with the targets in their own launch
     cfg = dict(extra.get(base) or bench.CONFIGS[base], mem=2048, ln=opt in ('ln', 'launcher'),
-               ret=opt in ('launcher', 'ret'), nstep=7 if opt == 'launcher' else 0, p_done=0.1)
+               ret=opt in ('launcher', 'ret', 'retn'), nstep=7 if opt in ('launcher', 'retn', 'nstep') else 0,
+               p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
     if base in extra:
         assert drv.fused == (base == 'edge64')
+    elif opt:
+        assert drv.fused == (opt in ('ret', 'retn', 'nstep'))
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
     K = 6
