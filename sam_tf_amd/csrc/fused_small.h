@@ -137,6 +137,9 @@ struct StepArgs {
 int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
 // TD targets of B rows (and the n-step targets when a->n_idx) with the target nets: one launch
 int launch_targets(const AgentArgs* a, hipStream_t st);
+// ret_rms.update(tq [, tqn]) + PopArt rescale of the critic heads (sam_agent.py:554-590,662-672), one launch
+int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
+                      int popart, float* critic, float* targ_critic, int critic_in, hipStream_t st);
 constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,

@@ -1050,6 +1050,62 @@ __global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
     disc1_body(s.d, b, lds);
 }
 
+// ret_rms.update(targ_q_1) [, update(targ_q_n)] and the PopArt rescale of the online and target critic
+// heads in ONE launch (sam_agent.py:554-590,662-672; three launches on the layer-wise path).  One
+// workgroup: float64 sums of x and x^2 per batch (thread-strided, then a fixed LDS tree), the running
+// sums updated batch by batch, new mean/std, w3 <- w3 * old_std / new_std,
+// b3 <- (b3 * old_std + old_mean - new_mean) / new_std.
+__global__ __launch_bounds__(256) void ret_popart_kernel(const float* __restrict__ tq, const float* __restrict__ tqn,
+                                                         int64_t B, double* __restrict__ sums, float* mean,
+                                                         float* stdv, int popart, float* w3a, float* b3a,
+                                                         float* w3b, float* b3b) {
+    __shared__ double sh[4][256];
+    __shared__ float shf[4];
+    const int tid = threadIdx.x;
+    double a1 = 0.0, q1 = 0.0, a2 = 0.0, q2 = 0.0;
+    for (int64_t i = tid; i < B; i += 256) {
+        const double x = (double)tq[i];
+        a1 = __dadd_rn(a1, x); q1 = __dadd_rn(q1, __dmul_rn(x, x));
+        if (tqn) {
+            const double y = (double)tqn[i];
+            a2 = __dadd_rn(a2, y); q2 = __dadd_rn(q2, __dmul_rn(y, y));
+        }
+    }
+    sh[0][tid] = a1; sh[1][tid] = q1; sh[2][tid] = a2; sh[3][tid] = q2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sh[k][tid] = __dadd_rn(sh[k][tid], sh[k][tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        shf[0] = mean[0];
+        shf[1] = stdv[0];
+        double s0 = sums[0], s1 = sums[1], s2 = sums[2];
+        s0 = __dadd_rn(s0, sh[0][0]); s1 = __dadd_rn(s1, sh[1][0]); s2 = __dadd_rn(s2, (double)B);
+        if (tqn) { s0 = __dadd_rn(s0, sh[2][0]); s1 = __dadd_rn(s1, sh[3][0]); s2 = __dadd_rn(s2, (double)B); }
+        sums[0] = s0; sums[1] = s1; sums[2] = s2;
+        const float m = (float)(s0 / s2), msq = (float)(s1 / s2);
+        const float sd = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(m, m)), 1e-2f));
+        mean[0] = m;
+        stdv[0] = sd;
+        shf[2] = m;
+        shf[3] = sd;
+    }
+    __syncthreads();
+    if (!popart) return;
+    const float om = shf[0], os = shf[1], nm = shf[2], ns = shf[3];
+    if (tid < H) {
+        w3a[tid] = __fdiv_rn(__fmul_rn(w3a[tid], os), ns);
+        w3b[tid] = __fdiv_rn(__fmul_rn(w3b[tid], os), ns);
+    }
+    if (tid == 0) {
+        b3a[0] = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(b3a[0], os), om), nm), ns);
+        b3b[0] = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(b3b[0], os), om), nm), ns);
+    }
+}
+
 __global__ __launch_bounds__(NT) void targets_kernel(AgentArgs a, int tiles) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
@@ -1347,6 +1403,15 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
         attr_set = lds;
     }
     step_kernel<<<(unsigned)(s.n_a + s.n_tc + s.n_disc), NT, lds, st>>>(s);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
+                      int popart, float* critic, float* targ_critic, int critic_in, hipStream_t st) {
+    const int64_t oW3 = (int64_t)critic_in * H + H + H * H + H, ob3 = oW3 + H;   // 64x64 net, 1 output
+    ret_popart_kernel<<<1, 256, 0, st>>>(tq, tqn, B, sums, mean, stdv, popart, critic + oW3, critic + ob3,
+                                         targ_critic + oW3, targ_critic + ob3);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -773,14 +773,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         rc = fused::launch_targets(&a, st);
         if (rc != SAMX_OK) return rc;
         if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
-            rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, stream);
-            if (rc != SAMX_OK) return rc;
-            if (tqn) {
-                rc = samx_rms_batch_sums(tqn, B, nullptr, 0, 1, w.ret_add2, stream);
-                if (rc != SAMX_OK) return rc;
-            }
-            rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, tqn ? w.ret_add2 : nullptr, L->ret_mean,
-                                        L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, stream);
+            rc = fused::launch_ret_popart(o->targ_q, tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
+                                          L->params + Pa, L->targets + Pa, L->critic.in_dim, st);
             if (rc != SAMX_OK) return rc;
         }
         a.ext_tq = o->targ_q; a.ext_tqn = tqn;
