@@ -3,8 +3,9 @@
 Field names follow helpers/argparsers.py:6-50 (`disambiguate`: hid_widths / ent_reg_scale with the
 actorcritic_/d_ prefix stripped); defaults are the canonical launcher
 (launchers/imitation/mujoco_sam_imitate.sh:16-64) except that with_layernorm, rmsify_rets,
-enable_popart and n_step_returns default to off here (the BASELINE.json configs); all four are built
-and switch the step onto the layer-wise path.
+enable_popart and n_step_returns default to off here (the BASELINE.json configs); all four are built.
+with_layernorm switches the step onto the layer-wise path; the other three run on the whole-network
+path for 64x64 nets.
 """
 from types import SimpleNamespace
 
