@@ -112,6 +112,14 @@ int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen,
                          int64_t num_entries, const int64_t* idxs, int64_t B, int n, double gamma,
                          int64_t* end_idx_out, float* rews_out, double* rews64_out, float* dones_out,
                          float* td_len_out, void* stream);
+/* The same for K batches in one launch: batch k's B indices start at idxs + k * idx_stride; outputs are
+ * dense [K*B].  The lookahead reads only the replay storage, so the K batches of a multi-row launch
+ * (uniform replay: all indices known up front) can be done ahead and handed to samx_step_grads through
+ * samx_batch.n_end / n_rews / n_dones / n_len. */
+int samx_nstep_lookahead_many(const float* rews, const float* dones1, int64_t maxlen, int64_t start,
+                              int64_t num_entries, const int64_t* idxs, int64_t idx_stride, int64_t K,
+                              int64_t B, int n, double gamma, int64_t* end_idx_out, float* rews_out,
+                              float* dones_out, float* td_len_out, void* stream);
 
 /* RingBuffer.append of one staged transition (memory.py:36-57,177-184): `row` is the physical
  * slot the host ring arithmetic chose; packed = [obs0(ob) | acs(ac) | rew | obs1(ob) | done]. */
@@ -350,6 +358,10 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
     double* d_rms_sums;
     const double* d_rms_addvec;
     int64_t num_entries; /* entries in the replay ring: bounds the n-step lookahead window */
+    /* learner.n_step > 0: the lookahead of a_idx done ahead (outputs of samx_nstep_lookahead[_many] for
+     * exactly these B indices); all NULL = samx_step_grads runs the lookahead itself */
+    const int64_t* n_end;
+    const float *n_rews, *n_dones, *n_len;
 } samx_batch;
 
 typedef struct samx_step_out {

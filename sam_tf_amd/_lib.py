@@ -47,7 +47,8 @@ class Batch(C.Structure):
         'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'p_idx', 'a_idx', 'e_start')] +
                 [('ring_start', C.c_int64), ('ring_len', C.c_int64), ('rng_seed', C.c_uint64),
                  ('label_smoothing', C.c_int32), ('d_rms_sums', C.c_void_p), ('d_rms_addvec', C.c_void_p),
-                 ('num_entries', C.c_int64)])
+                 ('num_entries', C.c_int64), ('n_end', C.c_void_p), ('n_rews', C.c_void_p),
+                 ('n_dones', C.c_void_p), ('n_len', C.c_void_p)])
 
 
 class StepOut(C.Structure):
@@ -108,6 +109,8 @@ SIGNATURES = {
     'samx_ret_update_popart': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _MP, _P, _P, _P]),
     'samx_nstep_lookahead': (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, C.c_int, _D, _P, _P, _P, _P,
                                        _P, _P]),
+    'samx_nstep_lookahead_many': (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, C.c_int, _D, _P, _P,
+                                            _P, _P, _P]),
     'samx_disc_ws_bytes': (_SZ, [_MP, _I64]),
     'samx_disc_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int,
                                  _F, _P, _P, _P, _SZ, _P]),

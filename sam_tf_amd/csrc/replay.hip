@@ -125,7 +125,8 @@ namespace {
 __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ rews,
                                                     const float* __restrict__ dones1, int64_t maxlen,
                                                     int64_t start, int64_t num_entries,
-                                                    const int64_t* __restrict__ idxs, int64_t B, int n,
+                                                    const int64_t* __restrict__ idxs, int64_t idx_stride,
+                                                    int64_t rows_per_batch, int64_t B, int n,
                                                     double gamma, int64_t* __restrict__ end_idx_out,
                                                     float* __restrict__ rews_out,
                                                     double* __restrict__ rews64_out,
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ re
                                                     float* __restrict__ td_len_out) {
     const int64_t t = blockIdx.x * (int64_t)128 + threadIdx.x;
     if (t >= B) return;
-    const int64_t idx = idxs[t];
+    // batch k's indices start at idxs + k*idx_stride (the driver's per-row index words); outputs are dense
+    const int64_t idx = idxs[(t / rows_per_batch) * idx_stride + t % rows_per_batch];
     const int64_t last = (idx + n < num_entries ? idx + n : num_entries) - 1;  // lookahead_end_idx
     const int win = (int)(last - idx + 1);
     int64_t phys0 = start + idx;
@@ -240,8 +242,25 @@ int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen,
     SAMX_REQUIRE(maxlen > 0 && start >= 0 && start < maxlen && num_entries > 0 && num_entries <= maxlen,
                  "samx_nstep_lookahead: bad ring geometry");
     nstep_kernel<<<(unsigned)((B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
-        rews, dones1, maxlen, start, num_entries, idxs, B, n, gamma, end_idx_out, rews_out, rews64_out,
+        rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
         dones_out, td_len_out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_nstep_lookahead_many(const float* rews, const float* dones1, int64_t maxlen, int64_t start,
+                              int64_t num_entries, const int64_t* idxs, int64_t idx_stride, int64_t K,
+                              int64_t B, int n, double gamma, int64_t* end_idx_out, float* rews_out,
+                              float* dones_out, float* td_len_out, void* stream) {
+    SAMX_REQUIRE(rews && dones1 && idxs && end_idx_out && rews_out && dones_out && td_len_out,
+                 "samx_nstep_lookahead_many: null pointer");
+    SAMX_REQUIRE(B > 0 && K > 0 && idx_stride >= B && n > 1 && n <= 4096,
+                 "samx_nstep_lookahead_many: need B > 0, K > 0, idx_stride >= B and 1 < n <= 4096");
+    SAMX_REQUIRE(maxlen > 0 && start >= 0 && start < maxlen && num_entries > 0 && num_entries <= maxlen,
+                 "samx_nstep_lookahead_many: bad ring geometry");
+    nstep_kernel<<<(unsigned)((K * B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
+        rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
+        nullptr, dones_out, td_len_out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

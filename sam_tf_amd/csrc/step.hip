@@ -560,6 +560,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                  "samx_step_grads: missing batch input");
     SAMX_REQUIRE((b->eps_ob == nullptr) == (b->eps_ac == nullptr), "samx_step_grads: eps_ob/eps_ac go together");
     SAMX_REQUIRE(b->label_smoothing >= 0 && b->label_smoothing <= 2, "samx_step_grads: label_smoothing");
+    SAMX_REQUIRE(!b->n_end == !b->n_rews && !b->n_end == !b->n_dones && !b->n_end == !b->n_len,
+                 "samx_step_grads: n_end / n_rews / n_dones / n_len come together or not at all");
     SAMX_REQUIRE((!b->p_idx && !b->a_idx) ||
                      (b->ring_len > 0 && b->ring_start >= 0 && b->ring_start < b->ring_len),
                  "samx_step_grads: bad ring geometry");
@@ -657,16 +659,22 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         const bool popart_or_stats = L->ret_mean && L->enable_popart;  // sam_agent.py:662 (update only then)
         // ---- target + critic role (side 0)
         const float* tcns = nullptr;
+        const int64_t* nl_end = w.n_end;
+        const float *nl_rews = w.n_rews, *nl_dones = w.n_dones, *nl_len = w.n_len;
         if (do_a) {
         if (L->n_step > 0) {  // n-step lookahead from the sampled indices (memory.py:113-160)
             SAMX_REQUIRE(orig->a_idx && orig->num_entries > 0,
                          "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
-            rc = samx_nstep_lookahead(orig->rews, orig->dones1, orig->ring_len, orig->ring_start, orig->num_entries,
-                                      orig->a_idx, B, L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr,
-                                      w.n_dones, w.n_len, (void*)s_tc);
-            if (rc != SAMX_OK) return rc;
+            if (!orig->n_end) {
+                rc = samx_nstep_lookahead(orig->rews, orig->dones1, orig->ring_len, orig->ring_start,
+                                          orig->num_entries, orig->a_idx, B, L->n_step, (double)L->gamma, w.n_end,
+                                          w.n_rews, nullptr, w.n_dones, w.n_len, (void*)s_tc);
+                if (rc != SAMX_OK) return rc;
+            } else {   // done ahead by the caller (samx_nstep_lookahead_many)
+                nl_end = orig->n_end; nl_rews = orig->n_rews; nl_dones = orig->n_dones; nl_len = orig->n_len;
+            }
             rc = samx_replay_gather(nullptr, nullptr, nullptr, nullptr, orig->obs1, orig->ring_len, orig->ring_start,
-                                    ob, ac, w.n_end, B, nullptr, nullptr, nullptr, nullptr, w.n_obs1, (void*)s_tc);
+                                    ob, ac, nl_end, B, nullptr, nullptr, nullptr, nullptr, w.n_obs1, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
         }
         rc = samx_targ_q(&L->actor, ta, &L->critic, tc, b->obs1, b->rews, b->dones1, b->td_len, L->mu_mean,
@@ -675,7 +683,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (rc != SAMX_OK) return rc;
         if (L->n_step > 0) {
             float* tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
-            rc = samx_targ_q(&L->actor, ta, &L->critic, tc, w.n_obs1, w.n_rews, w.n_dones, w.n_len, L->mu_mean,
+            rc = samx_targ_q(&L->actor, ta, &L->critic, tc, w.n_obs1, nl_rews, nl_dones, nl_len, L->mu_mean,
                              L->mu_std, B, L->gamma, L->ac_high, tqn, ret, w.nets_ws, w.nets_bytes, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
             tcns = tqn;
@@ -762,12 +770,16 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (L->n_step > 0) {
             SAMX_REQUIRE(b->a_idx && b->num_entries > 0,
                          "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
-            rc = samx_nstep_lookahead(b->rews, b->dones1, b->ring_len, b->ring_start, b->num_entries, b->a_idx, B,
-                                      L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr, w.n_dones, w.n_len,
-                                      stream);
-            if (rc != SAMX_OK) return rc;
+            if (b->n_end) {   // done ahead by the caller (samx_nstep_lookahead_many)
+                a.n_idx = b->n_end; a.n_rews = b->n_rews; a.n_dones = b->n_dones; a.n_len = b->n_len;
+            } else {
+                rc = samx_nstep_lookahead(b->rews, b->dones1, b->ring_len, b->ring_start, b->num_entries, b->a_idx,
+                                          B, L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr, w.n_dones,
+                                          w.n_len, stream);
+                if (rc != SAMX_OK) return rc;
+                a.n_idx = w.n_end; a.n_rews = w.n_rews; a.n_dones = w.n_dones; a.n_len = w.n_len;
+            }
             tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
-            a.n_idx = w.n_end; a.n_rews = w.n_rews; a.n_dones = w.n_dones; a.n_len = w.n_len;
             a.targ_qn_out = tqn;
         }
         rc = fused::launch_targets(&a, st);

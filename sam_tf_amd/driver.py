@@ -158,9 +158,20 @@ class UpdateStepDriver(object):
         r = self.d.obs_rms if (self.inline_stats or self.inline_stats_lw) else None
         if r is not None:  # the K batches' [sum, sumsq, count], filled by ONE kernel at the head of a launch
             self.addvecs = torch.zeros(self.K, 2 * self.mu.ob_dim + 1, dtype=torch.float64, device=self.dev)
+        # n-step returns with uniform replay: every row's indices are known when the launch starts and the
+        # lookahead (memory.py:113-160) reads only the replay storage -> ONE kernel for the K rows at the
+        # head of the launch instead of one per row (PER samples row k + 1 after row k's priority update)
+        self.nstep_ahead = bool(self.mu.hps.n_step_returns and not self.per)
+        nk = {}
+        if self.nstep_ahead:
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self.n_end = torch.zeros(self.K, B, dtype=torch.int64, device=self.dev)
+            self.n_rews, self.n_dones, self.n_len = (torch.zeros(self.K, B, **f32) for _ in range(3))
         self.batches = []
         for k in range(self.K):
             w = self.words[k]
+            if self.nstep_ahead:
+                nk = dict(n_end=self.n_end[k], n_rews=self.n_rews[k], n_dones=self.n_dones[k], n_len=self.n_len[k])
             self.batches.append(ops.make_batch(
                 B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
                 obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
@@ -168,7 +179,7 @@ class UpdateStepDriver(object):
                 e_start=w[2 * B:2 * B + 1], ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
                 label_smoothing=self.label_mode, num_entries=rb.num_entries,
                 d_rms_sums=r.sums if r else None,
-                d_rms_addvec=self.addvecs[k] if r else None))
+                d_rms_addvec=self.addvecs[k] if r else None, **nk))
         self.batch = self.batches[0]
 
     # ------------------------------------------------------------------ device segments
@@ -189,6 +200,15 @@ class UpdateStepDriver(object):
             rb = self.mu.replay_buffer
             ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], self.B,
                                   self.pool.obs0, self.addvecs[:K])
+
+    def _seg_lookahead(self, K):
+        """The n-step lookahead of all K rows of the launch (rows without an agent update carry index
+        words 0 and their results are not used)."""
+        if self.nstep_ahead:
+            rb, hp = self.mu.replay_buffer, self.mu.hps
+            ops.nstep_lookahead_many(rb.store, self._batch_start, self._batch_entries, self.words[:K], self.B,
+                                     self.B, hp.n, hp.gamma, self.n_end[:K], self.n_rews[:K], self.n_dones[:K],
+                                     self.n_len[:K])
 
     def _masks(self, role):
         """(part bits, apply-mode bits) that leave out the roles a row does not carry (samx.h)."""
@@ -279,6 +299,7 @@ class UpdateStepDriver(object):
                 else:
                     if any_d:
                         self._seg_sums(K)
+                    self._seg_lookahead(K)
                     for k in range(K):
                         self._seg_inputs(k, roles[k])
                         self._seg_grads(k, roles[k])
@@ -290,6 +311,7 @@ class UpdateStepDriver(object):
                 if self.inline_stats and any_d:
                     self._seg_sums(K)
                     ar(self.addvecs[:K])
+                self._seg_lookahead(K)
                 for k in range(K):
                     self._seg_grads(k, roles[k])
                     ar(self._grads_of(roles[k]))
@@ -303,7 +325,8 @@ class UpdateStepDriver(object):
                 plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
             # the optimiser pass of row k and the gradient pass of row k + 1 share one graph: per
             # row the host issues ONE graph launch and ONE all-reduce
-            plan += [self._capture(lambda: self._seg_grads(0, roles[0])), lambda: ar(self._grads_of(roles[0]))]
+            plan += [self._capture(lambda: (self._seg_lookahead(K), self._seg_grads(0, roles[0]))),
+                     lambda: ar(self._grads_of(roles[0]))]
             for k in range(1, K):
                 plan += [self._capture(lambda k=k: (self._seg_apply(roles[k - 1]), self._seg_grads(k, roles[k]))),
                          lambda k=k: ar(self._grads_of(roles[k]))]
@@ -312,7 +335,7 @@ class UpdateStepDriver(object):
         assert K == 1
         # N > 1, layer-wise path: one row per launch, three segments
         role = roles[0]
-        plan = [self._capture(lambda: self._seg_inputs(0, role))]
+        plan = [self._capture(lambda: (self._seg_lookahead(1), self._seg_inputs(0, role)))]
         if d.hps.rmsify_obs and role & self.D:
             plan.append(lambda: ar(d.obs_rms.addvec))
         plan += [self._capture(lambda: self._seg_grads(0, role)), lambda: ar(self._grads_of(role)),

@@ -395,6 +395,22 @@ def nstep_lookahead(store, start, num_entries, idxs, n, gamma, want64=False):
     return (end, rews, dones, tl, r64) if want64 else (end, rews, dones, tl)
 
 
+def nstep_lookahead_many(store, start, num_entries, words, a_off, B, n, gamma, end, rews, dones, tl):
+    """RB.lookahead for the K batches of a launch at once: batch k's indices are words[k, a_off:a_off+B];
+    outputs are the caller's dense [K, B] tensors (end int64, rews / dones / tl float32)."""
+    K, W = words.shape
+    _chk(words, I64, (K, W), 'words')
+    assert 0 <= a_off and a_off + B <= W
+    maxlen = store['rews'].shape[0]
+    _chk(store['rews'], F32, (maxlen, 1), 'rews'); _chk(store['dones1'], F32, (maxlen, 1), 'dones1')
+    _chk(end, I64, (K, B), 'end')
+    for t, nm in ((rews, 'rews'), (dones, 'dones'), (tl, 'tl')):
+        _chk(t, F32, (K, B), nm)
+    check(_L().samx_nstep_lookahead_many(ptr(store['rews']), ptr(store['dones1']), maxlen, int(start),
+                                         int(num_entries), words.data_ptr() + 8 * a_off, W, K, B, int(n),
+                                         float(gamma), ptr(end), ptr(rews), ptr(dones), ptr(tl), stream_ptr()))
+
+
 def disc_grad(dd, pd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real, fake, mean, std, ent_scale, ws,
               losses=None, grad=None):
     B, ob = p_obs.shape
@@ -477,8 +493,8 @@ class LearnerState(object):
 
 
 _BATCH_F32 = ('p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
-              'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len')
-_BATCH_I64 = ('p_idx', 'a_idx', 'e_start')
+              'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'n_rews', 'n_dones', 'n_len')
+_BATCH_I64 = ('p_idx', 'a_idx', 'e_start', 'n_end')
 _BATCH_F64 = ('d_rms_sums', 'd_rms_addvec')
 _BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing', 'num_entries')
 

@@ -206,3 +206,33 @@ def test_nstep_lookahead_kernel_matches_reference(name):
     assert np.array_equal(tl.cpu().numpy(), g['la_td_len'].ravel().astype(np.float32))
     got = rb.batchify_device(end, want=('obs1',))['obs1'].cpu().numpy()
     assert np.array_equal(got, g['la_obs1'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['replay_nstep_a', 'replay_nstep_wrap'])
+def test_nstep_lookahead_many_matches_single(name):
+    """samx_nstep_lookahead_many (K batches whose indices sit inside wider index words) gives, batch by
+    batch, exactly what samx_nstep_lookahead gives — which the test above pins on the reference's vectors."""
+    import os
+    import torch
+    from sam_tf_amd import memory as XP, ops
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = np.load(os.path.join(gdir, name + '.npz'))
+    rb = XP.RB(int(g['limit']), (int(g['ob']),), (int(g['ac']),))
+    for i in range(len(g['in_rews'])):
+        rb.append(g['in_obs0'][i], g['in_acs'][i], g['in_rews'][i], g['in_obs1'][i], g['in_dones1'][i])
+    K, B, off = 5, 37, 11
+    W = off + B + 3
+    rng = np.random.RandomState(5)
+    words = rng.randint(0, rb.num_entries, size=(K, W)).astype(np.int64)
+    words[0, off:off + min(B, len(g['idxs']))] = g['idxs'].ravel()[:B]
+    wd = torch.as_tensor(words).cuda()
+    end = torch.zeros(K, B, dtype=torch.int64, device='cuda')
+    rews, dones, tl = (torch.zeros(K, B, dtype=torch.float32, device='cuda') for _ in range(3))
+    ops.nstep_lookahead_many(rb.store, rb.start, rb.num_entries, wd, off, B, int(g['n']), float(g['gamma']), end,
+                             rews, dones, tl)
+    for k in range(K):
+        e1, r1, d1, t1 = ops.nstep_lookahead(rb.store, rb.start, rb.num_entries, wd[k, off:off + B].contiguous(),
+                                             int(g['n']), float(g['gamma']))
+        assert torch.equal(end[k], e1) and torch.equal(rews[k], r1) and torch.equal(dones[k], d1) \
+            and torch.equal(tl[k], t1)
