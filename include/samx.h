@@ -362,6 +362,10 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
      * exactly these B indices); all NULL = samx_step_grads runs the lookahead itself */
     const int64_t* n_end;
     const float *n_rews, *n_dones, *n_len;
+    /* Return normalisation with PopArt under N processes (samx_step_grads_part bits 4/5): double[6] =
+     * [sum, sum of squares, count] of the batch's 1-step targets, then of its n-step targets (zeros when
+     * off) — what helpers/mpi_running_mean_std.py:47-59 all-reduces.  NULL otherwise. */
+    double* ret_addvec;
 } samx_batch;
 
 typedef struct samx_step_out {
@@ -429,7 +433,14 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
  * Role subsets (the reference runs d_steps discriminator updates, then g_steps agent updates per training
  * step, sam.py:323-433; launcher: 1 and 3): part bit 2 (value 4) leaves the discriminator role out, bit 3
  * (value 8) the agent roles; the optimiser segments, losses, statistics commit and step counters of the
- * role left out are not touched.  Pass the same subset to samx_step_apply (mode bits 3 and 4). */
+ * role left out are not touched.  Pass the same subset to samx_step_apply (mode bits 3 and 4).
+ * Return normalisation with PopArt under N processes: ret_rms.update all-reduces the batch sums of the
+ * targets BETWEEN the target pass and the PopArt rescale (sam_agent.py:662-672,
+ * helpers/mpi_running_mean_std.py:47-59), so the call splits there: part bit 4 (value 16, with bit 0) runs
+ * only [lookahead ->] targets -> batch sums into batch.ret_addvec and returns; after the caller's
+ * all-reduce(SUM) of ret_addvec, part bit 5 (value 32) resumes: commit of ret_addvec, PopArt, then the
+ * loss/gradient passes as usual against out.targ_q (/ targ_q_n) of the first call.  Same learner, batch,
+ * out and workspace in both calls. */
 int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const samx_step_out* out,
                          void* ws, size_t ws_bytes, int part, void* stream);
 

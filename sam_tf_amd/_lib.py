@@ -48,7 +48,7 @@ class Batch(C.Structure):
                 [('ring_start', C.c_int64), ('ring_len', C.c_int64), ('rng_seed', C.c_uint64),
                  ('label_smoothing', C.c_int32), ('d_rms_sums', C.c_void_p), ('d_rms_addvec', C.c_void_p),
                  ('num_entries', C.c_int64), ('n_end', C.c_void_p), ('n_rews', C.c_void_p),
-                 ('n_dones', C.c_void_p), ('n_len', C.c_void_p)])
+                 ('n_dones', C.c_void_p), ('n_len', C.c_void_p), ('ret_addvec', C.c_void_p)])
 
 
 class StepOut(C.Structure):

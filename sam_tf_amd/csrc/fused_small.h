@@ -139,7 +139,8 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
 int launch_targets(const AgentArgs* a, hipStream_t st);
 // ret_rms.update(tq [, tqn]) + PopArt rescale of the critic heads (sam_agent.py:554-590,662-672), one launch
 int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
-                      int popart, float* critic, float* targ_critic, int critic_in, hipStream_t st);
+                      int popart, float* critic, float* targ_critic, int critic_in, int phase, double* addvec,
+                      hipStream_t st);   // phase 1: batch sums -> addvec[6] only; 2: commit addvec; 0: both
 constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,

@@ -1058,11 +1058,16 @@ __global__ __launch_bounds__(NT) void step_kernel(StepArgs s) {
 __global__ __launch_bounds__(256) void ret_popart_kernel(const float* __restrict__ tq, const float* __restrict__ tqn,
                                                          int64_t B, double* __restrict__ sums, float* mean,
                                                          float* stdv, int popart, float* w3a, float* b3a,
-                                                         float* w3b, float* b3b) {
+                                                         float* w3b, float* b3b, int phase,
+                                                         double* __restrict__ addvec) {
+    // phase 0: everything (one process).  N processes (mpi_running_mean_std.py:47-59 all-reduces the batch
+    // sums): phase 1 = the batch sums only -> addvec[6] = [sum, sumsq, n | the same for the n-step targets];
+    // phase 2 = commit the (all-reduced) addvec and rescale.
     __shared__ double sh[4][256];
     __shared__ float shf[4];
     const int tid = threadIdx.x;
     double a1 = 0.0, q1 = 0.0, a2 = 0.0, q2 = 0.0;
+    if (phase != 2)
     for (int64_t i = tid; i < B; i += 256) {
         const double x = (double)tq[i];
         a1 = __dadd_rn(a1, x); q1 = __dadd_rn(q1, __dmul_rn(x, x));
@@ -1079,12 +1084,21 @@ __global__ __launch_bounds__(256) void ret_popart_kernel(const float* __restrict
             for (int k = 0; k < 4; ++k) sh[k][tid] = __dadd_rn(sh[k][tid], sh[k][tid + s]);
         __syncthreads();
     }
+    if (phase == 1) {
+        if (tid == 0) {
+            addvec[0] = sh[0][0]; addvec[1] = sh[1][0]; addvec[2] = (double)B;
+            addvec[3] = sh[2][0]; addvec[4] = sh[3][0]; addvec[5] = tqn ? (double)B : 0.0;
+        }
+        return;
+    }
     if (tid == 0) {
         shf[0] = mean[0];
         shf[1] = stdv[0];
         double s0 = sums[0], s1 = sums[1], s2 = sums[2];
-        s0 = __dadd_rn(s0, sh[0][0]); s1 = __dadd_rn(s1, sh[1][0]); s2 = __dadd_rn(s2, (double)B);
-        if (tqn) { s0 = __dadd_rn(s0, sh[2][0]); s1 = __dadd_rn(s1, sh[3][0]); s2 = __dadd_rn(s2, (double)B); }
+        double t0 = sh[0][0], t1 = sh[1][0], t2 = (double)B, u0 = sh[2][0], u1 = sh[3][0], u2 = (double)B;
+        if (phase == 2) { t0 = addvec[0]; t1 = addvec[1]; t2 = addvec[2]; u0 = addvec[3]; u1 = addvec[4]; u2 = addvec[5]; }
+        s0 = __dadd_rn(s0, t0); s1 = __dadd_rn(s1, t1); s2 = __dadd_rn(s2, t2);
+        if (tqn) { s0 = __dadd_rn(s0, u0); s1 = __dadd_rn(s1, u1); s2 = __dadd_rn(s2, u2); }
         sums[0] = s0; sums[1] = s1; sums[2] = s2;
         const float m = (float)(s0 / s2), msq = (float)(s1 / s2);
         const float sd = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(m, m)), 1e-2f));
@@ -1408,10 +1422,12 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
 }
 
 int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
-                      int popart, float* critic, float* targ_critic, int critic_in, hipStream_t st) {
+                      int popart, float* critic, float* targ_critic, int critic_in, int phase, double* addvec,
+                      hipStream_t st) {
     const int64_t oW3 = (int64_t)critic_in * H + H + H * H + H, ob3 = oW3 + H;   // 64x64 net, 1 output
+    SAMX_REQUIRE(phase == 0 || addvec, "launch_ret_popart: phase %d needs addvec", phase);
     ret_popart_kernel<<<1, 256, 0, st>>>(tq, tqn, B, sums, mean, stdv, popart, critic + oW3, critic + ob3,
-                                         targ_critic + oW3, targ_critic + ob3);
+                                         targ_critic + oW3, targ_critic + ob3, phase, addvec);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -548,9 +548,17 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
 int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                          size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
-    SAMX_REQUIRE((part & ~15) == 0 && (part & 3) != 0 && (part & 12) != 12,
-                 "samx_step_grads_part: part uses bits 0-3, needs bit 0 or 1, and cannot skip both roles");
+    SAMX_REQUIRE((part & ~63) == 0 && (part & 3) != 0 && (part & 12) != 12,
+                 "samx_step_grads_part: part uses bits 0-5, needs bit 0 or 1, and cannot skip both roles");
     const bool do_d = !(part & 4), do_a = !(part & 8);   // roles of this call
+    const bool t_only = part & 16, t_done = part & 32;   // PopArt with N processes: the call split at the all-reduce
+    if (t_only || t_done) {
+        SAMX_REQUIRE(!(t_only && t_done) && (part & 1) && do_a,
+                     "samx_step_grads_part: bits 4 and 5 exclude each other and need bit 0 and the agent roles");
+        SAMX_REQUIRE(L->ret_mean && L->enable_popart && b && b->ret_addvec,
+                     "samx_step_grads_part: bits 4/5 are for return normalisation with PopArt and need "
+                     "batch.ret_addvec");
+    }
     const int segs = (do_a ? 3 : 0) | (do_d ? 4 : 0);
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(b && o && ws, "samx_step_grads: null argument");
@@ -616,7 +624,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (serial < 0) { const char* e = getenv("SAMX_SERIAL_ROLES"); serial = e ? atoi(e) : 0; }
         hipStream_t s_tc = st, s_a = st;
         SideStreams* ss = nullptr;
-        if (!serial && do_a) {
+        if (!serial && do_a && !t_only) {
             rc = side_streams(&ss);
             if (rc != SAMX_OK) return rc;
             SAMX_CHECK_HIP(hipEventRecord(ss->fork, st));
@@ -625,25 +633,25 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             s_tc = ss->s[0];
             s_a = ss->s[1];
         }
-        if (b->d_rms_sums && do_d) {  // d.obs_rms.update on this row's D batch (sam.py:389-390), committed
+        if (b->d_rms_sums && do_d && !t_only) {  // d.obs_rms.update on this row's D batch (sam.py:389-390), committed
             rc = samx_d_input_stats(b->p_obs, b->ring_start, b->ring_len, b->p_idx, b->e_obs, b->e_start, B, ob,
                                     const_cast<double*>(b->d_rms_addvec), 1, b->d_rms_sums,
                                     const_cast<float*>(L->d_mean), const_cast<float*>(L->d_std), w.stats_ws,
                                     w.stats_bytes, stream);
             if (rc != SAMX_OK) return rc;
         }
-        if (b->p_idx && do_d) {
+        if (b->p_idx && do_d && !t_only) {
             rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
                                     ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
             if (rc != SAMX_OK) return rc;
             dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
         }
-        if (b->e_start && do_d) {
+        if (b->e_start && do_d && !t_only) {
             expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
             SAMX_LAUNCH_CHECK();
             dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
         }
-        if (!b->eps_ob && do_d) {
+        if (!b->eps_ob && do_d && !t_only) {
             const int64_t n = B * (ob + ac + 2);
             randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
                 b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
@@ -662,6 +670,10 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         const int64_t* nl_end = w.n_end;
         const float *nl_rews = w.n_rews, *nl_dones = w.n_dones, *nl_len = w.n_len;
         if (do_a) {
+        double* add1 = orig->ret_addvec ? orig->ret_addvec : w.ret_add1;
+        double* add2 = orig->ret_addvec ? orig->ret_addvec + 3 : w.ret_add2;
+        if (L->n_step > 0) tcns = o->targ_q_n ? o->targ_q_n : w.n_tq;
+        if (!t_done) {
         if (L->n_step > 0) {  // n-step lookahead from the sampled indices (memory.py:113-160)
             SAMX_REQUIRE(orig->a_idx && orig->num_entries > 0,
                          "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
@@ -682,20 +694,23 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                          (void*)s_tc);
         if (rc != SAMX_OK) return rc;
         if (L->n_step > 0) {
-            float* tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
             rc = samx_targ_q(&L->actor, ta, &L->critic, tc, w.n_obs1, nl_rews, nl_dones, nl_len, L->mu_mean,
-                             L->mu_std, B, L->gamma, L->ac_high, tqn, ret, w.nets_ws, w.nets_bytes, (void*)s_tc);
+                             L->mu_std, B, L->gamma, L->ac_high, const_cast<float*>(tcns), ret, w.nets_ws,
+                             w.nets_bytes, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
-            tcns = tqn;
         }
-        if (popart_or_stats) {  // ret_rms.update(targ_q_1 [, targ_q_n]) then PopArt (sam_agent.py:662-672)
-            rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, (void*)s_tc);
+        if (popart_or_stats) {  // batch sums of ret_rms.update(targ_q_1 [, targ_q_n]) (sam_agent.py:662-665)
+            rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, add1, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
             if (tcns) {
-                rc = samx_rms_batch_sums(tcns, B, nullptr, 0, 1, w.ret_add2, (void*)s_tc);
+                rc = samx_rms_batch_sums(tcns, B, nullptr, 0, 1, add2, (void*)s_tc);
                 if (rc != SAMX_OK) return rc;
             }
-            rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, tcns ? w.ret_add2 : nullptr, L->ret_mean,
+        }
+        }  // !t_done
+        if (t_only) return SAMX_OK;   // (bits 4/5 run on the caller's stream: s_tc == st)
+        if (popart_or_stats) {  // commit + PopArt (sam_agent.py:662-672)
+            rc = samx_ret_update_popart(L->ret_sums, add1, tcns ? add2 : nullptr, L->ret_mean,
                                         L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, (void*)s_tc);
             if (rc != SAMX_OK) return rc;
             if (ss) {  // the actor role reads the rescaled critic head and the new statistics
@@ -766,8 +781,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     if ((part & 1) && do_a && ext) {
         // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
         // ret_rms.update + PopArt -> losses with the new ones
-        float* tqn = nullptr;
-        if (L->n_step > 0) {
+        float* tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;
+        if (L->n_step > 0 && !t_done) {
             SAMX_REQUIRE(b->a_idx && b->num_entries > 0,
                          "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
             if (b->n_end) {   // done ahead by the caller (samx_nstep_lookahead_many)
@@ -779,16 +794,19 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                 if (rc != SAMX_OK) return rc;
                 a.n_idx = w.n_end; a.n_rews = w.n_rews; a.n_dones = w.n_dones; a.n_len = w.n_len;
             }
-            tqn = o->targ_q_n ? o->targ_q_n : w.n_tq;
             a.targ_qn_out = tqn;
         }
-        rc = fused::launch_targets(&a, st);
-        if (rc != SAMX_OK) return rc;
-        if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
-            rc = fused::launch_ret_popart(o->targ_q, tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
-                                          L->params + Pa, L->targets + Pa, L->critic.in_dim, st);
+        if (!t_done) {
+            rc = fused::launch_targets(&a, st);
             if (rc != SAMX_OK) return rc;
         }
+        if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
+            rc = fused::launch_ret_popart(o->targ_q, tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
+                                          L->params + Pa, L->targets + Pa, L->critic.in_dim,
+                                          t_only ? 1 : (t_done ? 2 : 0), b->ret_addvec, st);
+            if (rc != SAMX_OK) return rc;
+        }
+        if (t_only) return SAMX_OK;
         a.ext_tq = o->targ_q; a.ext_tqn = tqn;
     } else if (ext) {
         a.ext_tq = o->targ_q; a.ext_tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;

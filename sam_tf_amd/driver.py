@@ -97,9 +97,11 @@ class UpdateStepDriver(object):
         self.collectives_in_graph = bool(self.world > 1 and self.fused and self.use_graph and
                                          getattr(self.comm, 'capturable', False) and
                                          os.environ.get('SAMX_RCCL_GRAPH', '1') != '0')
-        if self.world > 1 and mu.hps.rmsify_rets and mu.hps.enable_popart:
-            raise NotImplementedError('PopArt inside the fused step needs an all-reduce of the return sums '
-                                      'between target and loss passes: use SAMAgent.train() for N > 1')
+        # N > 1 with return normalisation + PopArt: ret_rms.update all-reduces the targets' batch sums between
+        # the target pass and the PopArt rescale (sam_agent.py:662-672, mpi_running_mean_std.py:47-59): the
+        # row's gradient call splits there (samx_step_grads_part bits 4/5)
+        self.popart_split = bool(self.world > 1 and mu.hps.rmsify_rets and mu.hps.enable_popart)
+        self.ret_addvec = torch.zeros(6, dtype=torch.float64, device=dev) if self.popart_split else None
         f32 = dict(dtype=torch.float32, device=dev)
         rb = mu.replay_buffer
         assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
@@ -179,7 +181,7 @@ class UpdateStepDriver(object):
                 e_start=w[2 * B:2 * B + 1], ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
                 label_smoothing=self.label_mode, num_entries=rb.num_entries,
                 d_rms_sums=r.sums if r else None,
-                d_rms_addvec=self.addvecs[k] if r else None, **nk))
+                d_rms_addvec=self.addvecs[k] if r else None, ret_addvec=self.ret_addvec, **nk))
         self.batch = self.batches[0]
 
     # ------------------------------------------------------------------ device segments
@@ -224,14 +226,20 @@ class UpdateStepDriver(object):
                                               idxs_out=self.idx_a, iws_out=self.iws,
                                               iws32_out=self.iws32)
 
+    def _seg_targets(self, k=0, role=3):
+        """N > 1 with PopArt: [PER sampling,] the target pass and the local return sums -> ret_addvec."""
+        self._seg_trees(role)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 16 | self._masks(role)[0])
+
     def _seg_grads(self, k=0, role=3, trees_done=False):
         mu, d = self.mu, self.d
         part, mode = self._masks(role)
         if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats and role & self.D:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
-        if not trees_done:
+        split = self.popart_split and role & self.A   # _seg_targets + all-reduce(ret_addvec) came before
+        if not trees_done and not split:
             self._seg_trees(role)
-        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0))
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
         ops.step_apply(self.L, self.B, (3 if self.world == 1 else 1) | mode, 1.0)
         if self.world == 1:
@@ -306,40 +314,44 @@ class UpdateStepDriver(object):
                 if self.per_graph_io and roles[0] & self.A:   # TD errors + sampled indices -> pinned host
                     ops.to_host_pair(self.td_post, self._td_host, self.idx_a, self._idx_host)
             return [self._capture(run)]
-        if self.collectives_in_graph:
-            def run():
-                if self.inline_stats and any_d:
-                    self._seg_sums(K)
-                    ar(self.addvecs[:K])
-                self._seg_lookahead(K)
-                for k in range(K):
-                    self._seg_grads(k, roles[k])
-                    ar(self._grads_of(roles[k]))
-                    self._seg_apply(roles[k])
-            return [self._capture(run)]
-        if self.inline_stats or (self.fused and not d.hps.rmsify_obs):
-            # N > 1, fused path: [sums of K rows] -> ONE all-reduce of the K float64 sum vectors ->
-            # per row: gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
-            plan = []
-            if self.inline_stats and any_d:
-                plan = [self._capture(lambda: self._seg_sums(K)), lambda: ar(self.addvecs[:K])]
-            # the optimiser pass of row k and the gradient pass of row k + 1 share one graph: per
-            # row the host issues ONE graph launch and ONE all-reduce
-            plan += [self._capture(lambda: (self._seg_lookahead(K), self._seg_grads(0, roles[0]))),
-                     lambda: ar(self._grads_of(roles[0]))]
-            for k in range(1, K):
-                plan += [self._capture(lambda k=k: (self._seg_apply(roles[k - 1]), self._seg_grads(k, roles[k]))),
-                         lambda k=k: ar(self._grads_of(roles[k]))]
-            plan.append(self._capture(lambda: self._seg_apply(roles[K - 1])))
-            return plan
-        assert K == 1
-        # N > 1, layer-wise path: one row per launch, three segments
-        role = roles[0]
-        plan = [self._capture(lambda: (self._seg_lookahead(1), self._seg_inputs(0, role)))]
-        if d.hps.rmsify_obs and role & self.D:
-            plan.append(lambda: ar(d.obs_rms.addvec))
-        plan += [self._capture(lambda: self._seg_grads(0, role)), lambda: ar(self._grads_of(role)),
-                 self._capture(lambda: self._seg_apply(role))]
+        # N > 1: the launch as a list of device segments and collectives in execution order
+        #   [D-input sums of the K rows -> all-reduce of the K float64 sum vectors]   (fused path)
+        #   [n-step lookahead of the K rows]
+        #   per row: [statistics -> all-reduce]                                      (layer-wise path)
+        #            [targets + local return sums -> all-reduce]                     (PopArt)
+        #            gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
+        assert self.fused or K == 1
+        fused_stats = self.inline_stats or (self.fused and not d.hps.rmsify_obs)
+        items = []
+        if self.inline_stats and any_d:
+            items += [('dev', lambda: self._seg_sums(K)), ('ar', lambda: ar(self.addvecs[:K]))]
+        items.append(('dev', lambda: self._seg_lookahead(K)))
+        for k in range(K):
+            role = roles[k]
+            if not fused_stats:
+                items.append(('dev', lambda k=k, role=role: self._seg_inputs(k, role)))
+                if d.hps.rmsify_obs and role & self.D:
+                    items.append(('ar', lambda: ar(d.obs_rms.addvec)))
+            if self.popart_split and role & self.A:
+                items += [('dev', lambda k=k, role=role: self._seg_targets(k, role)),
+                          ('ar', lambda: ar(self.ret_addvec))]
+            items += [('dev', lambda k=k, role=role: self._seg_grads(k, role)),
+                      ('ar', lambda role=role: ar(self._grads_of(role))),
+                      ('dev', lambda role=role: self._seg_apply(role))]
+        if self.collectives_in_graph:   # collectives on the caller's stream: ONE graph for the launch
+            return [self._capture(lambda: [f() for _, f in items])]
+        # host-issued collectives: consecutive device segments share one graph (the optimiser pass of row
+        # k and the gradient pass of row k + 1: per row the host issues ONE graph launch per collective)
+        plan, run = [], []
+        for kind, f in items + [('ar', None)]:
+            if kind == 'dev':
+                run.append(f)
+                continue
+            if run:
+                plan.append(self._capture(lambda fs=tuple(run): [g() for g in fs]))
+                run = []
+            if f is not None:
+                plan.append(f)
         return plan
 
     # ------------------------------------------------------------------ host side of a step

@@ -495,7 +495,7 @@ class LearnerState(object):
 _BATCH_F32 = ('p_obs', 'p_acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real_labels', 'fake_labels', 'obs0',
               'acs', 'rews', 'dones1', 'obs1', 'iws', 'td_len', 'n_rews', 'n_dones', 'n_len')
 _BATCH_I64 = ('p_idx', 'a_idx', 'e_start', 'n_end')
-_BATCH_F64 = ('d_rms_sums', 'd_rms_addvec')
+_BATCH_F64 = ('d_rms_sums', 'd_rms_addvec', 'ret_addvec')
 _BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing', 'num_entries')
 
 

@@ -107,9 +107,12 @@ class OracleLearner(object):
             tqn = NO.targ_q(self.pa_t, self.pc_t, self.da, self.dc, la['obs1'], la['rews'].astype(np.float32),
                             la['dones1'], la['td_len'].astype(np.float64), mean, std, hp.gamma, 1.0, ret=ret)
         if hp.rmsify_rets and hp.enable_popart:  # sam_agent.py:662-672 (targets enter as float32)
-            self.ret_sums = NO.rms_update(self.ret_sums, tq.astype(np.float32), 1)
+            # every rank contributes its targets (identical replicas); mpi_running_mean_std.py:47-59
+            for _ in range(self.world):
+                self.ret_sums = NO.rms_update(self.ret_sums, tq.astype(np.float32), 1)
             if tqn is not None:
-                self.ret_sums = NO.rms_update(self.ret_sums, tqn.astype(np.float32), 1)
+                for _ in range(self.world):
+                    self.ret_sums = NO.rms_update(self.ret_sums, tqn.astype(np.float32), 1)
             nm, ns = NO.rms_mean_std(self.ret_sums, 1)
             new = (float(nm[0]), float(ns[0]))
             sl = NO.param_slices(self.dc)
@@ -494,16 +497,21 @@ class _TwinComm(object):
         pass
 
 
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'ragged'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'ragged', 'C1-retn', 'C3-ret', 'ragged-retn', 'C1-launcher'])
 def test_two_rank_plan_matches_oracle(cfg_name):
+    """-ret / -retn / -launcher: return normalisation + PopArt under N > 1 — the targets' batch sums are
+    all-reduced between the target pass and the PopArt rescale (samx_step_grads_part bits 4/5)."""
     import bench
-    if cfg_name == 'ragged':  # not fusable: the layer-wise path under the N > 1 plan
+    base, _, opt = cfg_name.partition('-')
+    if base == 'ragged':  # not fusable: the layer-wise path under the N > 1 plan
         cfg = dict(ob=5, ac=2, h=(33, 70), B=37, per=False, mem=2048, name='ragged')
     else:
-        cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+        cfg = dict(bench.CONFIGS[base], mem=2048)
+    cfg.update(ln=opt == 'launcher', ret=bool(opt), nstep=7 if opt in ('retn', 'launcher') else 0, p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
-    assert drv.world == 2 and drv.inline_stats == (cfg_name != 'ragged')
-    assert drv.K == (16 if cfg_name == 'C1' else 1)   # uniform replay on the fused path packs K steps
+    fusable = base != 'ragged' and opt != 'launcher'
+    assert drv.world == 2 and drv.inline_stats == fusable and drv.popart_split == bool(opt)
+    assert drv.K == (16 if base == 'C1' and fusable else 1)   # uniform replay on the fused path packs K steps
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
     K = 4
@@ -518,16 +526,20 @@ def test_two_rank_plan_matches_oracle(cfg_name):
         o = drv.outputs()
         for name in ('d_losses', 'actor_losses', 'critic_losses'):
             got, exp = h(o[name]).astype(np.float64), out[name]
-            assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-5, (name, k, got, exp)
+            floor = 1.0 if opt and name == 'actor_losses' else 1e-3   # see test_k_steps_match_oracle
+            assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), floor)) < 1e-5, (name, k, got, exp)
     assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
     assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
     assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
     assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
+    if opt:
+        assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
+        assert abs(mu.ret_rms.sums[2].item() - ref.ret_sums[2]) < 1e-9   # counts: 2 ranks x B x (1 or 2) per step
 
 
-@pytest.mark.parametrize('g_steps', [1, 3])
-def test_two_rank_packed_launch_equals_single_steps(g_steps):
+@pytest.mark.parametrize('g_steps,retn', [(1, False), (3, False), (1, True), (3, True)])
+def test_two_rank_packed_launch_equals_single_steps(g_steps, retn):
     """N > 1, fused path: K rows per host iteration (one all-reduce of the K D-input sum vectors, then
     one gradient all-reduce per row — of the segments the row's roles fill) leave the learner
     bit-identical to single-row launches; also with the launcher's 1:3 schedule."""
@@ -535,6 +547,8 @@ def test_two_rank_packed_launch_equals_single_steps(g_steps):
     import bench
     from sam_tf_amd.driver import UpdateStepDriver
     cfg = dict(bench.CONFIGS['C1'], mem=4096)
+    if retn:   # + return normalisation, PopArt (one more all-reduce per agent row) and n-step returns
+        cfg.update(ret=True, nstep=7, p_done=0.1)
     states = []
     for mode in ('single', 'packed'):
         mu, d, pool, _ = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 5, True)
@@ -543,7 +557,7 @@ def test_two_rank_packed_launch_equals_single_steps(g_steps):
         assert drv.K == (4 if g_steps == 1 else 6) and drv.world == 2
         drv.prepare_all()
         if g_steps == 1:
-            assert len(drv.plans[(4, 0)]) == 2 + 2 * 4 + 1
+            assert len(drv.plans[(4, 0)]) == 2 + (4 if retn else 2) * 4 + 1
         np.random.seed(78); random.seed(78)
         pool.pointer = 0
         n = 9 if g_steps == 1 else 15
@@ -554,7 +568,8 @@ def test_two_rank_packed_launch_equals_single_steps(g_steps):
             drv.run(n)   # 4 + 4 + 1  /  6 + 6 + 3
         torch.cuda.synchronize()
         states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
-                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
+                                           d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std] +
+                       ([mu.ret_rms.sums, mu.ret_rms.mean, mu.ret_rms.std] if retn else [])])
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
 
@@ -576,17 +591,21 @@ def test_in_graph_rccl_collectives_equal_host_issued():
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
                             device_id=dev)
     try:
+      # second pass: + return normalisation / PopArt / n-step (the all-reduce of the return sums in the graph)
+      for retn in (False, True):
         cfg = dict(bench.CONFIGS['C1'], mem=4096)
+        if retn:
+            cfg.update(ret=True, nstep=7, p_done=0.1)
         states = []
         for mode in ('single', 'host', 'graph'):
             comm = TwinOverRccl(dev, True)
             assert comm.capturable
             mu, d, pool, _ = bench.build_learner(cfg, comm, dev, 5, True)
             drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
-            assert drv.collectives_in_graph and drv.K == 4
+            assert drv.collectives_in_graph and drv.K == 4 and drv.popart_split == retn
             assert drv.set_collectives(mode == 'graph') == (mode == 'graph')
             drv.prepare(1); drv.prepare(4)
-            assert len(drv.plans[(4, 0)]) == (1 if mode == 'graph' else 2 + 2 * 4 + 1)
+            assert len(drv.plans[(4, 0)]) == (1 if mode == 'graph' else 2 + (4 if retn else 2) * 4 + 1)
             np.random.seed(79); random.seed(79)
             pool.pointer = 0
             if mode == 'single':
@@ -596,7 +615,8 @@ def test_in_graph_rccl_collectives_equal_host_issued():
                 drv.run(9)
             torch.cuda.synchronize()
             states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
-                                               d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]])
+                                               d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std] +
+                           ([mu.ret_rms.sums, mu.ret_rms.mean, mu.ret_rms.std] if retn else [])])
             comm.direct.destroy()
         for other in states[1:]:
             for a, b in zip(states[0], other):
