@@ -202,12 +202,10 @@ def main():
         from tools.rehearse_nccl import TwinOverRccl
         dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29617', rank=0, world_size=1,
                                 device_id=device)
-        comm = TwinOverRccl(device, os.environ.get('SAMX_RCCL_DIRECT', '1') != '0')
+        comm = TwinOverRccl(device, False)
         world = 2
     else:
         comm = TorchComm(device)
-        if world > 1 and os.environ.get('SAMX_RCCL_DIRECT', '1') != '0':
-            comm.enable_direct()   # all-reduces on the launch stream through librccl (sam_tf_amd/rccl.py)
     nstep = 96 if args.launcher else (10 if args.argparse_defaults else 0)
     cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher or args.argparse_defaults,
                nstep=nstep if not CONFIGS[args.config]['per'] else 0)
@@ -263,41 +261,58 @@ def main():
                          'pass_us': {k: v * 1e6 for k, v in passes.items()}},
         }
 
-    host_label = 'none' if world == 1 else ('rccl on the launch stream, issued by the host between graph '
-                                            'segments' if comm.capturable else
-                                            'torch.distributed all_reduce between graph segments')
-    want_in_graph = drv.collectives_in_graph
-    # N > 1: first the plan whose collectives the host issues between graph segments ...
+    # N > 1: three plans, from the most ordinary to the fastest, each measured over the same K steps; the
+    # line reports the fastest one that completed and carries the others' ms/step in `config`.
+    #   1. torch.distributed all_reduce between graph segments (the process group's own stream);
+    #   2. RCCL called directly on the launch stream (sam_tf_amd/rccl.py), issued by the host between segments;
+    #   3. those RCCL all-reduces captured INSIDE the K-step hipGraph.
+    # No multi-GPU box was available while this was written: plans 2 and 3 run under a watchdog, and if
+    # they do not come back the rank reports the measurement it already has instead of hanging the job.
     drv.set_collectives(False)
     el = timed()
     passes = time_passes(drv, cfg)
-    result = result_for(el, passes, host_label)
-    if want_in_graph:
-        # ... then the plan with the all-reduces captured INSIDE the K-step graph, under a watchdog: no
-        # multi-GPU box was available while this was written, so if that plan does not come back the
-        # rank reports the measurement it already has instead of hanging the job.
-        import threading
+    result = result_for(el, passes, 'none' if world == 1 else 'torch.distributed all_reduce between graph segments')
+    import threading
+    stage = ['']
+
+    def watchdog(seconds, what):
+        """Past `seconds`, rank 0 prints the measurement it has (with a note) and every rank exits."""
+        stage[0] = what
 
         def bail():
             if rank == 0:
-                result['config']['collectives'] += ' (in-graph plan did not complete: watchdog)'
+                result['config']['collectives'] += ' (%s did not complete: watchdog)' % stage[0]
                 print(json.dumps(result), flush=True)
             os._exit(0)
-        dog = threading.Timer(float(os.environ.get('SAMX_BENCH_WATCHDOG_S', '90')), bail)
-        dog.daemon = True
-        dog.start()
+        t = threading.Timer(seconds, bail)
+        t.daemon = True
+        t.start()
+        return t
+
+    if world > 1 and os.environ.get('SAMX_RCCL_DIRECT', '1') != '0':
+        dog = watchdog(float(os.environ.get('SAMX_BENCH_WATCHDOG_S', '120')), 'direct RCCL set-up')
         try:
-            drv.set_collectives(True)
-            el_g = timed()
+            tried = {'torch_distributed': el}
+            if comm.enable_direct():   # all ranks or none
+                stage[0] = 'plan with host-issued direct RCCL'
+                labels = {'host_issued_rccl': 'rccl on the launch stream, issued by the host between graph segments',
+                          'in_graph_rccl': 'rccl all-reduces captured inside the %d-step hipGraph' % drv.K}
+                tried['host_issued_rccl'] = timed()
+                if drv.set_collectives(True):
+                    stage[0] = 'plan with in-graph RCCL'
+                    tried['in_graph_rccl'] = timed()
+                best = min(tried, key=tried.get)
+                if best != 'torch_distributed':
+                    if best != 'in_graph_rccl':
+                        drv.set_collectives(False)
+                    result = result_for(tried[best], passes, labels[best])
+                for k, v in tried.items():
+                    if k != best:
+                        result['config']['ms_per_step_' + k] = v / args.steps * 1e3
             dog.cancel()
-            if el_g < el:
-                result = result_for(el_g, passes, 'rccl all-reduces captured inside the %d-step hipGraph' % drv.K)
-                result['config']['ms_per_step_host_issued_collectives'] = el / args.steps * 1e3
-            else:
-                result['config']['ms_per_step_in_graph_collectives'] = el_g / args.steps * 1e3
         except Exception as e:  # noqa: BLE001 - keep the measurement we have; other ranks' watchdogs end them
             dog.cancel()
-            result['config']['collectives'] += ' (in-graph plan failed: %s)' % (str(e)[:120],)
+            result['config']['collectives'] += ' (%s failed: %s)' % (stage[0], str(e)[:120])
             if rank == 0:
                 print(json.dumps(result), flush=True)
             os._exit(0)
@@ -319,6 +334,7 @@ def main():
         # all-reduce latency vs bucket bytes, back to back on the launch stream (what a
         # step pays in series is the first entry at or above this config's gradient bucket)
         lat = {}
+        dog = watchdog(60.0, 'all-reduce latency sweep')
         for nbytes in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
             buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
             for _ in range(10):
@@ -329,6 +345,7 @@ def main():
                 comm.allreduce_(buf)
             torch.cuda.synchronize()
             lat[str(nbytes)] = (time.perf_counter() - t0) / 50 * 1e6
+        dog.cancel()
         result['config']['allreduce_us_by_bytes'] = lat
         result['config']['grad_bucket_bytes'] = int(mu.L.grads.numel() * 4)
     if rank == 0:
@@ -337,6 +354,9 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
+        bye = threading.Timer(30.0, lambda: os._exit(0))   # the line is out: a stuck teardown must not hold the job
+        bye.daemon = True
+        bye.start()
         if comm.direct is not None:
             comm.direct.destroy()
         dist.destroy_process_group()

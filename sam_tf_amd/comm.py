@@ -32,6 +32,14 @@ class TorchComm(object):
         except Exception as e:  # noqa: BLE001 - any failure means: stay on torch.distributed
             print('sam_tf_amd.comm: direct RCCL unavailable (%s); using torch.distributed' % (e,), flush=True)
             self.direct = None
+        # all ranks or none: a rank that fell back while the others did not would wait in a different
+        # communicator from theirs
+        ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32,
+                          device=self.device if self.device is not None else 'cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and self.direct is not None:
+            self.direct.destroy()
+            self.direct = None
         return self.direct is not None
 
     @property
