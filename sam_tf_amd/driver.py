@@ -28,6 +28,7 @@ keep the reference's order.  `step()` / `run(n)` count rows.
 """
 import random as _random
 
+import gc
 import os
 
 import numpy as np
@@ -277,9 +278,19 @@ class UpdateStepDriver(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        # thread_local: the process group's watchdog thread may touch events while we capture
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            run()
+        # No cyclic garbage collection while capturing: a collected CUDAGraph of an older driver releases
+        # its memory pool (hipFree), which the capturing thread must not call (torch collects once before
+        # the capture for the same reason, but our segments allocate Python objects and can trigger another)
+        was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            # thread_local: the process group's watchdog thread may touch events while we capture
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                run()
+        finally:
+            if was:
+                gc.enable()
         return g.replay
 
     def _build_plan(self, K, phase=0):
