@@ -155,10 +155,25 @@ def cpu_baseline(cfg, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 2000:
             break
-    return {'value': n / el, 'unit': 'steps/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d update steps of the same workload (CPU restatement of the reference in its '
-                      'own call structure: 3 D passes + 8 agent passes per step, fp32 torch, 1 thread, '
-                      'Python replay loops), %.1f s' % (n, el)}
+    out = {'value': n / el, 'unit': 'steps/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d update steps of the same workload (CPU restatement of the reference in its '
+                     'own call structure: 3 D passes + 8 agent passes per step, fp32 torch, 1 thread, '
+                     'Python replay loops), %.1f s' % (n, el)}
+    # the N-thread variant beside it (the reference itself pins one thread per worker,
+    # run_sam.py:18); a short sample, reported next to the 1-core figure, never instead of it
+    nt = min(16, os.cpu_count() or 1)
+    if nt > 1:
+        torch.set_num_threads(nt)
+        ref.step()
+        n2, t0 = 0, time.perf_counter()
+        while True:
+            ref.step(); n2 += 1
+            el2 = time.perf_counter() - t0
+            if el2 > budget_s / 3 or n2 >= 2000:
+                break
+        torch.set_num_threads(1)
+        out['n_thread_variant'] = {'value': n2 / el2, 'cores': nt, 'sample': '%d steps, %.1f s' % (n2, el2)}
+    return out
 
 
 def main():
