@@ -1410,12 +1410,8 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
     if (!(roles & 2)) s.n_tc = 0;
     if (!(roles & 4)) s.n_disc = 0;
     if (s.n_a + s.n_tc + s.n_disc == 0) return SAMX_OK;
-    static size_t attr_set = 0;  // largest dynamic-LDS size already granted
-    if (lds > attr_set) {
-        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)step_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)step_kernel, lds)) return rc;
     step_kernel<<<(unsigned)(s.n_a + s.n_tc + s.n_disc), NT, lds, st>>>(s);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
@@ -1436,12 +1432,8 @@ int launch_targets(const AgentArgs* a, hipStream_t st) {
     const int tiles = (int)(a->B / R);
     const size_t lds = agent_lds_bytes(a->ob, a->ac, false);
     SAMX_REQUIRE(lds <= 150 * 1024, "fused targets kernel needs %zu bytes of LDS", lds);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)targets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
-        attr_set = lds;
-    }
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)targets_kernel, lds)) return rc;
     targets_kernel<<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
@@ -1456,12 +1448,8 @@ int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const 
     a.td_out = td_out; a.ob = ob; a.ac = dc->in_dim - ob; a.idx = idx; a.ring_start = ring_start;
     a.ring_len = ring_len;
     const size_t lds = (net_lds_floats(dc->in_dim, 1) + 3 * R * LD + 16) * sizeof(float);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)td_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
-        attr_set = lds;
-    }
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)td_kernel, lds)) return rc;
     td_kernel<<<(unsigned)(B / R), NT, lds, st>>>(a);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;

@@ -452,12 +452,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
 int launch_inst(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     constexpr size_t lds = (size_t)ring<KS>() * 2 * TILE * sizeof(float);
-    static bool attr_done = false;  // per instantiation; > 64 KB of LDS needs the opt-in
-    if (!attr_done && lds > 64 * 1024) {
-        SAMX_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<A_RC, B_RC, KS, A_W, B_W>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static LdsGrant grant;  // per instantiation and device; > 64 KB of LDS needs the opt-in
+    if (int rc = grant.ensure((const void*)gemm_kernel<A_RC, B_RC, KS, A_W, B_W>, lds, 64 * 1024)) return rc;
     gemm_kernel<A_RC, B_RC, KS, A_W, B_W><<<grid, 256 * KS, lds, stream>>>(g);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;

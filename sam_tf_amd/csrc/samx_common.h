@@ -52,4 +52,20 @@ struct Arena {
     bool ok() const { return dry || off <= cap; }
 };
 
+// Dynamic LDS above 64 KB is an opt-in per kernel AND per device: remember the largest size granted to a
+// kernel on each device (one slot array per call site).
+struct LdsGrant {
+    size_t granted[64] = {0};
+    int ensure(const void* kernel, size_t bytes, size_t floor_bytes = 0) {
+        int dev = 0;
+        SAMX_CHECK_HIP(hipGetDevice(&dev));
+        SAMX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+        if (bytes > granted[dev] && bytes > floor_bytes) {
+            SAMX_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            granted[dev] = bytes;
+        }
+        return SAMX_OK;
+    }
+};
+
 }  // namespace samx
