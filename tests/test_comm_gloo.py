@@ -50,6 +50,19 @@ def _worker(rank, world, port, out):
         rows = np.concatenate([np.random.RandomState(100 + r).randn(5185 + (33 + r) * ob)[5185:].reshape(-1, ob)
                                .astype(np.float32) for r in range(world)])
         np.testing.assert_allclose(tot.numpy(), NO.rms_update(np.zeros(2 * ob + 1), rows, ob), rtol=1e-12)
+        # --- return normalisation + PopArt: the 6-double exchange of samx_step_grads_part bits 4/5
+        # ([sum, sumsq, n] of the 1-step targets | of the n-step targets), mpi_running_mean_std.py:47-59
+        tq = [np.random.RandomState(300 + r).randn(16 + r).astype(np.float32) for r in range(world)]
+        tqn = [np.random.RandomState(400 + r).randn(16 + r).astype(np.float32) for r in range(world)]
+        mine = np.concatenate([NO.rms_update(np.zeros(3), tq[rank][:, None], 1),
+                               NO.rms_update(np.zeros(3), tqn[rank][:, None], 1)])
+        ex = torch.from_numpy(mine.copy())
+        comm.allreduce_(ex)
+        want = NO.rms_update(NO.rms_update(np.zeros(3), np.concatenate(tq)[:, None], 1),
+                             np.concatenate(tqn)[:, None], 1)
+        np.testing.assert_allclose(ex.numpy()[:3] + ex.numpy()[3:], want, rtol=1e-12)
+        # the direct-RCCL switch stays off on a non-nccl group, on every rank alike
+        assert comm.enable_direct() is False and not comm.capturable
         # --- sync_from_root / check_synced semantics
         p = torch.full((10,), float(rank))
         comm.bcast_(p, root=0)
