@@ -243,12 +243,16 @@ int samx_td_errors(const samx_mlp* critic, const float* critic_params, const flo
 /* The same TD errors for rows addressed IN PLACE in the replay storages: row r of the batch is storage row
  * (ring_start + idx[r]) % ring_len (idx NULL: obs0/acs are B dense rows).  64x64 critics without return
  * normalisation run as one whole-network launch; anything else gathers into ws and takes the layer-wise
- * pass.  This is the PER priority refresh with the post-update critic (sam_agent.py:693-701). */
+ * pass.  This is the PER priority refresh with the post-update critic (sam_agent.py:693-701).
+ * td_copy_out / idx_copy_out (both or neither; need idx): second copies of td_out and of idx, written by the
+ * same launch — pointed at pinned host memory they hand the host what memory.py:344-379 needs for the next
+ * priority update without a separate device-to-host step. */
 size_t samx_td_errors_rows_ws_bytes(const samx_mlp* critic, int64_t B);
 int samx_td_errors_rows(const samx_mlp* critic, const float* critic_params, const float* obs0,
                         const float* acs, const int64_t* idx, int64_t ring_start, int64_t ring_len,
                         const float* tc1s, const float* ob_mean, const float* ob_std, int64_t B, int ob_dim,
-                        float* td_out, const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream);
+                        float* td_out, float* td_copy_out, int64_t* idx_copy_out, const samx_retnorm* ret,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* setup_actor (sam_agent.py:406-433): loss = -q_scale*mean Q(obz0, mu(obz0))
  *                                           -d_scale*mean D(obz0, mu(obz0)), gradient wrt the actor only.

@@ -102,7 +102,7 @@ SIGNATURES = {
                                    _P, _RP, _P, _F, _P, _P, _SZ, _P]),
     'samx_td_errors': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _P, _RP, _P, _SZ, _P]),
     'samx_td_errors_rows_ws_bytes': (_SZ, [_MP, _I64]),
-    'samx_td_errors_rows': (C.c_int, [_MP, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, _RP, _P,
+    'samx_td_errors_rows': (C.c_int, [_MP, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, _P, _P, _RP, _P,
                                       _SZ, _P]),
     'samx_actor_grad': (C.c_int, [_MP, _P, _MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _F, _F, _P, _P,
                                   _RP, _P, _SZ, _P]),

@@ -145,7 +145,8 @@ constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
               const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
-              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, hipStream_t st);
+              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, float* td_copy,
+              int64_t* idx_copy, hipStream_t st);
 int launch_finalize(const FinalizeArgs& f, hipStream_t st);
 int launch_apply(const ApplyArgs& f, hipStream_t st);
 int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st);

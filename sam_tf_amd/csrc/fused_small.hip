@@ -987,6 +987,8 @@ struct TdArgs {
     const float *ret_mean, *ret_std;   // return normalisation (device scalars) or nullptr
     const float *obs0, *acs, *tc1s, *mean, *stdv, *critic;
     float* td_out;
+    float* td_copy;       // optional second copy (pinned host memory) of td_out
+    int64_t* idx_copy;    // optional copy of idx
     int ob, ac;
     const int64_t* idx;
     int64_t ring_start, ring_len;
@@ -1025,6 +1027,8 @@ __global__ __launch_bounds__(NT) void td_kernel(TdArgs a) {
             t = (t - rm) / rs;
         }
         a.td_out[row0 + tid] = q - t;
+        if (a.td_copy) a.td_copy[row0 + tid] = q - t;
+        if (a.idx_copy) a.idx_copy[row0 + tid] = a.idx[row0 + tid];
     }
 }
 
@@ -1441,8 +1445,10 @@ int launch_targets(const AgentArgs* a, hipStream_t st) {
 
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
               const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
-              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, hipStream_t st) {
+              int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, float* td_copy,
+              int64_t* idx_copy, hipStream_t st) {
     TdArgs a;
+    a.td_copy = td_copy; a.idx_copy = idx ? idx_copy : nullptr;
     a.ret_mean = ret_mean; a.ret_std = ret_std;
     a.obs0 = obs0; a.acs = acs; a.tc1s = tc1s; a.mean = mean; a.stdv = stdv; a.critic = critic;
     a.td_out = td_out; a.ob = ob; a.ac = dc->in_dim - ob; a.idx = idx; a.ring_start = ring_start;

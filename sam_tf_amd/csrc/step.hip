@@ -497,17 +497,20 @@ int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t
 int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
                         const int64_t* idx, int64_t ring_start, int64_t ring_len, const float* tc1s,
                         const float* mean, const float* stdv, int64_t B, int ob_dim, float* td_out,
-                        const samx_retnorm* ret, void* ws, size_t ws_bytes, void* stream) {
+                        float* td_copy_out, int64_t* idx_copy_out, const samx_retnorm* ret, void* ws,
+                        size_t ws_bytes, void* stream) {
     SAMX_REQUIRE(dc && pc && obs0 && acs && tc1s && td_out && B > 0 && ob_dim > 0 && ob_dim < dc->in_dim,
                  "samx_td_errors_rows: bad arguments");
+    SAMX_REQUIRE((td_copy_out == nullptr) == (idx_copy_out == nullptr) && (!idx_copy_out || idx),
+                 "samx_td_errors_rows: td_copy_out and idx_copy_out come together, and only with idx");
     SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_td_errors_rows: mean/std must come together");
     SAMX_REQUIRE(!idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_td_errors_rows: bad ring geometry");
     const bool ret_on = ret && ret->mean;
     if (fused::supported(dc, B) && dc->out_dim == 1 && fused::fits_lds(ob_dim, dc->in_dim - ob_dim))
         return fused::launch_td(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, idx, ring_start, ring_len,
-                                td_out, ret_on ? ret->mean : nullptr, ret_on ? ret->std : nullptr,
-                                (hipStream_t)stream);
+                                td_out, ret_on ? ret->mean : nullptr, ret_on ? ret->std : nullptr, td_copy_out,
+                                idx_copy_out, (hipStream_t)stream);
     // general path: gather the rows, then the layer-wise pass
     const int ac = dc->in_dim - ob_dim;
     SAMX_REQUIRE(ws, "samx_td_errors_rows: this configuration needs a workspace");
@@ -523,7 +526,9 @@ int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, 
         if (rc != SAMX_OK) return rc;
         obs0 = g_obs; acs = g_acs;
     }
-    return samx_td_errors(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, td_out, ret, nws, nets_bytes, stream);
+    int rc = samx_td_errors(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, td_out, ret, nws, nets_bytes, stream);
+    if (rc != SAMX_OK || !td_copy_out) return rc;
+    return samx_to_host_pair(td_out, td_copy_out, idx, idx_copy_out, B, stream);
 }
 
 size_t samx_td_errors_rows_ws_bytes(const samx_mlp* dc, int64_t B) {

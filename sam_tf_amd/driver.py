@@ -255,8 +255,11 @@ class UpdateStepDriver(object):
             mu = self.mu
             mean, std = mu._mean_std()
             st = mu.replay_buffer.store
+            # (one process: the TD errors and the sampled indices also land in pinned host memory, for the
+            # host's leaf arithmetic of the next priority update)
+            io = dict(td_host=self._td_host, idx_host=self._idx_host) if self.per_graph_io else {}
             ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self.idx_a, self._batch_start,
-                               self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret)
+                               self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret, **io)
 
     def _grads_of(self, role):
         """The slice of the flat gradient a row with these roles fills (what is all-reduced)."""
@@ -322,8 +325,6 @@ class UpdateStepDriver(object):
                     for k in range(K):
                         self._seg_inputs(k, roles[k])
                         self._seg_grads(k, roles[k])
-                if self.per_graph_io and roles[0] & self.A:   # TD errors + sampled indices -> pinned host
-                    ops.to_host_pair(self.td_post, self._td_host, self.idx_a, self._idx_host)
             return [self._capture(run)]
         # N > 1: the launch as a list of device segments and collectives in execution order
         #   [D-input sums of the K rows -> all-reduce of the K float64 sum vectors]   (fused path)

@@ -330,8 +330,13 @@ def td_errors(dc, pc, obs0, acs, tc1s, mean, std, ws, out=None, ret=None):
 _TDR_WS = {}
 
 
-def td_errors_rows(dc, pc, obs0_store, acs_store, idx, ring_start, tc1s, mean, std, out, ret=None):
-    """TD errors of the batch rows addressed in place in the replay storages (idx int64[B])."""
+def td_errors_rows(dc, pc, obs0_store, acs_store, idx, ring_start, tc1s, mean, std, out, ret=None,
+                   td_host=None, idx_host=None):
+    """TD errors of the batch rows addressed in place in the replay storages (idx int64[B]).  td_host /
+    idx_host: pinned host tensors that receive copies of the TD errors and of idx from the same launch."""
+    if td_host is not None:
+        assert idx_host is not None and td_host.is_pinned() and idx_host.is_pinned()
+        assert td_host.dtype == F32 and idx_host.dtype == I64 and td_host.numel() == idx.numel() == idx_host.numel()
     B = idx.numel()
     ring_len, ob = obs0_store.shape
     _chk(obs0_store, F32, (ring_len, ob), 'obs0 store'); _chk(acs_store, F32, (ring_len, dc.in_dim - ob), 'acs store')
@@ -345,7 +350,8 @@ def td_errors_rows(dc, pc, obs0_store, acs_store, idx, ring_start, tc1s, mean, s
     ws = _TDR_WS[key]
     check(_L().samx_td_errors_rows(C.byref(dc), ptr(pc), ptr(obs0_store), ptr(acs_store), ptr(idx),
                                    int(ring_start), int(ring_len), ptr(tc1s), ptr(mean), ptr(std), B, ob,
-                                   ptr(out), _ret(ret), ptr(ws), ws.numel(), stream_ptr()))
+                                   ptr(out), ptr(td_host), ptr(idx_host), _ret(ret), ptr(ws), ws.numel(),
+                                   stream_ptr()))
     return out
 
 

@@ -660,3 +660,29 @@ def test_train_with_launcher_options():
     # the combination the reference itself cannot run
     with pytest.raises(NotImplementedError):
         SAMAgent('mu2', comm, env, make_hps(n_step_returns=True, prioritized_replay=True), d)
+
+
+@pytest.mark.parametrize('h', [(64, 64), (33, 70)])
+def test_td_errors_rows_host_copies(h):
+    """samx_td_errors_rows with td_copy_out / idx_copy_out in pinned host memory (whole-network launch for
+    64x64, gather + layer-wise pass + copy kernel otherwise): the copies equal the device outputs, which
+    equal samx_td_errors on the gathered rows."""
+    from sam_tf_amd import ops
+    ob, ac, B, N = 7, 3, 48, 500
+    g = torch.Generator().manual_seed(3)
+    dc = ops.mlp_desc(ob + ac, h[0], h[1], 1, False)
+    pc = (torch.randn(ops.param_count(dc), generator=g) * 0.2).cuda()
+    obs = torch.randn(N, ob, generator=g).cuda(); acs = torch.rand(N, ac, generator=g).cuda()
+    idx = torch.randint(0, N, (B,), generator=g).cuda()
+    tc = torch.randn(B, generator=g).cuda()
+    mean = torch.zeros(ob).cuda(); std = torch.ones(ob).cuda()
+    start = 123
+    out = torch.zeros(B, device='cuda')
+    td_h = torch.zeros(B).pin_memory(); idx_h = torch.zeros(B, dtype=torch.int64).pin_memory()
+    ops.td_errors_rows(dc, pc, obs, acs, idx, start, tc, mean, std, out, td_host=td_h, idx_host=idx_h)
+    torch.cuda.synchronize()
+    assert torch.equal(td_h, out.cpu()) and torch.equal(idx_h, idx.cpu())
+    phys = (start + idx) % N
+    ws = ops.nets_ws(dc, dc, dc, B)
+    exp = ops.td_errors(dc, pc, obs[phys].contiguous(), acs[phys].contiguous(), tc, mean, std, ws)
+    assert relerr(out.cpu().numpy(), exp.cpu().numpy()) < 1e-5
