@@ -1,0 +1,27 @@
+// Internal entry points of the layer-wise network path that the step (step.hip) calls with the batch
+// still addressed IN PLACE (ring rows / pool slice / in-kernel randoms), see samx_batch in include/samx.h.
+#pragma once
+#include "samx_common.h"
+#include "../../include/samx.h"
+
+namespace samx {
+
+// Where the discriminator's rows come from when they are not dense (all optional, zero = dense inputs):
+struct DiscSrc {
+    const int64_t* p_idx = nullptr;    // p_obs/p_acs address the replay storage: row r = (ring_start + p_idx[r]) % ring_len
+    int64_t ring_start = 0, ring_len = 0;
+    const int64_t* e_start = nullptr;  // e_obs/e_acs address the expert pool: row r = e_start[0] + r
+    bool draw = false;                 // eps_ob / eps_ac / labels are drawn here (Philox, rng.h) instead of read
+    uint64_t rng_seed = 0;
+    const int64_t* step_dev = nullptr; // device: the reward-net update count that keys the draws
+    float *real_out = nullptr, *fake_out = nullptr;   // [B] smoothed labels written by the prep kernel (or null)
+};
+
+// samx_disc_grad (include/samx.h) with the rows resolved inside its first kernel
+int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const float* p_acs, const float* e_obs,
+                  const float* e_acs, const float* eps_ob, const float* eps_ac, const float* real_labels,
+                  const float* fake_labels, const float* mean, const float* stdv, int64_t B, int ob_dim,
+                  float ent_reg_scale, float* losses_out, float* grad_out, void* ws, size_t ws_bytes,
+                  const DiscSrc* src, void* stream);
+
+}  // namespace samx

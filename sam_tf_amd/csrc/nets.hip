@@ -4,6 +4,8 @@
 //   sam_agent.py:145-205,406-520 ; discriminator.py:61-194 ; networks.py:45-72,222-404
 #include "samx_common.h"
 #include "gemm.h"
+#include "nets.h"
+#include "rng.h"
 #include "../../include/samx.h"
 #include <math.h>
 
@@ -76,30 +78,47 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ obs
 
 // rows [0,B): policy pair, [B,2B): expert pair, [2B,3B): eps*policy + (1-eps)*expert on the
 // NORMALISED observations and raw actions (discriminator.py:71-72,129-134)
+// The rows may still live in the replay storage (src.p_idx) / the expert pool (src.e_start) and the randoms
+// may be drawn here (src.draw; same Philox streams and indices as samx_disc_randoms): no gather, slice or
+// random-number launch in front of the discriminator's chain.
 __global__ __launch_bounds__(256) void disc_prep_kernel(
     const float* __restrict__ p_obs, const float* __restrict__ p_acs, const float* __restrict__ e_obs,
     const float* __restrict__ e_acs, const float* __restrict__ eps_ob,
     const float* __restrict__ eps_ac, const float* __restrict__ mean, const float* __restrict__ stdv,
-    int64_t B, int ob, int ac, float* __restrict__ X) {
+    int64_t B, int ob, int ac, float* __restrict__ X, DiscSrc src) {
     const int w = ob + ac;
     const int64_t tot = B * w;
+    const uint64_t st = src.draw ? (uint64_t)src.step_dev[0] : 0;
+    const int64_t e0 = src.e_start ? src.e_start[0] : 0;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = t / w;
         const int c = (int)(t % w);
+        int64_t pr = row;
+        if (src.p_idx) {
+            pr = src.ring_start + src.p_idx[row];
+            if (pr >= src.ring_len) pr -= src.ring_len;
+        }
+        const int64_t er = e0 + row;
+        if (src.draw && c == 0) {
+            if (src.real_out) src.real_out[row] = real_label(philox_uniform(src.rng_seed, st, RNG_REAL, (uint64_t)row));
+            if (src.fake_out) src.fake_out[row] = fake_label(philox_uniform(src.rng_seed, st, RNG_FAKE, (uint64_t)row));
+        }
         float p, e, eps;
         if (c < ob) {
-            p = p_obs[row * ob + c];
-            e = e_obs[row * ob + c];
+            p = p_obs[pr * ob + c];
+            e = e_obs[er * ob + c];
             if (mean) {
                 p = fminf(fmaxf((p - mean[c]) / stdv[c], -5.f), 5.f);
                 e = fminf(fmaxf((e - mean[c]) / stdv[c], -5.f), 5.f);
             }
-            eps = eps_ob[row * ob + c];
+            eps = src.draw ? philox_uniform(src.rng_seed, st, RNG_EPS_OB, (uint64_t)(row * ob + c))
+                           : eps_ob[row * ob + c];
         } else {
-            p = p_acs[row * ac + (c - ob)];
-            e = e_acs[row * ac + (c - ob)];
-            eps = eps_ac[row * ac + (c - ob)];
+            p = p_acs[pr * ac + (c - ob)];
+            e = e_acs[er * ac + (c - ob)];
+            eps = src.draw ? philox_uniform(src.rng_seed, st, RNG_EPS_AC, (uint64_t)(row * ac + (c - ob)))
+                           : eps_ac[row * ac + (c - ob)];
         }
         X[row * w + c] = p;
         X[(B + row) * w + c] = e;
@@ -1110,9 +1129,26 @@ int samx_disc_grad(const samx_mlp* dd, const float* pd, const float* p_obs, cons
                    const float* real_labels, const float* fake_labels, const float* mean,
                    const float* stdv, int64_t B, int ob_dim, float ent_reg_scale, float* losses_out,
                    float* grad_out, void* ws, size_t ws_bytes, void* stream) {
+    return samx::disc_grad_src(dd, pd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real_labels, fake_labels, mean,
+                               stdv, B, ob_dim, ent_reg_scale, losses_out, grad_out, ws, ws_bytes, nullptr, stream);
+}
+
+}  // extern "C"
+
+namespace samx {
+int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const float* p_acs, const float* e_obs,
+                  const float* e_acs, const float* eps_ob, const float* eps_ac, const float* real_labels,
+                  const float* fake_labels, const float* mean, const float* stdv, int64_t B, int ob_dim,
+                  float ent_reg_scale, float* losses_out, float* grad_out, void* ws, size_t ws_bytes,
+                  const DiscSrc* srcp, void* stream) {
+    const DiscSrc src = srcp ? *srcp : DiscSrc();
     TRY(check_desc(dd, "samx_disc_grad"));
-    SAMX_REQUIRE(pd && p_obs && p_acs && e_obs && e_acs && eps_ob && eps_ac && losses_out && grad_out && ws,
+    SAMX_REQUIRE(pd && p_obs && p_acs && e_obs && e_acs && (src.draw || (eps_ob && eps_ac)) && losses_out &&
+                     grad_out && ws,
                  "samx_disc_grad: null pointer");
+    SAMX_REQUIRE(!src.draw || src.step_dev, "samx_disc_grad: in-kernel draws need the device step counter");
+    SAMX_REQUIRE(!src.p_idx || (src.ring_len > 0 && src.ring_start >= 0 && src.ring_start < src.ring_len),
+                 "samx_disc_grad: bad ring geometry");
     SAMX_REQUIRE((mean == nullptr) == (stdv == nullptr), "samx_disc_grad: mean/std must come together");
     SAMX_REQUIRE(B > 0 && dd->out_dim == 1 && ob_dim > 0 && ob_dim < dd->in_dim, "samx_disc_grad: bad sizes");
     SAMX_REQUIRE(ent_reg_scale >= 0.f, "samx_disc_grad: ent_reg_scale must be non-negative");
@@ -1124,8 +1160,9 @@ int samx_disc_grad(const samx_mlp* dd, const float* pd, const float* p_obs, cons
     const int ob = ob_dim, ac = d.in - ob_dim;
     const float gp_coeff = 10.f;  // discriminator.py:154
     disc_prep_kernel<<<grid1d(B * d.in), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, mean,
-                                                      stdv, B, ob, ac, w.X);
+                                                      stdv, B, ob, ac, w.X, src);
     SAMX_LAUNCH_CHECK();
+    if (src.draw) { real_labels = src.real_out; fake_labels = src.fake_out; }
 
     if (!d.ln) {
         // ---- leaky-ReLU only: the tangent of the network is linear in its masks, the second-order
@@ -1227,4 +1264,4 @@ int samx_disc_grad(const samx_mlp* dd, const float* pd, const float* p_obs, cons
     return SAMX_OK;
 }
 
-}  // extern "C"
+}  // namespace samx

@@ -4,6 +4,7 @@
 //   reference sequence: sam.py:369-433 (D update, then mu.train(), then update_target_net())
 #include "samx_common.h"
 #include "fused_small.h"
+#include "nets.h"
 #include "tree_dev.h"
 #include "rng.h"
 #include <stdlib.h>
@@ -20,9 +21,9 @@ struct StepWs {
     size_t nets_bytes;
     void* disc_ws;
     size_t disc_bytes;
-    // layer-wise path only: gathered rows and materialised randoms
-    float *g_pobs, *g_pacs, *g_eobs, *g_eacs, *g_obs0, *g_acs, *g_rews, *g_dones, *g_obs1, *r_eob, *r_eac,
-        *r_real, *r_fake;
+    // layer-wise path only: the agent's gathered rows and the drawn labels (the discriminator's rows and
+    // eps are resolved inside its first kernel)
+    float *g_obs0, *g_acs, *g_rews, *g_dones, *g_obs1, *r_real, *r_fake;
     // n-step lookahead (memory.py:113-160) and return-statistics sums
     int64_t* n_end;
     float *n_rews, *n_dones, *n_len, *n_obs1, *n_tq;
@@ -84,11 +85,8 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.nets_ws2 = ar.take<char>(w.nets_bytes);
     w.disc_ws = ar.take<char>(w.disc_bytes);
     const int64_t ob = L->ob_dim, ac = L->ac_dim, n = f ? 0 : B;
-    w.g_pobs = ar.take<float>(n * ob); w.g_pacs = ar.take<float>(n * ac);
-    w.g_eobs = ar.take<float>(n * ob); w.g_eacs = ar.take<float>(n * ac);
     w.g_obs0 = ar.take<float>(n * ob); w.g_acs = ar.take<float>(n * ac);
     w.g_rews = ar.take<float>(n); w.g_dones = ar.take<float>(n); w.g_obs1 = ar.take<float>(n * ob);
-    w.r_eob = ar.take<float>(n * ob); w.r_eac = ar.take<float>(n * ac);
     w.r_real = ar.take<float>(n); w.r_fake = ar.take<float>(n);
     const int64_t nn = L->n_step > 0 ? B : 0;   // both paths: lookahead outputs (the gathered n_obs1 rows
                                                 // are only used by the layer-wise path)
@@ -167,19 +165,6 @@ __global__ __launch_bounds__(256) void randoms_kernel(uint64_t seed, const int64
         } else if (fake) {
             fake[t - n_ob - n_ac - B] = fake_label(philox_uniform(seed, st, RNG_FAKE, (uint64_t)(t - n_ob - n_ac - B)));
         }
-    }
-}
-
-// rows e_start[0] .. e_start[0]+B of the expert pool -> dense [B, *] (layer-wise path only)
-__global__ __launch_bounds__(256) void expert_slice_kernel(const float* __restrict__ obs,
-                                                           const float* __restrict__ acs,
-                                                           const int64_t* __restrict__ e_start, int64_t B,
-                                                           int ob, int ac, float* __restrict__ o_obs,
-                                                           float* __restrict__ o_acs) {
-    const int64_t e0 = e_start[0];
-    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < B * (ob + ac); t += (int64_t)gridDim.x * 256) {
-        if (t < B * ob) o_obs[t] = obs[e0 * ob + t];
-        else o_acs[t - B * ob] = acs[e0 * ac + (t - B * ob)];
     }
 }
 
@@ -645,26 +630,15 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                                     w.stats_bytes, stream);
             if (rc != SAMX_OK) return rc;
         }
-        if (b->p_idx && do_d && !t_only) {
-            rc = samx_replay_gather(b->p_obs, b->p_acs, nullptr, nullptr, nullptr, b->ring_len, b->ring_start,
-                                    ob, ac, b->p_idx, B, w.g_pobs, w.g_pacs, nullptr, nullptr, nullptr, stream);
-            if (rc != SAMX_OK) return rc;
-            dense.p_obs = w.g_pobs; dense.p_acs = w.g_pacs;
-        }
-        if (b->e_start && do_d && !t_only) {
-            expert_slice_kernel<<<64, 256, 0, st>>>(b->e_obs, b->e_acs, b->e_start, B, ob, ac, w.g_eobs, w.g_eacs);
-            SAMX_LAUNCH_CHECK();
-            dense.e_obs = w.g_eobs; dense.e_acs = w.g_eacs;
-        }
-        if (!b->eps_ob && do_d && !t_only) {
-            const int64_t n = B * (ob + ac + 2);
-            randoms_kernel<<<(unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(
-                b->rng_seed, L->steps + 2, 0, B, ob, ac, w.r_eob, w.r_eac,
-                b->label_smoothing >= 1 ? w.r_real : nullptr, b->label_smoothing == 2 ? w.r_fake : nullptr);
-            SAMX_LAUNCH_CHECK();
-            dense.eps_ob = w.r_eob; dense.eps_ac = w.r_eac;
-            dense.real_labels = b->label_smoothing >= 1 ? w.r_real : nullptr;
-            dense.fake_labels = b->label_smoothing == 2 ? w.r_fake : nullptr;
+        // the discriminator's rows stay where they are: its first kernel reads the ring rows / the pool
+        // slice in place and draws the randoms itself (no gather, slice or random-number launch in front)
+        samx::DiscSrc dsrc;
+        dsrc.p_idx = b->p_idx; dsrc.ring_start = b->ring_start; dsrc.ring_len = b->ring_len;
+        dsrc.e_start = b->e_start;
+        if (!b->eps_ob) {
+            dsrc.draw = true; dsrc.rng_seed = b->rng_seed; dsrc.step_dev = L->steps + 2;
+            dsrc.real_out = b->label_smoothing >= 1 ? w.r_real : nullptr;
+            dsrc.fake_out = b->label_smoothing == 2 ? w.r_fake : nullptr;
         }
         b = &dense;
         samx_retnorm retv{L->ret_mean, L->ret_std};
@@ -736,10 +710,10 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (rc != SAMX_OK) return rc;
         }  // do_a
         if (do_d) {
-        rc = samx_disc_grad(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
-                            b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,
-                            L->ent_reg_scale, o->d_losses, L->grads + Pa + Pc, w.disc_ws, w.disc_bytes,
-                            stream);
+        rc = samx::disc_grad_src(&L->reward, pd, b->p_obs, b->p_acs, b->e_obs, b->e_acs, b->eps_ob, b->eps_ac,
+                           b->real_labels, b->fake_labels, L->d_mean, L->d_std, B, L->ob_dim,
+                           L->ent_reg_scale, o->d_losses, L->grads + Pa + Pc, w.disc_ws, w.disc_bytes, &dsrc,
+                           stream);
         if (rc != SAMX_OK) return rc;
         }  // do_d
         if (ss) {  // join
