@@ -288,11 +288,14 @@ constexpr int kStatGroupsMax = 128;
 __global__ __launch_bounds__(256) void d_input_partials_kernel(
     const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
-    const int64_t* __restrict__ e_start, int64_t B, int dim, double* __restrict__ part) {
+    const int64_t* __restrict__ e_start, int64_t B, int dim, double* __restrict__ part,
+    const double* __restrict__ sums) {
     const int G = gridDim.x, g = blockIdx.x;
     const int64_t e0 = e_start ? e_start[0] : 0;
-    for (int c0 = 0; c0 < dim; c0 += 256) {
-        const int col = c0 + threadIdx.x;
+    // snapshot of the running count for the commit kernel (slot behind the partials)
+    if (sums && g == 0 && blockIdx.y == 0 && threadIdx.x == 0) part[(int64_t)G * 2 * dim] = sums[2 * dim];
+    {   // blockIdx.y: the chunk of 256 columns
+        const int col = blockIdx.y * 256 + threadIdx.x;
         double a = 0.0, q = 0.0;
         for (int64_t rb = g; rb < 2 * B; rb += (int64_t)G * 8) {
             float v[8];
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(256) void d_input_partials_kernel(
     }
 }
 
+// One wave per column.  The running count every column divides by is the snapshot the partials kernel took
+// (the launch before), so column 0 can advance the count in place without a third launch.
 __global__ __launch_bounds__(64) void d_input_commit_kernel(const double* __restrict__ part, int G, int64_t B,
                                                             int dim, double* __restrict__ addvec, int commit,
                                                             double* __restrict__ sums,
@@ -346,25 +351,21 @@ __global__ __launch_bounds__(64) void d_input_commit_kernel(const double* __rest
         addvec[col] = a;
         addvec[dim + col] = q;
         if (col == 0) addvec[2 * dim] = (double)(2 * B);
-        if (commit) {  // helpers/mpi_running_mean_std.py:31-45 ; the count is advanced by column 0 LAST
-            const double cnt = sums[2 * dim] + (double)(2 * B);
+        if (commit) {  // helpers/mpi_running_mean_std.py:31-45
+            const double cnt = part[(int64_t)G * 2 * dim] + (double)(2 * B);   // old count: the snapshot
             const double s1 = __dadd_rn(sums[col], a), s2 = __dadd_rn(sums[dim + col], q);
             sums[col] = s1;
             sums[dim + col] = s2;
             const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
             mean_out[col] = mean;
             std_out[col] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+            if (col == 0) sums[2 * dim] = cnt;
         }
     }
 }
 
-// the running count, advanced once every column has used the old value (stream order)
-__global__ void d_input_count_kernel(double* sums, int dim, int64_t B) {
-    if (threadIdx.x == 0) sums[2 * dim] = sums[2 * dim] + (double)(2 * B);
-}
-
 int stat_groups(int64_t B) {
-    int64_t g = (2 * B) / 32;
+    int64_t g = (2 * B) / 16;
     return (int)(g < 1 ? 1 : (g > kStatGroupsMax ? kStatGroupsMax : g));
 }
 
@@ -406,15 +407,11 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
             return fail(SAMX_ERR_WORKSPACE, "samx_d_input_stats: workspace %zu < %zu", ws_bytes,
                         samx_d_input_stats_ws_bytes(B, ob_dim));
         double* part = (double*)ws;
-        d_input_partials_kernel<<<G, 256, 0, st>>>(replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start,
-                                                   B, ob_dim, part);
+        d_input_partials_kernel<<<dim3(G, (ob_dim + 255) / 256), 256, 0, st>>>(
+            replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, part, commit ? sums : nullptr);
         SAMX_LAUNCH_CHECK();
         d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out);
         SAMX_LAUNCH_CHECK();
-        if (commit) {
-            d_input_count_kernel<<<1, 64, 0, st>>>(sums, ob_dim, B);
-            SAMX_LAUNCH_CHECK();
-        }
         return SAMX_OK;
     }
     int dimpad = 1;
