@@ -19,5 +19,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o c4 -- python3 bench.
 DB4=$(ls $O/*c4_results.db $O/*/*c4_results.db 2>/dev/null | head -1)
 python3 profiles/summarize_rocpd.py $DB4 > $O/${R}_c4_bench_kernel_stats.txt || exit 1
 grep "^{\"metric\"" $O/c4_bench.log | tail -1 > $O/${R}_bench_c4_under_rocprof.json
+for C in C3 C5; do
+  c=$(echo $C | tr A-Z a-z)
+  N=$([ $C = C5 ] && echo 60 || echo 500)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o $c -- python3 bench.py --no-cpu --config $C --steps $N --warmup 20 --no-training-step > $O/${c}_bench.log 2>&1 || exit 1
+  DBc=$(find $O -name "*${c}_results.db" | head -1)
+  python3 profiles/summarize_rocpd.py $DBc > $O/${R}_${c}_bench_kernel_stats.txt || exit 1
+  if [ $C = C3 ]; then python3 profiles/timeline_rocpd.py $DBc step_kernel 300 > $O/${R}_c3_step_timeline.txt || exit 1; fi
+  rm -f $DBc
+done
 rm -f $O/*.db $O/*/*.db
 echo done
