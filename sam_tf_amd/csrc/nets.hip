@@ -795,7 +795,9 @@ struct AgentWs {
 
 AgentWs carve_agent(Arena& ar, const samx_mlp* da, const samx_mlp* dc, const samx_mlp* dd, int64_t B) {
     AgentWs w;
-    const int acdim = dc->in_dim - (da ? da->in_dim : 0);
+    // action-gradient rows exist only with an actor: a critic-only carve (reward, critic gradient, TD errors)
+    // must fit any workspace sized by samx_nets_ws_bytes for the same critic, whatever actor was named there
+    const int acdim = da ? dc->in_dim - da->in_dim : 0;
     w.XC = ar.take<float>(B * dc->in_dim);
     w.ha = carve_hid(ar, da, B);
     w.hc = carve_hid(ar, dc, B);

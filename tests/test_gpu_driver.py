@@ -686,3 +686,28 @@ def test_td_errors_rows_host_copies(h):
     ws = ops.nets_ws(dc, dc, dc, B)
     exp = ops.td_errors(dc, pc, obs[phys].contiguous(), acs[phys].contiguous(), tc, mean, std, ws)
     assert relerr(out.cpu().numpy(), exp.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('cfg_name', ['C2', 'C4'])
+def test_rollout_calls_at_batch_one(cfg_name):
+    """The per-environment-step calls (sam.py:50-71) at B = 1, also with the Humanoid-shaped 256-wide nets
+    (a critic-only workspace carve must fit what the Python side sized): get_reward / predict agree with the
+    batched kernels on the same row."""
+    import bench
+    from sam_tf_amd import ops
+    from sam_tf_amd.comm import TorchComm
+    cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
+    mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, False)
+    rs = np.random.RandomState(1)
+    obs = rs.randn(16, cfg['ob']).astype(np.float32)
+    acs = rs.uniform(-1, 1, (16, cfg['ac'])).astype(np.float32)
+    r1 = np.array([d.get_reward(obs[i], acs[i]) for i in range(3)], dtype=np.float64)
+    rb = d.get_reward_device(torch.as_tensor(obs).cuda(), torch.as_tensor(acs).cuda()).cpu().numpy().ravel()
+    assert relerr(r1, rb[:3]) < 1e-5
+    a0, q0 = mu.predict(obs[0], False, True)
+    assert a0.shape == (cfg['ac'],) and np.isfinite(a0).all() and np.isfinite(q0)
+    m2, s2 = mu._mean_std()
+    ab, qb = ops.act_q(mu.da, mu.actor.flat, mu.dc, mu.critic.flat, torch.as_tensor(obs).cuda(), m2, s2,
+                       mu.ac_high, ops.nets_ws(mu.da, mu.dc, None, 16), want_q=True, ret=mu.ret)
+    assert relerr(a0, ab[0].cpu().numpy()) < 1e-5 and abs(q0 - float(qb[0].item())) <= 1e-5 * max(1.0, abs(q0))
+    mu.store_transition(obs[0], a0, 1.0, obs[1], False)
