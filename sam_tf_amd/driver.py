@@ -155,6 +155,7 @@ class UpdateStepDriver(object):
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
         self.inline_stats = bool(self.fused and self.d.hps.rmsify_obs)
+        self.sums_small = 2 * B * self.mu.ob_dim <= 16384   # what the one-workgroup sums kernels hold (samx.h)
         # layer-wise path, one process: samx_step_grads computes and commits the row's D statistics itself,
         # on the discriminator's stream, while the agent roles already run (no separate stats segment)
         self.inline_stats_lw = bool(not self.fused and self.world == 1 and self.d.hps.rmsify_obs)
@@ -200,9 +201,15 @@ class UpdateStepDriver(object):
         """The D-input sums of all K rows of the launch (they do not depend on the learner; rows
         without a D update carry index words 0 and their sums are not used)."""
         if self.inline_stats:
-            rb = self.mu.replay_buffer
-            ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], self.B,
-                                  self.pool.obs0, self.addvecs[:K])
+            rb, B = self.mu.replay_buffer, self.B
+            if self.sums_small:
+                ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], B,
+                                      self.pool.obs0, self.addvecs[:K])
+            else:   # large batches of wide observations: the two-stage sums, row by row (no commit)
+                for k in range(K):
+                    w = self.words[k]
+                    ops.d_input_stats(rb.store['obs0'], self._batch_start, w[:B], self.pool.obs0,
+                                      w[2 * B:2 * B + 1], B, self.addvecs[k], commit=False)
 
     def _seg_lookahead(self, K):
         """The n-step lookahead of all K rows of the launch (rows without an agent update carry index
@@ -311,7 +318,7 @@ class UpdateStepDriver(object):
                     self.words[:1].copy_(self._launch_words, non_blocking=True)
                 rb = self.mu.replay_buffer
                 if (self.per_graph_io and K == 1 and roles[0] == self.D | self.A and self.inline_stats
-                        and self.B < 1024):
+                        and self.B < 1024 and self.sums_small):
                     # pending priority update and this row's D-input sums: one launch, two workgroups
                     ops.per_row_prologue(rb.trees, self.prev_idx, self.prev_leaf, rb.store['obs0'],
                                          self._batch_start, self.words[0], self.B, self.pool.obs0, self.addvecs[0])
