@@ -13,7 +13,33 @@ from sam_tf_amd.comm import TorchComm  # noqa: E402
 from sam_tf_amd.driver import UpdateStepDriver  # noqa: E402
 
 
+class TwinComm(object):
+    """2 ranks whose second rank is an identical twin (SUM doubles): drives the N > 1 plans on one GPU."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 2
+
+    def Barrier(self):
+        pass
+
+    def allreduce_(self, t):
+        return t.mul_(2)
+
+    def bcast_(self, t, root=0):
+        return t
+
+    def Allreduce(self, sendbuf, recvbuf, op='sum'):
+        recvbuf[...] = 2 * np.asarray(sendbuf)
+
+    def Bcast(self, buf, root=0):
+        pass
+
+
 def main():
+    twin = len(sys.argv) > 1 and sys.argv[1] == 'twin'
     shapes = [(4, 1, (64, 64), 32), (11, 3, (64, 64), 256), (20, 4, (64, 64), 48), (376, 17, (256, 256), 64),
               (5, 2, (33, 70), 37), (50, 10, (64, 64), 32), (3, 1, (8, 8), 1), (111, 8, (400, 300), 16),
               (17, 6, (64, 64), 2048), (17, 6, (64, 64), 512)]
@@ -26,7 +52,7 @@ def main():
                                nstep=nstep, p_done=0.1)
                     n += 1
                     try:
-                        mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 1, graph)
+                        mu, d, pool, _ = bench.build_learner(cfg, TwinComm() if twin else TorchComm('cuda'), torch.device('cuda', 0), 1, graph)
                         drv = UpdateStepDriver(mu, d, pool, use_graph=graph, steps_per_launch=6, g_steps=g_steps)
                         drv.run(2 * drv.K + 1)
                         drv.flush()

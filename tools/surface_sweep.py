@@ -15,9 +15,35 @@ from sam_tf_amd.discriminator import Discriminator  # noqa: E402
 from sam_tf_amd.hps import make_hps, SyntheticEnv  # noqa: E402
 
 
+TWIN = len(sys.argv) > 1 and sys.argv[1] == 'twin'
+
+
+class TwinComm(object):
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 2
+
+    def Barrier(self):
+        pass
+
+    def allreduce_(self, t):
+        return t.mul_(2)
+
+    def bcast_(self, t, root=0):
+        return t
+
+    def Allreduce(self, sendbuf, recvbuf, op='sum'):
+        recvbuf[...] = 2 * np.asarray(sendbuf)
+
+    def Bcast(self, buf, root=0):
+        pass
+
+
 def run(ob, ac, hid, B, per, ln, ret, nstep, d_scale, noise):
     np.random.seed(0); random.seed(0)
-    comm = TorchComm('cuda')
+    comm = TwinComm() if TWIN else TorchComm('cuda')
     env = SyntheticEnv(ob, ac, 1.0)
     hps = make_hps(batch_size=B, mem_size=4 * B + 64, prioritized_replay=per, noise_type=noise,
                    d_actor_loss_scale=d_scale, hid_widths=hid, with_layernorm=ln, rmsify_rets=ret,
@@ -52,7 +78,8 @@ def main():
     cases = []
     for (ob, ac, hid, B) in [(4, 1, (64, 64), 32), (11, 3, (64, 64), 256), (17, 6, (64, 64), 256),
                              (376, 17, (256, 256), 64), (376, 17, (400, 300), 128), (5, 2, (33, 70), 37),
-                             (50, 10, (64, 64), 32), (3, 1, (8, 8), 1), (111, 8, (256, 256), 16)]:
+                             (50, 10, (64, 64), 32), (3, 1, (8, 8), 1), (111, 8, (256, 256), 16), (17, 6, (64, 64), 512),
+                             (11, 3, (64, 64), 2048)]:
         for per in (False, True):
             for ln, ret, nstep in ((False, False, 0), (True, True, 0 if per else 5), (False, True, 0 if per else 3)):
                 cases.append((ob, ac, hid, B, per, ln, ret, nstep, 0.0 if ln else 0.5,
