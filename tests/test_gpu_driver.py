@@ -439,7 +439,7 @@ def test_schedule_packed_launch_equals_single_rows():
         assert torch.equal(a.cpu(), b.cpu())
 
 
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-retn'])
 def test_appending_transitions_between_runs(cfg_name):
     """Rollouts append transitions between training phases (sam.py:305-321): the driver notices that the
     ring geometry / entry count changed and re-captures.  Same learner state as a driver built AFTER the
@@ -447,7 +447,10 @@ def test_appending_transitions_between_runs(cfg_name):
     import bench
     from sam_tf_amd.comm import TorchComm
     from sam_tf_amd.driver import UpdateStepDriver
-    cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
+    base, _, opt = cfg_name.partition('-')
+    cfg = dict(bench.CONFIGS[base], mem=4096)
+    if opt:   # the K-row n-step lookahead buffers are rebuilt with the batches; new rows change the windows
+        cfg.update(ret=True, nstep=7, p_done=0.1)
     states = []
     for mode in ('same-driver', 'fresh-driver'):
         mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
@@ -468,6 +471,8 @@ def test_appending_transitions_between_runs(cfg_name):
             drv.run(5)
         torch.cuda.synchronize()
         extra = [rb.trees.sum, rb.trees.min] if cfg['per'] else []
+        if opt:
+            extra += [mu.ret_rms.sums]
         states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps,
                                            d.obs_rms.sums] + extra])
     for a, b in zip(*states):
