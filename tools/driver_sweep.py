@@ -38,8 +38,7 @@ class TwinComm(object):
         pass
 
 
-def main():
-    twin = len(sys.argv) > 1 and sys.argv[1] == 'twin'
+def main(twin=False, quick=False):
     shapes = [(4, 1, (64, 64), 32), (11, 3, (64, 64), 256), (20, 4, (64, 64), 48), (376, 17, (256, 256), 64),
               (5, 2, (33, 70), 37), (50, 10, (64, 64), 32), (3, 1, (8, 8), 1), (111, 8, (400, 300), 16),
               (17, 6, (64, 64), 2048), (17, 6, (64, 64), 512)]
@@ -47,7 +46,7 @@ def main():
     for ob, ac, hid, B in shapes:
         for per in (False, True):
             for ln, ret, nstep in ((False, False, 0), (True, True, 0 if per else 5), (False, True, 0 if per else 3)):
-                for graph, g_steps in ((True, 1), (True, 3), (False, 1)):
+                for graph, g_steps in (((True, 3), (False, 1)) if quick else ((True, 1), (True, 3), (False, 1))):
                     cfg = dict(ob=ob, ac=ac, h=hid, B=B, per=per, mem=max(4 * B, 512), name='sweep', ln=ln, ret=ret,
                                nstep=nstep, p_done=0.1)
                     n += 1
@@ -69,4 +68,4 @@ def main():
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    sys.exit(main(len(sys.argv) > 1 and sys.argv[1] == 'twin'))

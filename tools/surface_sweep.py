@@ -15,7 +15,7 @@ from sam_tf_amd.discriminator import Discriminator  # noqa: E402
 from sam_tf_amd.hps import make_hps, SyntheticEnv  # noqa: E402
 
 
-TWIN = len(sys.argv) > 1 and sys.argv[1] == 'twin'
+TWIN = False
 
 
 class TwinComm(object):
@@ -74,7 +74,9 @@ def run(ob, ac, hid, B, per, ln, ret, nstep, d_scale, noise):
     torch.cuda.synchronize()
 
 
-def main():
+def main(twin=False):
+    global TWIN
+    TWIN = twin
     cases = []
     for (ob, ac, hid, B) in [(4, 1, (64, 64), 32), (11, 3, (64, 64), 256), (17, 6, (64, 64), 256),
                              (376, 17, (256, 256), 64), (376, 17, (400, 300), 128), (5, 2, (33, 70), 37),
@@ -98,4 +100,4 @@ def main():
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    sys.exit(main(len(sys.argv) > 1 and sys.argv[1] == 'twin'))
