@@ -236,3 +236,67 @@ def test_nstep_lookahead_many_matches_single(name):
                                              int(g['n']), float(g['gamma']))
         assert torch.equal(end[k], e1) and torch.equal(rews[k], r1) and torch.equal(dones[k], d1) \
             and torch.equal(tl[k], t1)
+
+
+@pytest.mark.parametrize('limit,n_demos,seed', [(50, 0, 1), (100, 7, 2), (257, 20, 3), (64, 0, 4), (1000, 0, 5)])
+def test_random_op_sequences_vs_oracle(limit, n_demos, seed):
+    """Random sequences of append / sample / sample_uniform / update_priorities (duplicate indices, demo
+    rows, priorities over several orders of magnitude, ring wrap-around, non-power-of-two limits) on the HIP
+    PrioritizedRB and on the oracle (pinned on the reference's vectors) side by side: indices, both trees,
+    range sums / minima and max_priority bit for bit after every operation; IS weights to 1e-13."""
+    from oracle.replay_oracle import PrioritizedReplayOracle
+    from sam_tf_amd.memory import PrioritizedRB
+    ob, ac = 3, 2
+    alpha, beta = 0.3, 1.0
+    hip = PrioritizedRB(limit, (ob,), (ac,), alpha, beta)
+    ref = PrioritizedReplayOracle(limit, (ob,), (ac,), alpha, beta)
+    rs = np.random.RandomState(seed)
+
+    def row():
+        return (rs.randn(ob).astype(np.float32), rs.uniform(-1, 1, ac).astype(np.float32), float(rs.uniform(0, 5)),
+                rs.randn(ob).astype(np.float32), float(rs.rand() < 0.1))
+    if n_demos:
+        d = RC.Demos()
+        rows = [row() for _ in range(n_demos)]
+        d.obs0 = np.stack([r[0] for r in rows]); d.acs = np.stack([r[1] for r in rows])
+        d.env_rews = np.array([r[2] for r in rows], dtype=np.float32)
+        d.obs1 = np.stack([r[3] for r in rows]); d.dones1 = np.array([r[4] for r in rows], dtype=np.float32)
+        hip.add_demo_transitions_to_mem(d); ref.add_demo_transitions_to_mem(d)
+    for _ in range(5):
+        r = row()
+        hip.append(*r); ref.append(*r)
+
+    def same_trees(what):
+        assert np.array_equal(hip.tree_values('sum'), ref.tree_values('sum')), what
+        assert np.array_equal(hip.tree_values('min'), ref.tree_values('min')), what
+        assert hip.num_entries == ref.num_entries and float(hip.max_priority) == float(ref.max_priority), what
+
+    for step in range(60):
+        op = rs.randint(4)
+        if op == 0:
+            for _ in range(int(rs.randint(1, limit // 2 + 2))):
+                r = row()
+                hip.append(*r); ref.append(*r)
+        elif op == 1 and hip.num_entries >= 2:
+            B = int(rs.choice([1, 4, 16, 33]))
+            random.seed(1000 * seed + step); a = hip.sample(B)
+            random.seed(1000 * seed + step); b = ref.sample(B)
+            assert np.array_equal(np.asarray(a['idxs'], dtype=np.int64), np.asarray(b['idxs'], dtype=np.int64)), step
+            np.testing.assert_allclose(np.asarray(a['iws'], dtype=np.float64).ravel(), b['iws'].ravel(), rtol=1e-13)
+            assert np.array_equal(np.asarray(a['obs0']), b['obs0']) and np.array_equal(np.asarray(a['rews']), b['rews'])
+            # priorities over many orders of magnitude, with duplicate indices
+            idxs = np.asarray(b['idxs'], dtype=np.int64)
+            if B > 1:
+                idxs[-1] = idxs[0]
+            prios = np.abs(rs.randn(B)) * 10.0 ** rs.uniform(-6, 3, B) + 1e-6
+            hip.update_priorities(idxs, prios); ref.update_priorities(idxs, prios)
+        elif op == 2 and hip.num_entries >= 2:
+            np.random.seed(2000 * seed + step); a = hip.sample_uniform(8)
+            np.random.seed(2000 * seed + step); b = ref.sample_uniform(8)
+            assert np.array_equal(np.asarray(a['idxs']), np.asarray(b['idxs']))
+            assert np.array_equal(np.asarray(a['obs1']), b['obs1'])
+        else:
+            n = hip.num_entries
+            lo = int(rs.randint(0, n)); hi = int(rs.randint(lo + 1, n + 1))   # [lo, hi): never empty
+            assert hip.tree_sum(lo, hi) == ref.tree_sum(lo, hi) and hip.tree_min(lo, hi) == ref.tree_min(lo, hi)
+        same_trees((step, op))
