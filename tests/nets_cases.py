@@ -11,6 +11,13 @@ CONFIGS = {
     'C4': (376, 17, 256, 256, 1024),
     'C5': (376, 17, 400, 300, 8192),
     'ragged': (5, 2, 33, 70, 37),   # nothing a multiple of a tile
+    # whole-network path away from the benchmark shapes: 1-wide inputs, widths not a multiple of 4 (the
+    # padded k4 rows of the LDS weight tiles), the widest input that fits, one tile, many tiles
+    's_1x1': (1, 1, 64, 64, 16),
+    's_2x1': (2, 1, 64, 64, 16),
+    's_7x5': (7, 5, 64, 64, 80),
+    's_20x4': (20, 4, 64, 64, 48),
+    's_13x2': (13, 2, 64, 64, 1024),
 }
 
 

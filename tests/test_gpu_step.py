@@ -67,11 +67,14 @@ def _oracle(c, d_scale, ent, per, rms=True):
     ('C4', 0.0, 0.0, False, True, False),
     # with_layernorm (launcher default, mujoco_sam_imitate.sh): layer-wise path, two-stream GP backward
     ('C2', 0.5, 1e-3, True, True, True), ('ragged', 0.5, 0.0, False, True, True),
-    ('C4', 0.0, 0.0, False, True, True)])
+    ('C4', 0.0, 0.0, False, True, True),
+    ('s_1x1', 0.5, 0.0, False, True, False), ('s_2x1', 0.0, 1e-3, True, True, False),
+    ('s_7x5', 0.5, 1e-3, True, False, False), ('s_20x4', 0.5, 0.0, False, True, False),
+    ('s_13x2', 0.0, 0.0, True, True, False)])
 def test_step_grads_vs_oracle(name, d_scale, ent, per, rms, ln):
     from sam_tf_amd import ops
     c, L, batch, out = _setup(name, d_scale, ent, per, rms, ln)
-    assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3') and not ln)
+    assert L.fused(c['B']) == ((name in ('C1', 'C2', 'C3') or name.startswith('s_')) and not ln)
     exp = _oracle(c, d_scale, ent, per, rms)
     ops.step_grads(L, batch, out)
     torch.cuda.synchronize()
