@@ -144,7 +144,8 @@ class OracleLearner(object):
 
 @pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
-                                      'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper'])
+                                      'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper', 'ragged-launcher',
+                                      'raggedper-ret'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
@@ -158,7 +159,10 @@ def test_k_steps_match_oracle(cfg_name, graph):
              'edge64': dict(ob=20, ac=4, h=(64, 64), B=32, per=True, name='edge'),
              # whole-network path with 2*B*ob beyond what the one-workgroup D-input sums kernels hold
              'bigB': dict(ob=17, ac=6, h=(64, 64), B=512, per=False, name='big-batch'),
-             'bigBper': dict(ob=17, ac=6, h=(64, 64), B=512, per=True, name='big-batch-per')}
+             'bigBper': dict(ob=17, ac=6, h=(64, 64), B=512, per=True, name='big-batch-per'),
+             # nothing a multiple of a tile, on the layer-wise path with the launcher's options
+             'ragged': dict(ob=5, ac=2, h=(33, 70), B=37, per=False, name='ragged'),
+             'raggedper': dict(ob=5, ac=2, h=(33, 70), B=37, per=True, name='ragged-per')}
     # ret / retn / nstep: the argparse-default options (rmsify_rets + PopArt, n-step returns) WITHOUT
     # LayerNorm: whole-network path with the targets in their own launch
     cfg = dict(extra.get(base) or bench.CONFIGS[base], mem=2048, ln=opt in ('ln', 'launcher'),
@@ -166,9 +170,9 @@ def test_k_steps_match_oracle(cfg_name, graph):
                p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
     if base in extra:
-        assert drv.fused == (base != 'widein')
+        assert drv.fused == (base not in ('widein', 'ragged', 'raggedper'))
         assert drv.sums_small == (not base.startswith('bigB'))
-    elif opt:
+    if opt and base not in extra:
         assert drv.fused == (opt in ('ret', 'retn', 'nstep'))
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
