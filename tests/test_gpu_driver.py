@@ -724,3 +724,42 @@ def test_rollout_calls_at_batch_one(cfg_name):
                        mu.ac_high, ops.nets_ws(mu.da, mu.dc, None, 16), want_q=True, ret=mu.ret)
     assert relerr(a0, ab[0].cpu().numpy()) < 1e-5 and abs(q0 - float(qb[0].item())) <= 1e-5 * max(1.0, abs(q0))
     mu.store_transition(obs[0], a0, 1.0, obs[1], False)
+
+
+@pytest.mark.parametrize('world', [1, 2])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C1-retn', 'C1-launcher', 'ragged-retn'])
+def test_agent_train_matches_oracle(cfg_name, world):
+    """SAMAgent.train() + update_target_net() — the drop-in path through the per-role entry points, with
+    the communicator's Allreduce in ret_rms.update and MpiAdam at world 2 — against the same oracle as the
+    driver: losses, returned clipped gradients' norm bound, parameters and return statistics over 3 updates."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    base, _, opt = cfg_name.partition('-')
+    cfg = (dict(ob=5, ac=2, h=(33, 70), B=37, per=False, name='ragged') if base == 'ragged'
+           else dict(bench.CONFIGS[base]))
+    cfg.update(mem=1024, ln=opt == 'launcher', ret=bool(opt), nstep=7 if opt else 0, p_done=0.1)
+    comm = _TwinComm() if world == 2 else TorchComm('cuda')
+    mu, d, pool, _ = bench.build_learner(cfg, comm, torch.device('cuda', 0), 9, False)
+    ref = OracleLearner(mu, d, pool, False, world=world)
+    B, N = cfg['B'], mu.replay_buffer.num_entries
+    for k in range(3):
+        np.random.seed(500 + k)
+        idx = np.random.randint(low=0, high=N, size=B)   # what RB.sample draws first (memory.py:90)
+        np.random.seed(500 + k)
+        out = mu.train()
+        mu.update_target_net()
+        exp = ref.a_step(idx_a=idx)
+        floor = 1.0 if opt else 1e-3
+        for name in ('actor_losses', 'critic_losses'):
+            got, want = np.asarray(out[name], dtype=np.float64), np.asarray(exp[name], dtype=np.float64)
+            if name == 'critic_losses' and len(want) == 4:   # train() returns the reference's order: td1, tdn, wd, total
+                want = want[[0, 3, 1, 2]]
+            assert np.max(np.abs(got - want) / np.maximum(np.abs(want), floor if name == 'actor_losses' else 1e-3)) \
+                < 1e-5, (name, k, got, want)
+        assert np.linalg.norm(out['actor_grads']) <= mu.hps.clip_norm * (1 + 1e-5)
+    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
+    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
+    assert relerr(mu.targ_actor.get_flat(), ref.pa_t) < 1e-5
+    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
+    if opt:
+        assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
