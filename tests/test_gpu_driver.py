@@ -763,3 +763,37 @@ def test_agent_train_matches_oracle(cfg_name, world):
     assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
     if opt:
         assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
+
+
+@pytest.mark.parametrize('world', [1, 2])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C1-ln', 'ragged', 'C4small'])
+def test_discriminator_feed_path_matches_oracle(cfg_name, world):
+    """The reference-shaped discriminator calls of sam.py:372-402 — obs_rms.update(batch, comm), then
+    optimize(feeds) — against the oracle's D update at world 1 and 2 (the randoms the call drew are
+    re-drawn from the saved generator state), parameters and statistics after 3 updates."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    base, _, opt = cfg_name.partition('-')
+    shapes = {'ragged': dict(ob=5, ac=2, h=(33, 70), B=37, per=False, name='ragged'),
+              'C4small': dict(ob=376, ac=17, h=(256, 256), B=48, per=False, name='humanoid-small-batch')}
+    cfg = dict(shapes.get(base) or bench.CONFIGS[base], mem=1024, ln=opt == 'ln')
+    comm = _TwinComm() if world == 2 else TorchComm('cuda')
+    mu, d, pool, _ = bench.build_learner(cfg, comm, torch.device('cuda', 0), 4, False)
+    ref = OracleLearner(mu, d, pool, False, world=world)
+    B, N = cfg['B'], mu.replay_buffer.num_entries
+    h = lambda t: t.cpu().numpy()
+    for k in range(3):
+        idx = np.random.RandomState(700 + k).randint(0, N, B)
+        rows = ref.rows(idx)
+        e_obs, e_acs = h(pool.obs0[k * B:(k + 1) * B]), h(pool.acs[k * B:(k + 1) * B])
+        feeds = {d.p_obs: rows['obs0'], d.p_acs: rows['acs'], d.e_obs: e_obs, d.e_acs: e_acs}
+        d.obs_rms.update(np.concatenate((feeds[d.p_obs], feeds[d.e_obs])), comm)
+        state = d.gen.get_state()
+        d.optimize(feeds)
+        d.gen.set_state(state)
+        eps_ob, eps_ac, real, fake = d.draw_randoms(B)
+        assert fake is None
+        ref.d_step(idx, e_obs, e_acs, h(eps_ob), h(eps_ac), h(real) if real is not None else np.ones(B))
+    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
+    assert relerr(d.optimizer.m.cpu().numpy(), ref.opt['d'][0]) < 1e-5
