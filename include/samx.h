@@ -403,12 +403,15 @@ size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
 /* Head of a prioritized-replay row in ONE launch: workgroup 0 applies the pending priority update to both
  * trees (= samx_tree_set with n_upd < 1024: memory.py:373-379 of the PREVIOUS agent update), workgroup 1
  * computes the D-input sums of this row (= samx_d_input_stats with commit = 0: sam.py:389-390).  The two
- * do not depend on each other. */
+ * do not depend on each other.  u != NULL: workgroup 0 goes on, on the updated trees, with this row's
+ * stratified sample and importance weights (= samx_per_sample with the same arguments: memory.py:266-309)
+ * while workgroup 1 still adds. */
 int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
                           const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
                           const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
-                          void* stream);
+                          int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
+                          float* iws_f32_out, void* stream);
 
 /* a[n] (float) and b[n] (int64) to PINNED HOST memory (device-accessible) in one launch: the refreshed TD
  * errors and the sampled indices a prioritized-replay row hands back to the host (sam_agent.py:693-703). */

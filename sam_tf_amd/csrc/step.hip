@@ -263,9 +263,15 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
     const int64_t* __restrict__ upd_idx, const double* __restrict__ upd_leaf, int n_upd, int levels,
     const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
-    const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec) {
+    const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
+    int64_t n_ent, const double* __restrict__ u, double beta, int64_t* __restrict__ idxs_out,
+    double* __restrict__ iws_out, float* __restrict__ iws32_out) {
     if (blockIdx.x == 0) {
         samx::tree_set_body(ts, tm, stamp, cap, upd_idx, upd_leaf, n_upd, levels);
+        if (u) {   // ... and, on the updated trees, this row's stratified sample (memory.py:266-309)
+            __syncthreads();
+            samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, 0, B);
+        }
     } else {
         d_input_stats_body(0, replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, dim, dimpad, addvec,
                            0, nullptr, nullptr, nullptr, 0, 0);
@@ -427,7 +433,8 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
                           const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
                           const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
-                          void* stream) {
+                          int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
+                          float* iws_f32_out, void* stream) {
     SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && upd_leaf, "samx_per_row_prologue: null tree argument");
     SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_row_prologue: cap %lld is not a power of two",
                  (long long)cap);
@@ -438,13 +445,15 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
                  (long long)(2 * B * ob_dim));
     SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_per_row_prologue: bad ring geometry");
+    SAMX_REQUIRE(!u || (idxs_out && iws_out && num_entries >= 2 && num_entries <= cap && beta > 0),
+                 "samx_per_row_prologue: sampling needs idxs_out, iws_out, num_entries in [2, cap] and beta > 0");
     int levels = 0;
     while ((int64_t(1) << levels) < cap) ++levels;
     int dimpad = 1;
     while (dimpad < ob_dim) dimpad *= 2;
     per_row_prologue_kernel<<<2, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
         sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, (int)n_upd, levels, replay_obs0, ring_start, ring_len,
-        p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec);
+        p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, num_entries, u, beta, idxs_out, iws_out, iws_f32_out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

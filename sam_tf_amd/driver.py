@@ -320,10 +320,11 @@ class UpdateStepDriver(object):
                 if (self.per_graph_io and K == 1 and roles[0] == self.D | self.A and self.inline_stats
                         and self.B < 1024 and self.sums_small):
                     # pending priority update and this row's D-input sums: one launch, two workgroups
+                    # ... and workgroup 0 goes on with the row's stratified sample on the updated trees
                     ops.per_row_prologue(rb.trees, self.prev_idx, self.prev_leaf, rb.store['obs0'],
-                                         self._batch_start, self.words[0], self.B, self.pool.obs0, self.addvecs[0])
-                    rb.trees.per_sample(rb.num_entries, self.u, self.mu.hps.beta, idxs_out=self.idx_a,
-                                        iws_out=self.iws, iws32_out=self.iws32)
+                                         self._batch_start, self.words[0], self.B, self.pool.obs0, self.addvecs[0],
+                                         sample=(rb.num_entries, self.u, self.mu.hps.beta, self.idx_a, self.iws,
+                                                 self.iws32))
                     self._seg_grads(0, roles[0], trees_done=True)
                 else:
                     if any_d:

@@ -582,17 +582,25 @@ def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
                                       ptr(addvecs), 2 * ob + 1, K, stream_ptr()))
 
 
-def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec):
+def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec,
+                     sample=None):
     """Pending priority update (trees.set) + the row's D-input sums in one launch (samx_per_row_prologue).
-    words_row: int64 [W] with idx_p at [:B] and e_start at [2B]; addvec: float64 [2*ob+1]."""
+    words_row: int64 [W] with idx_p at [:B] and e_start at [2B]; addvec: float64 [2*ob+1].
+    sample = (num_entries, u f64[B], beta, idxs_out i64[B], iws_out f64[B], iws32_out f32[B] or None): the
+    row's stratified sample on the updated trees in the same launch."""
     ring_len, ob = replay_obs0.shape
     n = upd_idx.numel()
     _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_leaf, F64, (n,), 'upd_leaf')
     _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+    n_ent, u, beta, idxs_out, iws_out, iws32_out = sample if sample is not None else (0, None, 1.0, None, None, None)
+    if sample is not None:
+        _chk(u, F64, (B,), 'u'); _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out')
+        _opt(iws32_out, F32, (B,), 'iws32_out')
     check(_L().samx_per_row_prologue(ptr(trees.sum), ptr(trees.min), ptr(trees.stamp), trees.cap, ptr(upd_idx),
                                      ptr(upd_leaf), n, ptr(replay_obs0), int(ring_start), int(ring_len),
                                      C.c_void_p(words_row.data_ptr()), ptr(pool_obs0),
                                      C.c_void_p(words_row.data_ptr() + 8 * 2 * B), int(B), int(ob), ptr(addvec),
+                                     int(n_ent), ptr(u), float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out),
                                      stream_ptr()))
 
 
