@@ -405,13 +405,18 @@ size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
  * computes the D-input sums of this row (= samx_d_input_stats with commit = 0: sam.py:389-390).  The two
  * do not depend on each other.  u != NULL: workgroup 0 goes on, on the updated trees, with this row's
  * stratified sample and importance weights (= samx_per_sample with the same arguments: memory.py:266-309)
- * while workgroup 1 still adds. */
+ * while workgroup 1 still adds.  copy_src != NULL: before anything else both workgroups copy copy_n
+ * int64 words from copy_src (pinned, device-accessible host memory: the row's host-drawn numbers) to copy_dst
+ * (device) — every other input pointer may point into copy_dst; this replaces a separate upload.  Words
+ * [copy_skip_lo, copy_skip_lo + copy_skip_n) are not copied: an output of this launch that lives inside
+ * copy_dst (idxs_out) must lie there. */
 int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
                           const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
                           const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
                           int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
-                          float* iws_f32_out, void* stream);
+                          float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
+                          int64_t copy_skip_lo, int64_t copy_skip_n, void* stream);
 
 /* a[n] (float) and b[n] (int64) to PINNED HOST memory (device-accessible) in one launch: the refreshed TD
  * errors and the sampled indices a prioritized-replay row hands back to the host (sam_agent.py:693-703). */

@@ -265,7 +265,17 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
     const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
     int64_t n_ent, const double* __restrict__ u, double beta, int64_t* __restrict__ idxs_out,
-    double* __restrict__ iws_out, float* __restrict__ iws32_out) {
+    double* __restrict__ iws_out, float* __restrict__ iws32_out, const int64_t* __restrict__ copy_src,
+    int64_t* copy_dst, int64_t copy_n, int64_t skip_lo, int64_t skip_n) {
+    if (copy_src) {
+        // the row's host-drawn words (pinned host memory) -> their device home, by BOTH workgroups (same
+        // values to the same addresses; each then reads what it wrote itself): no separate upload node.
+        // Words [skip_lo, skip_lo + skip_n) are left alone: an OUTPUT of this launch may live there (the
+        // sampled indices), and the other workgroup's copy could land after it was written.
+        for (int64_t t = threadIdx.x; t < copy_n; t += 1024)
+            if (t < skip_lo || t >= skip_lo + skip_n) copy_dst[t] = copy_src[t];
+        __syncthreads();
+    }
     if (blockIdx.x == 0) {
         samx::tree_set_body(ts, tm, stamp, cap, upd_idx, upd_leaf, n_upd, levels);
         if (u) {   // ... and, on the updated trees, this row's stratified sample (memory.py:266-309)
@@ -434,7 +444,8 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
                           const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
                           int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
-                          float* iws_f32_out, void* stream) {
+                          float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
+                          int64_t copy_skip_lo, int64_t copy_skip_n, void* stream) {
     SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && upd_leaf, "samx_per_row_prologue: null tree argument");
     SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_row_prologue: cap %lld is not a power of two",
                  (long long)cap);
@@ -445,6 +456,12 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
                  (long long)(2 * B * ob_dim));
     SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_per_row_prologue: bad ring geometry");
+    SAMX_REQUIRE(!copy_src || (copy_dst && copy_n > 0 && copy_n <= (1 << 20) && copy_skip_lo >= 0 &&
+                               copy_skip_n >= 0),
+                 "samx_per_row_prologue: copy_src needs copy_dst, 1 <= copy_n <= 2^20 and a non-negative skip range");
+    SAMX_REQUIRE(!(copy_src && idxs_out) || idxs_out + B <= copy_dst || idxs_out >= copy_dst + copy_n ||
+                     (idxs_out >= copy_dst + copy_skip_lo && idxs_out + B <= copy_dst + copy_skip_lo + copy_skip_n),
+                 "samx_per_row_prologue: idxs_out inside copy_dst must lie in the skipped range");
     SAMX_REQUIRE(!u || (idxs_out && iws_out && num_entries >= 2 && num_entries <= cap && beta > 0),
                  "samx_per_row_prologue: sampling needs idxs_out, iws_out, num_entries in [2, cap] and beta > 0");
     int levels = 0;
@@ -453,7 +470,8 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
     while (dimpad < ob_dim) dimpad *= 2;
     per_row_prologue_kernel<<<2, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
         sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, (int)n_upd, levels, replay_obs0, ring_start, ring_len,
-        p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, num_entries, u, beta, idxs_out, iws_out, iws_f32_out);
+        p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, num_entries, u, beta, idxs_out, iws_out, iws_f32_out,
+        copy_src, copy_dst, copy_n, copy_skip_lo, copy_skip_n);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -314,17 +314,21 @@ class UpdateStepDriver(object):
             # (forking the D-input sums beside the PER tree work as a second graph branch was measured:
             # 8.1 k -> 7.1 k steps/s at C3 — a two-branch hipGraph costs more to launch than it overlaps)
             def run():
-                if self.per_graph_io:
-                    self.words[:1].copy_(self._launch_words, non_blocking=True)
                 rb = self.mu.replay_buffer
-                if (self.per_graph_io and K == 1 and roles[0] == self.D | self.A and self.inline_stats
-                        and self.B < 1024 and self.sums_small):
+                in_prologue = (self.per_graph_io and K == 1 and roles[0] == self.D | self.A and self.inline_stats
+                               and self.B < 1024 and self.sums_small)
+                if self.per_graph_io and not in_prologue:
+                    self.words[:1].copy_(self._launch_words, non_blocking=True)
+                if in_prologue:
                     # pending priority update and this row's D-input sums: one launch, two workgroups
                     # ... and workgroup 0 goes on with the row's stratified sample on the updated trees
                     ops.per_row_prologue(rb.trees, self.prev_idx, self.prev_leaf, rb.store['obs0'],
                                          self._batch_start, self.words[0], self.B, self.pool.obs0, self.addvecs[0],
                                          sample=(rb.num_entries, self.u, self.mu.hps.beta, self.idx_a, self.iws,
-                                                 self.iws32))
+                                                 self.iws32),
+                                         # the row's host-drawn words come straight from pinned host memory
+                                         # (all but idx_a, which the sampling writes): no upload node
+                                         upload=(self._launch_words.view(-1), self.words[0], self.B, self.B))
                     self._seg_grads(0, roles[0], trees_done=True)
                 else:
                     if any_d:

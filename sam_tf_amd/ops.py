@@ -583,11 +583,21 @@ def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
 
 
 def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec,
-                     sample=None):
+                     sample=None, upload=None):
     """Pending priority update (trees.set) + the row's D-input sums in one launch (samx_per_row_prologue).
     words_row: int64 [W] with idx_p at [:B] and e_start at [2B]; addvec: float64 [2*ob+1].
     sample = (num_entries, u f64[B], beta, idxs_out i64[B], iws_out f64[B], iws32_out f32[B] or None): the
-    row's stratified sample on the updated trees in the same launch."""
+    row's stratified sample on the updated trees in the same launch.  upload = (pinned int64 host tensor,
+    device int64 tensor of the same size, skip_lo, skip_n): copied host -> device by the kernel before it reads
+    anything, except words [skip_lo, skip_lo + skip_n) (where idxs_out may live); the other arguments may be
+    views of the device tensor."""
+    src = dst = None
+    n_copy = skip_lo = skip_n = 0
+    if upload is not None:
+        src, dst, skip_lo, skip_n = upload
+        assert src.is_pinned() and dst.is_cuda and src.dtype == dst.dtype == I64 and src.numel() == dst.numel()
+        assert src.is_contiguous() and dst.is_contiguous()
+        n_copy = src.numel()
     ring_len, ob = replay_obs0.shape
     n = upd_idx.numel()
     _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_leaf, F64, (n,), 'upd_leaf')
@@ -601,6 +611,7 @@ def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_ro
                                      C.c_void_p(words_row.data_ptr()), ptr(pool_obs0),
                                      C.c_void_p(words_row.data_ptr() + 8 * 2 * B), int(B), int(ob), ptr(addvec),
                                      int(n_ent), ptr(u), float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out),
+                                     ptr(src), ptr(dst), int(n_copy), int(skip_lo), int(skip_n),
                                      stream_ptr()))
 
 
