@@ -47,6 +47,7 @@ class _Slot(object):
         self.words = torch.empty(K, self.W, dtype=torch.int64).pin_memory()
         # numpy views of the pinned words: the host fills them without going through torch ops
         w = self.words.numpy()
+        self.np_words = w
         self.np_idx = w[:, :2 * B].reshape(K, 2, B)   # [k][0] = idx_p, [k][1] = idx_a
         self.np_idx_p, self.np_idx_a, self.np_e = w[:, :B], w[:, B:2 * B], w[:, 2 * B]
         self.np_u = w[:, 2 * B + 1:3 * B + 1].view(np.float64)
@@ -133,11 +134,13 @@ class UpdateStepDriver(object):
         self._td_host = torch.empty(B, dtype=torch.float32).pin_memory()
         self._idx_host = torch.empty(B, dtype=torch.int64).pin_memory()
         self._leaf_np = np.empty(B, dtype=np.float64)
+        self._td_host_np, self._idx_host_np = self._td_host.numpy(), self._idx_host.numpy()
         # PER, one process: the row's H2D upload and the D2H of the refreshed TD errors are nodes of the
         # captured graph (fixed pinned buffers; the host waits for every row anyway), which leaves ONE
         # host call — the graph launch — between two rows' host arithmetic
         self.per_graph_io = bool(self.per and self.use_graph and self.world == 1)
         self._launch_words = torch.zeros(1, self.W, dtype=torch.int64).pin_memory()
+        self._launch_np = self._launch_words.numpy()
         self.slots = [_Slot(B, self.K) for _ in range(n_slots)]
         self.step_no = 0     # rows done
         self.launch_no = 0
@@ -512,7 +515,7 @@ class UpdateStepDriver(object):
             self.flush()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
-        self._launch_words.copy_(slot.words[:1])
+        np.copyto(self._launch_np, slot.np_words[:1])
         torch.cuda.synchronize()
         self.plans[(K, phase)] = self._build_plan(K, phase)
         torch.cuda.synchronize()
@@ -549,7 +552,7 @@ class UpdateStepDriver(object):
         slot = self.slots[self.launch_no % len(self.slots)]
         self._draw(slot, K, phase)
         if self.per_graph_io:
-            self._launch_words.copy_(slot.words[:1])   # host memcpy pinned -> pinned; the graph uploads it
+            np.copyto(self._launch_np, slot.np_words[:1])   # host memcpy pinned -> pinned; the graph uploads it
         else:
             self._upload(slot, K)
         for run in self.plans[(K, phase)]:
@@ -570,8 +573,8 @@ class UpdateStepDriver(object):
                 torch.cuda.current_stream().synchronize()
                 # |td| + 1e-6 in float32 (sam_agent.py:702), the reference's asserts, leaves = libm pow on
                 # the host (one C call); the trees are updated on the device by the next agent row
-                idxs = self._idx_host.numpy().copy()
-                leaf = self.mu.replay_buffer.leaves_from_td(idxs, self._td_host.numpy(), self._leaf_np).copy()
+                idxs = self._idx_host_np.copy()
+                leaf = self.mu.replay_buffer.leaves_from_td(idxs, self._td_host_np, self._leaf_np).copy()
                 self._pending = (idxs, leaf)
         self.step_no += K
         self.launch_no += 1
