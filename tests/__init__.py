@@ -1,0 +1,1 @@
+"""Parity and host-logic tests."""
