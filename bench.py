@@ -283,32 +283,54 @@ def main():
     #   3. those RCCL all-reduces captured INSIDE the K-step hipGraph.
     # No multi-GPU box was available while this was written: plans 2 and 3 run under a watchdog, and if
     # they do not come back the rank reports the measurement it already has instead of hanging the job.
-    drv.set_collectives(False)
-    el = timed()
-    passes = time_passes(drv, cfg)
-    result = result_for(el, passes, 'none' if world == 1 else 'torch.distributed all_reduce between graph segments')
+    # Every N > 1 stage runs under a watchdog.  A stage that hangs or raises is never silent: the line gets a
+    # top-level "degraded" (= "failed_stage") field naming it, and the process exits non-zero (3) when not even
+    # the plain torch.distributed plan completed — then `value` is null.  When only one of the optional faster
+    # plans failed, the line carries the measurement of the plans that did complete, "degraded" says which
+    # stage was lost, and the exit code is 0 unless SAMX_BENCH_STRICT=1.
     import threading
     stage = ['']
+    result = None
+    strict = os.environ.get('SAMX_BENCH_STRICT') == '1'
+
+    def degraded_exit(why):
+        """Print what there is (rank 0), flagged, and end this rank."""
+        line = result if result is not None else {
+            'metric': 'SAM update steps/sec (actor+critic+disc, batch %d)' % cfg['B'], 'value': None,
+            'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.config}}
+        line['degraded'] = line['failed_stage'] = '%s: %s' % (stage[0], why)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        os._exit(3 if (result is None or strict) else 0)
 
     def watchdog(seconds, what):
-        """Past `seconds`, rank 0 prints the measurement it has (with a note) and every rank exits."""
         stage[0] = what
-
-        def bail():
-            if rank == 0:
-                result['config']['collectives'] += ' (%s did not complete: watchdog)' % stage[0]
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-        t = threading.Timer(seconds, bail)
+        t = threading.Timer(seconds, lambda: degraded_exit('did not complete within %.0f s (watchdog)' % seconds))
         t.daemon = True
         t.start()
         return t
 
+    wd_s = float(os.environ.get('SAMX_BENCH_WATCHDOG_S', '120'))
+    drv.set_collectives(False)
+    dog = watchdog(wd_s + 0.05 * (args.steps + args.warmup), 'plan with torch.distributed all_reduce') if world > 1 else None
+    try:
+        el = timed()
+    except Exception as e:  # noqa: BLE001
+        if world == 1:
+            raise
+        degraded_exit('%s: %s' % (type(e).__name__, str(e)[:200]))
+    if dog:
+        dog.cancel()
+    passes = time_passes(drv, cfg)
+    result = result_for(el, passes, 'none' if world == 1 else 'torch.distributed all_reduce between graph segments')
+
     if world > 1 and os.environ.get('SAMX_RCCL_DIRECT', '1') != '0':
-        dog = watchdog(float(os.environ.get('SAMX_BENCH_WATCHDOG_S', '120')), 'direct RCCL set-up')
+        dog = watchdog(wd_s, 'direct RCCL set-up')
         try:
             tried = {'torch_distributed': el}
-            if comm.enable_direct():   # all ranks or none
+            if comm.enable_direct():   # all ranks or none (agreed in stages, sam_tf_amd/comm.py)
                 stage[0] = 'plan with host-issued direct RCCL'
                 labels = {'host_issued_rccl': 'rccl on the launch stream, issued by the host between graph segments',
                           'in_graph_rccl': 'rccl all-reduces captured inside the %d-step hipGraph' % drv.K}
@@ -324,13 +346,21 @@ def main():
                 for k, v in tried.items():
                     if k != best:
                         result['config']['ms_per_step_' + k] = v / args.steps * 1e3
+            else:
+                result['config']['direct_rccl'] = 'unavailable: ' + str(getattr(comm, 'direct_error', ''))[:160]
             dog.cancel()
-        except Exception as e:  # noqa: BLE001 - keep the measurement we have; other ranks' watchdogs end them
+        except Exception as e:  # noqa: BLE001 - the measurement we have is printed, flagged; peers' watchdogs end them
             dog.cancel()
-            result['config']['collectives'] += ' (%s failed: %s)' % (stage[0], str(e)[:120])
-            if rank == 0:
-                print(json.dumps(result), flush=True)
-            os._exit(0)
+            degraded_exit('%s: %s' % (type(e).__name__, str(e)[:200]))
+    if world > 1:
+        # which collective implementation the numbers belong to
+        info = {k: os.environ.get(k) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS',
+                                               'RCCL_MSCCL_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY')}
+        try:
+            info['rccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            info['rccl_version'] = None
+        result['config']['rccl'] = info
     if world == 1 and not args.no_training_step and not rehearse:
         # the reference's loop runs d_steps = 1 discriminator update and g_steps = 3 agent
         # updates per training step (mujoco_sam_imitate.sh:26-27); `value` above is the 1:1 step of the
@@ -350,7 +380,7 @@ def main():
         # step pays in series is the first entry at or above this config's gradient bucket)
         lat = {}
         dog = watchdog(60.0, 'all-reduce latency sweep')
-        for nbytes in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+        for nbytes in (1 << 8, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
             buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
             for _ in range(10):
                 comm.allreduce_(buf)
@@ -369,7 +399,13 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
-        bye = threading.Timer(30.0, lambda: os._exit(0))   # the line is out: a stuck teardown must not hold the job
+        # the line is out and complete: a stuck teardown must not hold the job; it is reported on stderr
+        # (and by exit code 4 under SAMX_BENCH_STRICT=1)
+        def stuck():
+            sys.stderr.write('bench.py: rank %d: communicator teardown did not complete in 30 s\n' % rank)
+            sys.stderr.flush()
+            os._exit(4 if strict else 0)
+        bye = threading.Timer(30.0, stuck)
         bye.daemon = True
         bye.start()
         if comm.direct is not None:

@@ -16,13 +16,18 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-fno-fast-math', '-Wall', '-Wno-unused-function'] + os.environ.get('SAMX_EXTRA_FLAGS', '').split()
 
 
+def _sources():
+    """What the build depends on: the HIP sources and headers only (not objects or compiler by-products)."""
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    deps.append(os.path.join(HERE, '..', 'include', 'samx.h'))
+    return deps
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(HERE, '..', 'include', 'samx.h'))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _sources())
 
 
 def build(force=False, verbose=True):
@@ -38,10 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(obj)
         if (not force and os.path.exists(obj) and
-                os.path.getmtime(obj) > max(os.path.getmtime(os.path.join(CSRC, f))
-                                            for f in os.listdir(CSRC) if not f.endswith('.o'))
-                and os.path.getmtime(obj) > os.path.getmtime(
-                    os.path.join(HERE, '..', 'include', 'samx.h'))):
+                os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _sources())):
             continue
         cmd = [hipcc] + FLAGS + ['-c', path, '-o', obj]
         if verbose:

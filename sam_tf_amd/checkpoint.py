@@ -23,7 +23,10 @@ def save_learner(path, mu, d):
         blob['ret_sums'] = mu.ret_rms.sums.cpu().numpy()
     if mu.d_params is not None and not mu.hps.tie_actor_reward_net:  # the agent's own frozen reward net
         blob['actor_reward_params'] = mu.d_params.cpu().numpy()
-    np.savez(path, **blob)
+    # through an open handle: np.savez(path) would append '.npz' to a path without that suffix and
+    # load_learner(path) with the same string would then miss the file
+    with open(path, 'wb') as f:
+        np.savez(f, **blob)
 
 
 def load_learner(path, mu, d):

@@ -19,26 +19,25 @@ class TorchComm(object):
         self.active = dist.is_available() and dist.is_initialized()
         self.device = device
         self.direct = None   # sam_tf_amd.rccl.RcclComm once enable_direct() succeeded
+        self.direct_error = None
 
     def enable_direct(self):
         """Device all-reduces go through librccl on the caller's stream (capturable into hipGraphs)
-        instead of the process group's side stream.  Returns True on success; on any failure the
-        communicator keeps using torch.distributed."""
+        instead of the process group's side stream.  Returns True on success on ALL ranks; otherwise every
+        rank keeps using torch.distributed.  The all-ranks-or-none agreement is reached stage by stage
+        inside RcclComm's constructor (library / id, communicator rendezvous, probe), so a rank that
+        fails locally never leaves its peers waiting in a different collective; `direct_error` keeps
+        the reason."""
+        self.direct_error = None
         if not (self.active and self.Get_size() > 1 and dist.get_backend() == 'nccl'):
+            self.direct_error = 'needs an initialised nccl process group with more than one rank'
             return False
         try:
             from .rccl import RcclComm
             self.direct = RcclComm(self.device if self.device is not None else torch.device('cuda'))
-        except Exception as e:  # noqa: BLE001 - any failure means: stay on torch.distributed
+        except Exception as e:  # noqa: BLE001 - agreed by all ranks inside RcclComm: stay on torch.distributed
             print('sam_tf_amd.comm: direct RCCL unavailable (%s); using torch.distributed' % (e,), flush=True)
-            self.direct = None
-        # all ranks or none: a rank that fell back while the others did not would wait in a different
-        # communicator from theirs
-        ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32,
-                          device=self.device if self.device is not None else 'cuda')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and self.direct is not None:
-            self.direct.destroy()
+            self.direct_error = str(e)
             self.direct = None
         return self.direct is not None
 

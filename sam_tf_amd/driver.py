@@ -141,7 +141,13 @@ class UpdateStepDriver(object):
         self.per_graph_io = bool(self.per and self.use_graph and self.world == 1)
         self._launch_words = torch.zeros(1, self.W, dtype=torch.int64).pin_memory()
         self._launch_np = self._launch_words.numpy()
+        # the captured graph reads _launch_words asynchronously: this event, recorded behind every launch,
+        # is waited for before the host overwrites the buffer (rows without an agent update do not end in
+        # a stream synchronisation of their own)
+        self._launch_event = torch.cuda.Event()
+        self._launch_busy = False
         self.slots = [_Slot(B, self.K) for _ in range(n_slots)]
+        self._warm_slot = _Slot(B, self.K)   # prepare()'s own staging: never holds pre-drawn words
         self.step_no = 0     # rows done
         self.launch_no = 0
         self.plans = {}
@@ -504,7 +510,7 @@ class UpdateStepDriver(object):
         saved = [t.clone() for t in keep]
         rng_np, rng_py = np.random.get_state(), _random.getstate()
         ptr0 = self.pool.pointer
-        slot = self.slots[0]
+        slot = self._warm_slot
         # warm-up indices: drawn without touching the expert-pool order
         if slot.used:
             slot.event.synchronize()
@@ -515,8 +521,9 @@ class UpdateStepDriver(object):
             self.flush()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
+        torch.cuda.synchronize()   # nothing in flight reads _launch_words any more
+        self._launch_busy = False
         np.copyto(self._launch_np, slot.np_words[:1])
-        torch.cuda.synchronize()
         self.plans[(K, phase)] = self._build_plan(K, phase)
         torch.cuda.synchronize()
         for t, sv in zip(keep, saved):
@@ -552,11 +559,16 @@ class UpdateStepDriver(object):
         slot = self.slots[self.launch_no % len(self.slots)]
         self._draw(slot, K, phase)
         if self.per_graph_io:
+            if self._launch_busy:   # the previous launch may still be reading the buffer (D-only rows)
+                self._launch_event.synchronize()
             np.copyto(self._launch_np, slot.np_words[:1])   # host memcpy pinned -> pinned; the graph uploads it
         else:
             self._upload(slot, K)
         for run in self.plans[(K, phase)]:
             run()
+        if self.per_graph_io:
+            self._launch_event.record()
+            self._launch_busy = True
         if self.per:
             refresh = bool(role & self.A)
             if refresh and not self.per_graph_io:

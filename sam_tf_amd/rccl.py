@@ -47,47 +47,103 @@ class RcclError(RuntimeError):
     pass
 
 
-def _check(rc, what):
+def _check(rc, what, lib=None):
     if rc != 0:
-        raise RcclError('%s failed: %s' % (what, _rccl().ncclGetErrorString(rc).decode()))
+        raise RcclError('%s failed: %s' % (what, (lib or _rccl()).ncclGetErrorString(rc).decode()))
 
 
 class RcclComm(object):
-    """One RCCL communicator over the ranks of the default torch.distributed group."""
+    """One RCCL communicator over the ranks of the default torch.distributed group.
 
-    def __init__(self, device):
+    Construction is COLLECTIVE and staged so that a rank that fails locally never leaves its peers inside
+    a different collective: after each stage every rank contributes "ok so far" to an all-reduce(MIN) over
+    the torch.distributed group (`agree`), and all ranks go on or all give up (ncclCommAbort where a
+    communicator already exists).  Stages: (1) library loaded, unique id obtained on rank 0;
+    (2) id broadcast + ncclCommInitRank; (3) probe all-reduce with a known answer.
+    N > 1 parity of this path is UNPINNED until it has run on two real GPUs (no multi-GPU box was
+    available to tests/; tests/test_comm_gloo.py covers the agreement logic with a stand-in library)."""
+
+    def __init__(self, device, agree=None, lib=None):
         assert dist.is_initialized(), 'RcclComm needs torch.distributed for the id exchange'
-        lib = _rccl()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = torch.device(device)
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+        self.comm = C.c_void_p()
+        self._lib = None
+        agree = agree or self._agree
+        # ---- stage 1: local set-up only (nothing here can block on a peer)
+        err, uid = None, _UniqueId()
+        try:
+            self._lib = (lib() if callable(lib) else lib) if lib is not None else _rccl()
+            if self.rank == 0:
+                _check(self._lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId', self._lib)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not agree(err is None):
+            raise RcclError('direct RCCL set-up, stage 1 (library / unique id): %s' %
+                            (err if err is not None else 'another rank failed'))
+        # ---- stage 2: every rank takes part in the broadcast and in the communicator's rendezvous
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8)
         if dist.get_backend() == 'nccl':
             t = t.to(self.device)
         dist.broadcast(t, src=0)
         C.memmove(C.byref(uid), t.cpu().numpy().tobytes(), 128)
-        self.comm = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
-        # first call outside any capture: lazy channel / proxy set-up happens here, and the result
-        # proves the communicator before the hot path depends on it
-        probe = torch.full((8,), float(self.rank + 1), dtype=torch.float32, device=self.device)
-        self.all_reduce_(probe)
-        torch.cuda.current_stream(self.device).synchronize()
-        want = self.world * (self.world + 1) / 2.0
-        if not bool((probe == want).all()):
-            raise RcclError('probe all-reduce returned %r, expected %r' % (probe.tolist(), want))
+        try:
+            with torch.cuda.device(self.device) if self.device.type == 'cuda' else _nullctx():
+                _check(self._lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank),
+                       'ncclCommInitRank', self._lib)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not agree(err is None):
+            self.abort()
+            raise RcclError('direct RCCL set-up, stage 2 (ncclCommInitRank): %s' %
+                            (err if err is not None else 'another rank failed'))
+        # ---- stage 3: first call outside any capture: lazy channel / proxy set-up happens here, and the
+        # result proves the communicator before the hot path depends on it
+        try:
+            probe = torch.full((8,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+            self.all_reduce_(probe)
+            if self.device.type == 'cuda':
+                torch.cuda.current_stream(self.device).synchronize()
+            want = self.world * (self.world + 1) / 2.0
+            if not bool((probe == want).all()):
+                raise RcclError('probe all-reduce returned %r, expected %r' % (probe.tolist(), want))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not agree(err is None):
+            self.abort()
+            raise RcclError('direct RCCL set-up, stage 3 (probe all-reduce): %s' %
+                            (err if err is not None else 'another rank failed'))
+
+    def _agree(self, ok):
+        """all-reduce(MIN) of this rank's verdict over the torch.distributed group."""
+        v = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                         device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(int(v.item()))
 
     def all_reduce_(self, t):
         """In-place SUM over ranks on torch's CURRENT stream (capturable)."""
-        assert t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES
-        _check(_rccl().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DTYPES[t.dtype], _SUM, self.comm,
-                                     torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllReduce')
+        assert t.is_contiguous() and t.dtype in _DTYPES
+        stream = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+        _check(self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DTYPES[t.dtype], _SUM, self.comm,
+                                       stream), 'ncclAllReduce', self._lib)
         return t
 
+    def abort(self):
+        """Tear the communicator down without waiting for peers (after a disagreement)."""
+        if self.comm and self._lib is not None:
+            self._lib.ncclCommAbort(self.comm)
+        self.comm = C.c_void_p()
+
     def destroy(self):
-        if self.comm:
-            _rccl().ncclCommDestroy(self.comm)
-            self.comm = C.c_void_p()
+        if self.comm and self._lib is not None:
+            self._lib.ncclCommDestroy(self.comm)
+        self.comm = C.c_void_p()
+
+
+class _nullctx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -81,6 +81,99 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+class _FakeRccl(object):
+    """Stand-in for librccl with the entry points sam_tf_amd.rccl binds, over the gloo group: lets the
+    staged all-ranks-or-none set-up of RcclComm run on CPU with a failure injected at a chosen stage."""
+
+    def __init__(self, rank, fail_stage=None):
+        self.rank, self.fail_stage, self.aborted, self.destroyed = rank, fail_stage, 0, 0
+
+    def ncclGetErrorString(self, rc):
+        return b'injected failure'
+
+    def ncclGetUniqueId(self, uid_ref):
+        return 0
+
+    def ncclCommInitRank(self, comm_ref, world, uid, rank):
+        dist.barrier()   # a rendezvous, like the real one
+        if self.fail_stage == 2:
+            return 1
+        comm_ref._obj.value = 1234
+        return 0
+
+    def ncclAllReduce(self, src, dst, n, dtype, op, comm, stream):
+        import ctypes as C
+        t = torch.frombuffer((C.c_float * n).from_address(dst), dtype=torch.float32)
+        dist.all_reduce(t)
+        if self.fail_stage == 3:
+            t.add_(1.0)   # a wrong answer on this rank only
+        return 0
+
+    def ncclCommAbort(self, comm):
+        self.aborted += 1
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        self.destroyed += 1
+        return 0
+
+
+def _staged_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sam_tf_amd.rccl import RcclComm, RcclError
+        cpu = torch.device('cpu')
+        # every stage passes: the communicator works
+        lib = _FakeRccl(rank)
+        c = RcclComm(cpu, lib=lib)
+        t = torch.full((5,), float(rank + 1))
+        c.all_reduce_(t)
+        assert (t == 3.0).all()
+        c.destroy()
+        assert lib.destroyed == 1
+        # rank 1 fails at stage 1 (library load), 2 (communicator init), 3 (probe): BOTH ranks raise at the
+        # same stage, nobody is left inside a collective, communicators that exist are aborted
+        for stage in (1, 2, 3):
+            def load(stage=stage):
+                if stage == 1 and rank == 1:
+                    raise OSError('librccl.so: cannot open shared object file')
+                return _FakeRccl(rank, stage if rank == 1 else None)
+            try:
+                RcclComm(cpu, lib=load)
+                raise AssertionError('stage %d: set-up should have failed on every rank' % stage)
+            except RcclError as e:
+                assert 'stage %d' % stage in str(e), str(e)
+                if rank == 0:
+                    assert 'another rank failed' in str(e), str(e)
+            dist.barrier()   # both ranks are free to enter the next collective
+        out.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world2(target):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_direct_rccl_setup_agrees_stage_by_stage():
+    """a rank that fails during the direct-RCCL set-up must not leave its peers in a different
+    collective.  Two gloo ranks, a stand-in library, a failure injected on rank 1 at each stage."""
+    res = _run_world2(_staged_worker)
+    assert res == {0: 'ok', 1: 'ok'}, res
+
+
 def test_world2_gloo():
     ctx = mp.get_context('spawn')
     out = ctx.Queue()

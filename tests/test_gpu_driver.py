@@ -443,6 +443,40 @@ def test_schedule_packed_launch_equals_single_rows():
         assert torch.equal(a.cpu(), b.cpu())
 
 
+def test_per_d_only_rows_run_equals_step():
+    """Prioritized replay with d_steps = 2, g_steps = 1: the D-only row does not end in a host wait, so
+    the next launch must not overwrite the pinned launch words while the previous graph may still read
+    them.  run(n) — launches back to back — must leave the learner and the trees bit-identical
+    to n x step(), which synchronises after every row."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    cfg = dict(bench.CONFIGS['C3'], mem=4096)
+    states = []
+    for mode in ('single', 'run'):
+        mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=2, g_steps=1)
+        assert drv.sched == [1, 3] and drv.K == 1 and drv.per_graph_io
+        drv.prepare_all()
+        np.random.seed(81); random.seed(81)
+        pool.pointer = 0
+        n = 14
+        if mode == 'single':
+            for _ in range(n):
+                drv.step()
+                torch.cuda.synchronize()
+        else:
+            drv.run(n)
+        torch.cuda.synchronize()
+        rb = mu.replay_buffer
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps, d.obs_rms.sums,
+                                           rb.trees.sum, rb.trees.min]] +
+                      [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([random.random()])])
+    assert int(states[0][4][0].item()) == 7 and int(states[0][4][2].item()) == 14
+    for a, b in zip(*states):
+        assert torch.equal(a.cpu(), b.cpu())
+
+
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-retn'])
 def test_appending_transitions_between_runs(cfg_name):
     """Rollouts append transitions between training phases (sam.py:305-321): the driver notices that the

@@ -109,7 +109,7 @@ def test_checkpoint_roundtrip_and_demo_rows(tmp_path):
     # a few updates, save, scramble, load: identical state
     for _ in range(3):
         mu.train(); mu.update_target_net()
-    ck = str(tmp_path / 'ck.npz')
+    ck = str(tmp_path / 'ck')   # no '.npz' suffix: save and load must agree on the file name
     checkpoint.save_learner(ck, mu, d)
     L = mu.L
     keep = [t.clone() for t in (L.params, L.targets, L.m, L.v, L.steps, mu.obs_rms.sums, mu.obs_rms.mean,
