@@ -400,6 +400,20 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
 /* Scratch for samx_d_input_stats (large inputs are summed by many workgroups into per-group float64
  * partials that are then added in a fixed order); ws may be NULL when 2*B*ob_dim <= 16384. */
 size_t samx_d_input_stats_ws_bytes(int64_t B, int ob_dim);
+/* samx_d_input_stats WITHOUT a workspace argument and without any allocation.  No counterpart in the
+ * reference: it exists for callers that cannot allocate device memory — code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The per-group float64 partials live in a
+ * file-scope device array of the library (1 MiB + 256 bytes, held by every GPU the library runs on until
+ * the process ends), which bounds the input: ob_dim <= samx_d_input_stats_static_max_ob() (512); wider
+ * observations are rejected with SAMX_ERR_ARG.  Same arithmetic, same bits as samx_d_input_stats.  All calls
+ * on one GPU share that array: calls that overlap on one GPU (two streams) race; calls on one stream are
+ * ordered.  The array's address is looked up on the first call on each device, which must therefore
+ * happen outside a stream capture. */
+int samx_d_input_stats_static_max_ob(void);
+int samx_d_input_stats_static(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                              const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
+                              int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
+                              float* std_out, void* stream);
 /* Head of a prioritized-replay row in ONE launch: workgroup 0 applies the pending priority update to both
  * trees (= samx_tree_set with n_upd < 1024: memory.py:373-379 of the PREVIOUS agent update), workgroup 1
  * computes the D-input sums of this row (= samx_d_input_stats with commit = 0: sam.py:389-390).  The two

@@ -120,6 +120,9 @@ SIGNATURES = {
     'samx_d_input_stats': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
                                      _P, _SZ, _P]),
     'samx_d_input_stats_ws_bytes': (_SZ, [_I64, C.c_int]),
+    'samx_d_input_stats_static_max_ob': (C.c_int, []),
+    'samx_d_input_stats_static': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
+                                            _P]),
     'samx_d_input_sums_many': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _I64, _P]),
     'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
     'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),

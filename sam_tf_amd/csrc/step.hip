@@ -8,6 +8,7 @@
 #include "tree_dev.h"
 #include "rng.h"
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/samx.h"
 
 using namespace samx;
@@ -385,6 +386,63 @@ int stat_groups(int64_t B) {
     return (int)(g < 1 ? 1 : (g > kStatGroupsMax ? kStatGroupsMax : g));
 }
 
+// ---- samx_d_input_stats_static: the per-group float64 partials in library-owned device memory --------
+// For callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc).
+// `scratch` is the HOST-SIDE NAME of a device array: it is never passed to a kernel or a memset.  Its
+// device address is resolved once per device with hipGetSymbolAddress (each GPU holds its own copy at its
+// own address) and only that pointer is used afterwards.
+constexpr int kStaticObMax = 512;   // widest observation the static variant takes
+constexpr size_t kStaticScratchBytes = (size_t)kStatGroupsMax * 2 * kStaticObMax * sizeof(double) + 256;  // 1 MiB + 256
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+int static_scratch(void** out) {
+    static void* per_dev[64] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    SAMX_CHECK_HIP(hipGetDevice(&dev));
+    SAMX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_dev[dev]) {
+        void* ptr = nullptr;
+        SAMX_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        SAMX_REQUIRE(ptr, "hipGetSymbolAddress returned a null address for the static scratch");
+        per_dev[dev] = ptr;
+    }
+    *out = per_dev[dev];
+    return SAMX_OK;
+}
+
+int d_input_stats_impl(const char* who, const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                       const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
+                       int ob_dim, double* addvec, int commit, double* sums, float* mean_out, float* std_out,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "%s: bad arguments", who);
+    SAMX_REQUIRE(ob_dim <= 1024, "%s: ob_dim %d > 1024", who, ob_dim);
+    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len), "%s: bad ring geometry", who);
+    SAMX_REQUIRE(!commit || (sums && mean_out && std_out), "%s: commit needs sums/mean/std", who);
+    if (2 * B * (int64_t)ob_dim > 16384) {  // two-stage form
+        const int G = stat_groups(B);
+        SAMX_REQUIRE(ws, "%s: this size needs a workspace (samx_d_input_stats_ws_bytes)", who);
+        if (ws_bytes < samx_d_input_stats_ws_bytes(B, ob_dim))
+            return fail(SAMX_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes,
+                        samx_d_input_stats_ws_bytes(B, ob_dim));
+        double* part = (double*)ws;
+        d_input_partials_kernel<<<dim3(G, (ob_dim + 255) / 256), 256, 0, st>>>(
+            replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, part, commit ? sums : nullptr);
+        SAMX_LAUNCH_CHECK();
+        d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out);
+        SAMX_LAUNCH_CHECK();
+        return SAMX_OK;
+    }
+    int dimpad = 1;
+    while (dimpad < ob_dim) dimpad *= 2;
+    d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), st>>>(
+        replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
+        mean_out, std_out, 0, 0);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -410,33 +468,31 @@ int samx_d_input_stats(const float* replay_obs0, int64_t ring_start, int64_t rin
                        const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
                        int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
                        float* std_out, void* ws, size_t ws_bytes, void* stream) {
-    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "samx_d_input_stats: bad arguments");
-    SAMX_REQUIRE(ob_dim <= 1024, "samx_d_input_stats: ob_dim %d > 1024", ob_dim);
-    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
-                 "samx_d_input_stats: bad ring geometry");
-    SAMX_REQUIRE(!commit || (sums && mean_out && std_out), "samx_d_input_stats: commit needs sums/mean/std");
-    hipStream_t st = (hipStream_t)stream;
-    if (2 * B * (int64_t)ob_dim > 16384) {  // two-stage form
-        const int G = stat_groups(B);
-        SAMX_REQUIRE(ws, "samx_d_input_stats: this size needs a workspace (samx_d_input_stats_ws_bytes)");
-        if (ws_bytes < samx_d_input_stats_ws_bytes(B, ob_dim))
-            return fail(SAMX_ERR_WORKSPACE, "samx_d_input_stats: workspace %zu < %zu", ws_bytes,
-                        samx_d_input_stats_ws_bytes(B, ob_dim));
-        double* part = (double*)ws;
-        d_input_partials_kernel<<<dim3(G, (ob_dim + 255) / 256), 256, 0, st>>>(
-            replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, part, commit ? sums : nullptr);
-        SAMX_LAUNCH_CHECK();
-        d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out);
-        SAMX_LAUNCH_CHECK();
-        return SAMX_OK;
-    }
-    int dimpad = 1;
-    while (dimpad < ob_dim) dimpad *= 2;
-    d_input_stats_kernel<<<1, 1024, 2 * 1024 * sizeof(double), st>>>(
-        replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, commit, sums,
-        mean_out, std_out, 0, 0);
-    SAMX_LAUNCH_CHECK();
-    return SAMX_OK;
+    return d_input_stats_impl("samx_d_input_stats", replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start,
+                              B, ob_dim, addvec, commit, sums, mean_out, std_out, ws, ws_bytes,
+                              (hipStream_t)stream);
+}
+
+int samx_d_input_stats_static_max_ob(void) { return kStaticObMax; }
+
+int samx_d_input_stats_static(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                              const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start, int64_t B,
+                              int ob_dim, double* addvec, int commit, double* sums, float* mean_out,
+                              float* std_out, void* stream) {
+    SAMX_REQUIRE(ob_dim <= kStaticObMax,
+                 "samx_d_input_stats_static: ob_dim %d exceeds the static scratch (at most %d columns; use "
+                 "samx_d_input_stats with a workspace)", ob_dim, kStaticObMax);
+    SAMX_REQUIRE(B > 0 && samx_d_input_stats_ws_bytes(B, ob_dim) <= kStaticScratchBytes,
+                 "samx_d_input_stats_static: B %lld x ob_dim %d needs %zu scratch bytes, the static scratch holds %zu",
+                 (long long)B, ob_dim, samx_d_input_stats_ws_bytes(B, ob_dim), kStaticScratchBytes);
+    void* ptr = nullptr;   // this device's copy of the array (never the symbol itself)
+    int rc = static_scratch(&ptr);
+    if (rc != SAMX_OK) return rc;
+    // every word of the partials that the commit kernel reads is written by the partials kernel of the
+    // same call first: nothing has to start at zero, the previous call's contents are simply overwritten
+    return d_input_stats_impl("samx_d_input_stats_static", replay_obs0, ring_start, ring_len, p_idx, pool_obs0,
+                              e_start, B, ob_dim, addvec, commit, sums, mean_out, std_out, ptr,
+                              kStaticScratchBytes, (hipStream_t)stream);
 }
 
 int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,

@@ -568,6 +568,21 @@ def d_input_stats(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec,
                                   ptr(mean), ptr(std), ptr(ws), ws.numel(), stream_ptr()))
 
 
+def d_input_stats_static(replay_obs0, ring_start, p_idx, pool_obs0, e_start, B, addvec, commit=False, sums=None,
+                         mean=None, std=None):
+    """d_input_stats through the entry point that allocates nothing: the partials live in the library's
+    static device scratch (ob <= samx_d_input_stats_static_max_ob()); no workspace tensor is made here."""
+    ring_len, ob = replay_obs0.shape
+    _chk(replay_obs0, F32, (ring_len, ob), 'replay_obs0'); _chk(pool_obs0, F32, (pool_obs0.shape[0], ob), 'pool')
+    _opt(p_idx, I64, (B,), 'p_idx'); _opt(e_start, I64, (1,), 'e_start')
+    _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+    if commit:
+        _chk(sums, F64, (2 * ob + 1,), 'sums'); _chk(mean, F32, (ob,), 'mean'); _chk(std, F32, (ob,), 'std')
+    check(_L().samx_d_input_stats_static(ptr(replay_obs0), int(ring_start), int(ring_len), ptr(p_idx),
+                                         ptr(pool_obs0), ptr(e_start), int(B), int(ob), ptr(addvec),
+                                         int(bool(commit)), ptr(sums), ptr(mean), ptr(std), stream_ptr()))
+
+
 def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
     """Batch sums of K steps at once.  words: int64 [K, W] with idx_p at [:, :B] and e_start at
     [:, 2B]; addvecs: float64 [K, 2*ob+1]."""
