@@ -125,8 +125,17 @@ struct ApplyArgs {
     float grad_scale, beta1, beta2, eps, tau;
 };
 
-bool supported(const samx_mlp* d, int64_t B);
+bool supported(const samx_mlp* d, int64_t B);   // 64x64, in <= 64, out <= 16, B % 16 == 0 (with or without LayerNorm)
 bool fits_lds(int ob, int ac);
+// LayerNorm nets (fused_ln.hip): same contracts as the launchers below; the critic role always runs
+// against stored targets (AgentArgs::ext_tq), which launch_targets_ln produces
+bool fits_lds_ln(int ob, int ac, bool use_d);
+int launch_step_ln(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
+int launch_targets_ln(const AgentArgs* a, hipStream_t st);
+int launch_td_ln(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,
+                 const float* mean, const float* stdv, int64_t B, int ob, const int64_t* idx, int64_t ring_start,
+                 int64_t ring_len, float* td_out, const float* ret_mean, const float* ret_std, float* td_copy,
+                 int64_t* idx_copy, hipStream_t st);
 int seg_blocks(int64_t n);
 struct StepArgs {
     AgentArgs a;
@@ -139,8 +148,8 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
 int launch_targets(const AgentArgs* a, hipStream_t st);
 // ret_rms.update(tq [, tqn]) + PopArt rescale of the critic heads (sam_agent.py:554-590,662-672), one launch
 int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
-                      int popart, float* critic, float* targ_critic, int critic_in, int phase, double* addvec,
-                      hipStream_t st);   // phase 1: batch sums -> addvec[6] only; 2: commit addvec; 0: both
+                      int popart, float* critic, float* targ_critic, int critic_in, int critic_ln, int phase,
+                      double* addvec, hipStream_t st);   // phase 1: batch sums -> addvec[6] only; 2: commit addvec; 0: both
 constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch
 int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const float* acs, const float* tc1s,

@@ -62,9 +62,13 @@ int side_streams(SideStreams** out) {
 }
 
 bool use_fused(const samx_learner* L, int64_t B) {
+    const bool ln = L->actor.layernorm != 0;
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
            fused::supported(&L->reward, B) && L->critic.in_dim == L->ob_dim + L->ac_dim &&
-           L->reward.in_dim == L->critic.in_dim && fused::fits_lds(L->ob_dim, L->ac_dim);
+           L->reward.in_dim == L->critic.in_dim && (L->critic.layernorm != 0) == ln &&
+           (L->reward.layernorm != 0) == ln &&
+           (ln ? fused::fits_lds_ln(L->ob_dim, L->ac_dim, L->d_actor_loss_scale != 0.f)
+               : fused::fits_lds(L->ob_dim, L->ac_dim));
 }
 
 StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
@@ -573,9 +577,10 @@ int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, 
                  "samx_td_errors_rows: bad ring geometry");
     const bool ret_on = ret && ret->mean;
     if (fused::supported(dc, B) && dc->out_dim == 1 && fused::fits_lds(ob_dim, dc->in_dim - ob_dim))
-        return fused::launch_td(dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, idx, ring_start, ring_len,
-                                td_out, ret_on ? ret->mean : nullptr, ret_on ? ret->std : nullptr, td_copy_out,
-                                idx_copy_out, (hipStream_t)stream);
+        return (dc->layernorm ? fused::launch_td_ln : fused::launch_td)(
+            dc, pc, obs0, acs, tc1s, mean, stdv, B, ob_dim, idx, ring_start, ring_len, td_out,
+            ret_on ? ret->mean : nullptr, ret_on ? ret->std : nullptr, td_copy_out, idx_copy_out,
+            (hipStream_t)stream);
     // general path: gather the rows, then the layer-wise pass
     const int ac = dc->in_dim - ob_dim;
     SAMX_REQUIRE(ws, "samx_td_errors_rows: this configuration needs a workspace");
@@ -836,7 +841,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     a.ret_mean = L->ret_mean; a.ret_std = L->ret_std;
     a.ext_tq = a.ext_tqn = nullptr; a.tdn_scale = L->td_loss_n_scale;
     a.n_idx = nullptr; a.n_rews = a.n_dones = a.n_len = nullptr; a.targ_qn_out = nullptr;
-    const bool ext = L->ret_mean || L->n_step > 0;   // targets from their own launch
+    const bool ln = L->actor.layernorm != 0;
+    // targets from their own launch: always with LayerNorm (the critic role then holds one network, not three)
+    const bool ext = L->ret_mean || L->n_step > 0 || ln;
     if ((part & 1) && do_a && ext) {
         // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
         // ret_rms.update + PopArt -> losses with the new ones
@@ -856,12 +863,12 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             a.targ_qn_out = tqn;
         }
         if (!t_done) {
-            rc = fused::launch_targets(&a, st);
+            rc = (ln ? fused::launch_targets_ln : fused::launch_targets)(&a, st);
             if (rc != SAMX_OK) return rc;
         }
         if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
             rc = fused::launch_ret_popart(o->targ_q, tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
-                                          L->params + Pa, L->targets + Pa, L->critic.in_dim,
+                                          L->params + Pa, L->targets + Pa, L->critic.in_dim, ln ? 1 : 0,
                                           t_only ? 1 : (t_done ? 2 : 0), b->ret_addvec, st);
             if (rc != SAMX_OK) return rc;
         }
@@ -871,7 +878,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         a.ext_tq = o->targ_q; a.ext_tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;
     }
     if (part & 1) {
-        rc = fused::launch_step(do_a ? &a : nullptr, do_d ? &d : nullptr, st);
+        rc = (ln ? fused::launch_step_ln : fused::launch_step)(do_a ? &a : nullptr, do_d ? &d : nullptr, st);
         if (rc != SAMX_OK) return rc;
     }
     if (!(part & 2)) return SAMX_OK;
@@ -899,7 +906,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         const int64_t inc = L->critic.in_dim, h = 64;
         s.wd = L->wd_scale; s.param = pc;
         s.wd0_lo = 0; s.wd0_hi = inc * h;
-        s.wd1_lo = inc * h + h; s.wd1_hi = s.wd1_lo + h * h;
+        s.wd1_lo = inc * h + h + (ln ? 2 * h : 0); s.wd1_hi = s.wd1_lo + h * h;   // W2 (behind b1 [beta1 gamma1])
     }
     f.agent_loss_part = do_a ? w.agent_loss : nullptr; f.agent_tiles = tiles;
     f.q_scale = L->q_actor_loss_scale; f.d_scale = L->d_actor_loss_scale;

@@ -173,7 +173,7 @@ def test_k_steps_match_oracle(cfg_name, graph):
         assert drv.fused == (base not in ('widein', 'ragged', 'raggedper'))
         assert drv.sums_small == (not base.startswith('bigB'))
     if opt and base not in extra:
-        assert drv.fused == (opt in ('ret', 'retn', 'nstep'))
+        assert drv.fused   # LayerNorm included: whole-network kernels of fused_ln.hip
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
     K = 6
@@ -556,7 +556,7 @@ def test_two_rank_plan_matches_oracle(cfg_name):
         cfg = dict(bench.CONFIGS[base], mem=2048)
     cfg.update(ln=opt == 'launcher', ret=bool(opt), nstep=7 if opt in ('retn', 'launcher') else 0, p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
-    fusable = base != 'ragged' and opt != 'launcher'
+    fusable = base != 'ragged'   # LayerNorm (launcher options) included
     assert drv.world == 2 and drv.inline_stats == fusable and drv.popart_split == bool(opt)
     assert drv.K == (16 if base == 'C1' and fusable else 1)   # uniform replay on the fused path packs K steps
     drv.prepare()

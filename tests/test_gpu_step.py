@@ -65,16 +65,20 @@ def _oracle(c, d_scale, ent, per, rms=True):
     ('C2', 0.5, 0.0, False, False, False),
     ('ragged', 0.5, 0.0, True, True, False),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
     ('C4', 0.0, 0.0, False, True, False),
-    # with_layernorm (launcher default, mujoco_sam_imitate.sh): layer-wise path, two-stream GP backward
+    # with_layernorm (launcher default, mujoco_sam_imitate.sh): two-stream GP backward; 64x64 nets on the
+    # whole-network LayerNorm kernels (fused_ln.hip), the rest on the layer-wise path
     ('C2', 0.5, 1e-3, True, True, True), ('ragged', 0.5, 0.0, False, True, True),
     ('C4', 0.0, 0.0, False, True, True),
+    ('C1', 0.0, 0.0, False, True, True), ('C3', 0.0, 1e-3, True, False, True), ('C2', 0.0, 0.0, False, True, True),
+    ('s_1x1', 0.5, 0.0, False, True, True), ('s_7x5', 0.5, 1e-3, True, False, True),
+    ('s_20x4', 0.5, 0.0, False, True, True), ('s_13x2', 0.0, 0.0, True, True, True),
     ('s_1x1', 0.5, 0.0, False, True, False), ('s_2x1', 0.0, 1e-3, True, True, False),
     ('s_7x5', 0.5, 1e-3, True, False, False), ('s_20x4', 0.5, 0.0, False, True, False),
     ('s_13x2', 0.0, 0.0, True, True, False)])
 def test_step_grads_vs_oracle(name, d_scale, ent, per, rms, ln):
     from sam_tf_amd import ops
     c, L, batch, out = _setup(name, d_scale, ent, per, rms, ln)
-    assert L.fused(c['B']) == ((name in ('C1', 'C2', 'C3') or name.startswith('s_')) and not ln)
+    assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3') or name.startswith('s_'))
     exp = _oracle(c, d_scale, ent, per, rms)
     ops.step_grads(L, batch, out)
     torch.cuda.synchronize()
@@ -124,10 +128,12 @@ def test_step_apply_vs_oracle(world):
             assert relerr(L.targets.cpu().numpy()[o:o + th.size], tg) < TOL
 
 
-def test_fused_matches_layerwise():
+@pytest.mark.parametrize('ln', [False, True])
+def test_fused_matches_layerwise(ln):
     """The two implementations of the same step agree far inside the parity bar."""
     from sam_tf_amd import ops
-    c, L, batch, out = _setup('C3', 0.5, 1e-3, True)
+    c, L, batch, out = _setup('C3', 0.5, 1e-3, True, ln=ln)
+    assert L.fused(c['B'])
     ops.step_grads(L, batch, out)
     g_f = L.grads.clone()
     ws = ops.nets_ws(L.da, L.dc, L.dd, c['B'])
