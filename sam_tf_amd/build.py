@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libsamx.so')
 SOURCES = ['core.hip', 'tree.hip', 'replay.hip', 'optim.hip', 'gemm.hip', 'nets.hip',
-           'fused_small.hip', 'fused_ln.hip', 'step.hip']
+           'fused_small.hip', 'fused_ln.hip', 'fused_wide.hip', 'step.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function'] + os.environ.get('SAMX_EXTRA_FLAGS', '').split()
 

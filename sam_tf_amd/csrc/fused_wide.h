@@ -1,0 +1,60 @@
+// Role-fused forward + input-gradient kernel for 256x256 networks (fused_wide.hip): one workgroup runs a
+// role's whole chain of layer products for 16 batch rows with the activations in LDS and the weights
+// streamed through an LDS-DMA ring; what the weight-gradient products need (layer inputs and
+// pre-activation cotangents) is written to HBM, where ONE grouped launch reduces it over the batch.
+#pragma once
+#include "samx_common.h"
+#include "../../include/samx.h"
+
+namespace samx {
+namespace wide {
+
+constexpr int kH = 256;     // hidden width (both layers)
+constexpr int kRows = 16;   // batch rows per workgroup
+constexpr int kMaxIn = 416; // widest network input (a multiple of 32)
+
+struct Net {   // plain leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat parameter vector)
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int in, out;
+};
+
+struct AgentArgs {
+    const float *obs0, *acs, *rews, *dones1, *obs1, *iws, *td_len, *mean, *stdv;
+    const int64_t* idx;   // optional ring indirection (memory.py:33-34)
+    int64_t ring_start, ring_len;
+    Net actor, critic, targ_actor, targ_critic;
+    int ob, ac;
+    int64_t B;
+    float high, gamma, td_scale, q_scale;
+    // target + critic role: TD targets / errors, and the critic's weight-gradient operands
+    float *targ_q, *td_out;
+    float *Xc, *A1c, *A2c, *DZ1c, *DZ2c;   // [B][ob+ac], [B][256] x 4
+    float *row_hub, *row_dq;               // [B] huber * iw ; d loss / d score
+    // actor role
+    float *Xa, *A1a, *A2a, *DZ1a, *DZ2a;   // [B][ob+ac] (obz0 | mu(obz0)), [B][256] x 4
+    float *dPre, *row_q;                   // [B][ac] ; [B] Q(obz0, mu(obz0))
+};
+
+struct DiscArgs {
+    const float *p_obs, *p_acs, *e_obs, *e_acs, *eps_ob, *eps_ac, *real, *fake, *mean, *stdv;
+    const int64_t *p_idx, *e_start;
+    int64_t ring_start, ring_len;
+    uint64_t rng_seed;
+    const int64_t* rng_step;
+    int label_smoothing;
+    Net net;
+    int ob, ac;
+    int64_t B;
+    float ent_scale;
+    // rows [0,B) policy, [B,2B) expert, [2B,3B) interpolates (for those: X = V, A1/A2 = the tangents)
+    float *X, *A1, *A2, *DZ1, *DZ2;   // [3B][ob+ac], [3B][256] x 4
+    float *DS, *ce, *ent, *sg;        // [3B] ; [2B] x 3
+    double* gp_part;                  // [B/16][2]
+};
+
+bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B);
+// roles: bit 0 actor, bit 1 target+critic, bit 2 discriminator
+int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t st);
+
+}  // namespace wide
+}  // namespace samx

@@ -1,0 +1,800 @@
+// Role-fused kernel for 256x256 leaky-ReLU networks (Humanoid-shaped configuration: ob 376, ac 17,
+// batch 1024).  One workgroup (4 waves) owns 16 batch rows and runs the ENTIRE chain of layer products of
+// its role for them:
+//   TC  target actor + target critic on obs1 -> TD target, then the online critic on (obs0, acs): forward,
+//       huber loss, backward to the first pre-activation            (sam_agent.py:196-205,457-520)
+//   A   actor forward, critic forward on [obz0 | mu(obz0)], backward through the critic to the action,
+//       tanh, backward through the actor                            (sam_agent.py:184-194,406-433)
+//   D   policy / expert rows: forward, BCE terms, backward; interpolate rows: forward, input gradient g,
+//       its squared sums, V = g / (B dim) and the tangent forward along V (gradient penalty)
+//                                                                   (discriminator.py:77-161)
+// Activations stay in LDS ([16][260] tiles); the 256x256 weight matrices do not fit next to them, so every
+// product streams its weights through a ring of three 32-deep LDS stages filled through registers (16-byte
+// global loads issued two stages ahead, written to LDS behind the MFMAs of the current stage).  All matmuls
+// are v_mfma_f32_16x16x4_f32 (exact f32).  A layer's k index is visited in the order
+// k = 32 t + 16 g + 4 (lane >> 4) + m so that the activation fragment is ONE ds_read_b128 per four MFMAs.
+// What the weight-gradient products need — layer inputs and pre-activation cotangents — is written to
+// HBM; they are batch reductions and run as ONE grouped MFMA launch afterwards (wgrad_group.hip).
+//
+// LDS images of a weight stage:
+//   NN (forward, B[k][j] = W[k][j]):  S[32][260]: rows 4 apart shift 16 banks, so the ds_read_b32 of lanes
+//       (j, kq) and (j, kq+1) never meet.
+//   NT (backward, B[k][j] = W[j][k]): S[256][32]: the eight 16-byte chunks of row j are XOR-permuted by
+//       (j >> 1) & 7 on the write and again on the read: one conflict-free ds_read_b128 per four MFMAs.
+#include "fused_wide.h"
+#include "rng.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace samx {
+namespace wide {
+namespace {
+
+constexpr int NT = 256;
+constexpr int R = kRows;
+constexpr int H = kH;
+constexpr int LDT = 260;               // pitch of a [16][256] tile
+constexpr int WP = 260;                // pitch of a staged weight row (NN image)
+constexpr int STAGE_F = 32 * WP;       // floats per ring stage (NT image: 256 * 32 fits)
+constexpr int NSTG = 3;
+constexpr int PP = 36;                 // pitch of the [16][ac <= 32] tile of the actor's pre-tanh cotangent
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Phase timestamps of workgroup 0 of each role (profiling builds only: -DSAMX_TRACE; never shipped)
+#ifdef SAMX_TRACE
+__device__ unsigned long long g_wtrace[128];
+#define WTRACE(w_, role, i) do { if ((w_) == 0 && threadIdx.x == 0) g_wtrace[(role) * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define WTRACE(w_, role, i) do { } while (0)
+#endif
+typedef __attribute__((address_space(3))) float lds_float;
+typedef const __attribute__((address_space(1))) float glb_float;
+
+__device__ __forceinline__ float lrelu(float z) { return fmaxf(z, 0.2f * z); }
+__device__ __forceinline__ float dlrelu(float a) { return a >= 0.f ? 1.f : 0.2f; }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void dma16(const float* g, float* s) {
+    __builtin_amdgcn_global_load_lds((glb_float*)g, (lds_float*)s, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// barrier that does not drain the DMAs in flight (a __syncthreads() would)
+__device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sig_ce(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
+
+__device__ __forceinline__ int64_t ring_row(const int64_t* idx, int64_t start, int64_t len, int64_t g) {
+    if (!idx) return g;
+    int64_t s = start + idx[g];
+    return s >= len ? s - len : s;
+}
+
+// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16)   for this wave's four 16-column blocks.
+//   A: LDS, pitch lda (a multiple of 4), zero in the columns [K, 32 ceil(K/32)).
+//   NTR = false: B[k][j] = W[k * ldw + jg0 + j], rows k < K (clamped: the padded A columns are zero)
+//   NTR = true : B[k][j] = W[(jg0 + j) * ldw + k], rows jg0 + j < N (clamped)
+// nvalid: number of valid output columns of this call (blocks that start beyond it are skipped).
+// Ends with a barrier: afterwards every wave is done with A and with the ring.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte-aligned address
+
+// One 32-deep weight stage, register-staged: 8 x 16 bytes per lane (the whole workgroup moves 32 KB).
+// LDS-DMA was measured first and dropped here: a 1 KiB DMA instruction costs the issuing wave ~130 cycles,
+// 8 per wave and stage = as long as the stage's 32 MFMAs, and the two do not overlap inside one wave;
+// plain 16-byte loads issue in a few cycles and land while the MFMAs run.
+struct WRegs { f32x4 q[8]; };
+
+// one layer product's weight operand:
+//   nt = false: B[k][j] = W[k * ldw + jg0 + j], rows k < K (clamped: the padded A columns are zero)
+//   nt = true : B[k][j] = W[(jg0 + j) * ldw + k], rows jg0 + j < N (clamped)
+// nvalid: number of valid output columns (16-column blocks that start beyond it are skipped)
+struct WDesc {
+    const float* W;
+    int ldw, K, N, jg0, nvalid;
+    bool nt;
+};
+__device__ __forceinline__ int wstages(const WDesc& d) { return (d.K + 31) >> 5; }
+
+__device__ __forceinline__ void wstage_load(WRegs& x, const WDesc& d, int t) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k0 = t << 5;
+    if (!d.nt) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int kr = k0 + wv + 4 * q;
+            kr = kr < d.K ? kr : d.K - 1;
+            x.q[q] = *(const f32x4u*)(d.W + (int64_t)kr * d.ldw + d.jg0 + 4 * lane);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int j = d.jg0 + 8 * (wv + 4 * q) + (lane >> 3);
+            j = j < d.N ? j : d.N - 1;
+            x.q[q] = *(const f32x4u*)(d.W + (int64_t)j * d.ldw + k0 + 4 * (lane & 7));
+        }
+    }
+}
+__device__ __forceinline__ void wstage_store(const WRegs& x, bool nt, float* S) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (!nt) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(f32x4*)(S + (wv + 4 * q) * WP + 4 * lane) = x.q[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int jl = 8 * (wv + 4 * q) + (lane >> 3);
+            *(f32x4*)(S + jl * 32 + (((lane & 7) ^ ((jl >> 1) & 7)) << 2)) = x.q[q];
+        }
+    }
+}
+
+// The weight stream of a chain of products: stages are numbered through the chain (pipe.s), stage s lives
+// in ring slot s % 3, is loaded into registers three stages ahead and written to LDS two stages ahead —
+// about 64 KB per workgroup in flight, across product boundaries (`next`): a product's epilogue runs
+// while the first stages of the next one land.
+struct WPipe {
+    WRegs x0, x1;
+    int s;         // stream index of the next product's first stage
+    bool primed;   // its stages 0 and 1 are in LDS and stage 2 is in flight in (flip ? x1 : x0)
+    bool flip;
+};
+__device__ __forceinline__ void wpipe_init(WPipe& p) { p.s = 0; p.primed = false; p.flip = false; }
+
+// E: the register set that holds stage 2 on entry, O: the other one.  Even iterations load stage t+3 into O
+// and store stage t+2 from E, odd iterations the other way round (all register indices static).
+__device__ __forceinline__ void wprod_run(WRegs& E, WRegs& O, WPipe& pipe, const WDesc cur, const WDesc next,
+                                          const bool has_next, const float* A, int lda, float* ring,
+                                          f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const int T = wstages(cur), s0 = pipe.s;
+    const int U = T + (has_next ? 3 : 0);   // stages this call may load (cur's, then the first three of next)
+    auto ld = [&](int u, WRegs& x) {
+        if (u < T) wstage_load(x, cur, u); else wstage_load(x, next, u - T);
+    };
+    auto st = [&](int u, const WRegs& x) {
+        wstage_store(x, u < T ? cur.nt : next.nt, ring + ((s0 + u) % NSTG) * STAGE_F);
+    };
+    if (!pipe.primed) {
+        ld(0, E);
+        if (1 < U) ld(1, O);
+        st(0, E);
+        if (1 < U) st(1, O);
+        if (2 < U) ld(2, E);
+    }
+    auto iter = [&](int t, WRegs& LD, const WRegs& ST) {
+        // every wave is done with stage t-1 and has written its share of stage t (and t+1)
+        bar();
+        if (t + 3 < U) ld(t + 3, LD);
+        const float* S = ring + ((s0 + t) % NSTG) * STAGE_F;
+        const int k0 = t << 5;
+        // all fragment reads of the stage are issued before the first MFMA (counted lgkmcnt waits let the
+        // first MFMAs start while the later reads are still in flight: one wave per SIMD has nobody else to
+        // hide the LDS latency behind)
+        f32x4 a4[2], b4[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            a4[g] = *(const f32x4*)(A + r * lda + k0 + 16 * g + 4 * kq);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int jl = 64 * wv + 16 * nb + r;
+                if (cur.nt) {
+                    b4[g][nb] = *(const f32x4*)(S + jl * 32 + (((4 * g + kq) ^ ((jl >> 1) & 7)) << 2));
+                } else {
+                    const float* p = S + (16 * g + 4 * kq) * WP + jl;
+                    b4[g][nb][0] = p[0]; b4[g][nb][1] = p[WP]; b4[g][nb][2] = p[2 * WP]; b4[g][nb][3] = p[3 * WP];
+                }
+            }
+        }
+        // consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair costs 40 cycles, not 32);
+        // blocks beyond nvalid compute finite values that are never stored
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(a4[g][m], b4[g][nb][m], acc[nb]);
+        if (t + 2 < U) st(t + 2, ST);
+    };
+    for (int t = 0; t < T; t += 2) {
+        iter(t, O, E);
+        if (t + 1 < T) iter(t + 1, E, O);
+    }
+    bar();
+    pipe.s = s0 + T;
+    pipe.primed = has_next;
+    if (T & 1) pipe.flip = !pipe.flip;
+}
+
+// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for this wave's four 16-column blocks; A in LDS with
+// pitch lda (a multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).
+// Ends with a barrier: afterwards every wave is done with A (the ring slots of `next` stay live).
+__device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc next, bool has_next, const float* A,
+                                      int lda, float* ring, f32x4 (&acc)[4]) {
+    if (wstages(cur) < 3 || wstages(next) < 3) has_next = false;   // short products do not chain
+    if (pipe.flip) wprod_run(pipe.x1, pipe.x0, pipe, cur, next, has_next, A, lda, ring, acc);
+    else wprod_run(pipe.x0, pipe.x1, pipe, cur, next, has_next, A, lda, ring, acc);
+}
+__device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const float* A, int lda, float* ring,
+                                      f32x4 (&acc)[4]) {   // last product of a chain
+    wprod(pipe, cur, cur, false, A, lda, ring, acc);
+}
+
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// f(row, col, value, bit index) over this wave's accumulator elements
+template <typename F>
+__device__ __forceinline__ void for_acc(const f32x4 (&acc)[4], F f) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f((lane >> 4) * 4 + j, 64 * wv + 16 * nb + (lane & 15), acc[nb][j], nb * 4 + j);
+}
+
+__device__ __forceinline__ WDesc w_nn(const float* W, int K) { return WDesc{W, H, K, H, 0, H, false}; }
+__device__ __forceinline__ WDesc w_nt(const float* W, int N, int jg0, int nvalid) {
+    return WDesc{W, H, H, N, jg0, nvalid, true};
+}
+
+// hidden layer: out = lrelu(A W + b) into the LDS tile T and, if hbm, to hbm[(row0 + r)][256].
+// Returns this lane's 16 mask bits (value >= 0).
+__device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                               const float* A, int lda, const float* __restrict__ b, float* ring,
+                                               float* T, float* __restrict__ hbm, int64_t row0) {
+    f32x4 acc[4];
+    zero_acc(acc);
+    wprod(pipe, cur, next, has_next, A, lda, ring, acc);
+    unsigned bits = 0;
+    for_acc(acc, [&](int r, int c, float v, int bi) {
+        const float a = lrelu(v + b[c]);
+        T[r * LDT + c] = a;
+        if (hbm) hbm[(row0 + r) * H + c] = a;
+        bits |= (a >= 0.f ? 1u : 0u) << bi;
+    });
+    bar();   // T is complete for every reader that follows
+    return bits;
+}
+
+// s[r] = <T[r], w3> + b3  (1-output head; w3 / b3 from global memory)
+__device__ __forceinline__ void head1(const float* T, const float* __restrict__ w3, const float* __restrict__ b3,
+                                      float* s_out) {
+    const int r = threadIdx.x >> 4, q = threadIdx.x & 15;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = q; c < H; c += 16) acc = fmaf(T[r * LDT + c], w3[c], acc);
+    acc = sum16(acc);
+    if (q == 0) s_out[r] = acc + b3[0];
+}
+
+// T[r][c] = dq[r] * w3[c] * lrelu'(T[r][c]) in place, and to hbm
+__device__ __forceinline__ void head_bwd(float* T, const float* dq, const float* __restrict__ w3,
+                                         float* __restrict__ hbm, int64_t row0) {
+    for (int t = threadIdx.x; t < R * H; t += NT) {
+        const int r = t >> 8, c = t & 255;
+        const float v = dq[r] * w3[c] * dlrelu(T[r * LDT + c]);
+        T[r * LDT + c] = v;
+        hbm[(row0 + r) * H + c] = v;
+    }
+}
+
+// the whole head matrix W3[256][out <= 32] (contiguous) into ring slot 0 as it lies: S[k * out + j]
+__device__ __forceinline__ void stage_head(const float* __restrict__ W3, int out, float* ring) {
+    const int n4 = 64 * out;   // 16-byte chunks
+    for (int t = threadIdx.x; t < n4; t += NT) *(f32x4*)(ring + 4 * t) = *(const f32x4u*)(W3 + 4 * t);
+    bar();
+}
+
+struct Lds {
+    float *ring, *X, *T1, *T2, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl;
+    int px;
+};
+__host__ __device__ inline int pitch_x(int in) { return ((in + 31) / 32) * 32 + 4; }
+__host__ __device__ inline size_t lds_floats(int in) {
+    return (size_t)NSTG * STAGE_F + (size_t)R * pitch_x(in) + 2 * R * LDT + R * PP + 16 * 8 + 64;
+}
+__device__ inline Lds carve(float* p, int in) {
+    Lds L;
+    L.px = pitch_x(in);
+    L.ring = p; p += NSTG * STAGE_F;
+    L.X = p; p += R * L.px;
+    L.T1 = p; p += R * LDT;
+    L.T2 = p; p += R * LDT;
+    L.PRE = p; p += R * PP;
+    L.s_ = p; L.tq = p + 16; L.dq = p + 32; L.rw = p + 48; L.dn = p + 64; L.iw = p + 80; L.tl = p + 96;
+    L.red = p + 112;   // 64 floats
+    return L;
+}
+
+// rows [obz | acs] of the batch into X[16][px], zero up to k32 columns; optional dense copy to HBM.
+// Thread t owns row t >> 4 and the columns (t & 15) + 16 i; the loads go out in batches of kRowBatch before
+// anything waits (a load -> use per column would pay one memory round trip per column).
+constexpr int kRowBatch = 13;
+__device__ __forceinline__ void load_rows(const Lds& L, int k32, const float* __restrict__ obs,
+                                          const float* __restrict__ acs, const float* __restrict__ mean,
+                                          const float* __restrict__ stdv, int ob, int ac, int acw, int64_t prow,
+                                          float* __restrict__ hbm, int64_t hrow, int ldh) {
+    const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    for (int cb = c0; cb < k32; cb += 16 * kRowBatch) {
+        float v[kRowBatch], m[kRowBatch], sd[kRowBatch];
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int c = cb + 16 * u;
+            v[u] = 0.f; m[u] = 0.f; sd[u] = 1.f;
+            if (c < ob) {
+                v[u] = obs[prow * ob + c];
+                if (mean) { m[u] = mean[c]; sd[u] = stdv[c]; }
+            } else if (c < ob + acw) {
+                v[u] = acs[prow * ac + (c - ob)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int c = cb + 16 * u;
+            if (c < k32) {
+                float x = v[u];
+                if (mean && c < ob) x = fminf(fmaxf((x - m[u]) / sd[u], -5.f), 5.f);
+                L.X[r * L.px + c] = x;
+                if (hbm && c < ob + acw) hbm[hrow * ldh + c] = x;
+            }
+        }
+    }
+}
+
+// actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac)
+__device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, int ac, float high,
+                                           float* __restrict__ hbm, int64_t row0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    stage_head(n.W3, ac, L.ring);
+    if (16 * wv < ac) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int jc = min(16 * wv + r, ac - 1);
+        for (int k = 0; k < H; k += 4) acc = mfma4(L.T2[r * LDT + k + kq], L.ring[(k + kq) * ac + jc], acc);
+        const int c = 16 * wv + (lane & 15);
+        if (c < ac) {
+            const float b = n.b3[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = (lane >> 4) * 4 + j;
+                float v = high * tanhf(acc[j] + b);
+                v = fminf(fmaxf(v, -high), high);
+                L.X[row * L.px + ob + c] = v;
+                if (hbm) hbm[(row0 + row) * (ob + ac) + ob + c] = v;
+            }
+        }
+    }
+    bar();
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac, in_c = ob + ac;
+    Lds L = carve(lds, in_c);
+    const int k32c = ((in_c + 31) / 32) * 32;
+    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    WPipe pipe;
+    wpipe_init(pipe);
+    const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
+    const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
+    const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    if (tid < R) {
+        const int64_t prs = ring_row(a.idx, a.ring_start, a.ring_len, row0 + tid);
+        L.rw[tid] = a.rews[prs];
+        L.dn[tid] = a.dones1[prs];
+        L.iw[tid] = a.iws ? a.iws[row0 + tid] : 1.f;
+        L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
+    }
+    // ---- TD target with the target nets on obs1
+    WTRACE(wg, 0, 0);
+    load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
+    bar();
+    WTRACE(wg, 0, 1);
+    hidden_fwd(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
+    WTRACE(wg, 0, 2);
+    hidden_fwd(pipe, ta2, ta2, false, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    WTRACE(wg, 0, 3);
+    actor_head(L, a.targ_actor, ob, ac, a.high, nullptr, 0);
+    WTRACE(wg, 0, 4);
+    hidden_fwd(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
+    WTRACE(wg, 0, 5);
+    hidden_fwd(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
+    WTRACE(wg, 0, 6);
+    head1(L.T2, a.targ_critic.W3, a.targ_critic.b3, L.s_);
+    bar();
+    WTRACE(wg, 0, 7);
+    if (tid < R) {
+        const float gam = a.td_len ? powf(a.gamma, L.tl[tid]) : a.gamma;
+        const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * L.s_[tid]);   // sam_agent.py:202-205
+        a.targ_q[row0 + tid] = t;
+        L.tq[tid] = t;
+    }
+    // ---- online critic on (obz0, acs): forward, loss, backward
+    load_rows(L, k32c, a.obs0, a.acs, a.mean, a.stdv, ob, ac, ac, pr, a.Xc, row0 + (tid >> 4), in_c);
+    bar();
+    WTRACE(wg, 0, 8);
+    hidden_fwd(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, a.A1c, row0);
+    WTRACE(wg, 0, 9);
+    hidden_fwd(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, a.A2c, row0);
+    WTRACE(wg, 0, 10);
+    head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+    bar();
+    if (tid < R) {
+        const float td = L.s_[tid] - L.tq[tid];
+        const float iw = L.iw[tid];
+        const float ad = fabsf(td);
+        const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;         // math_util.py:22-29
+        const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
+        const float dq = (a.td_scale / (float)a.B) * dh * iw;
+        L.dq[tid] = dq;
+        a.row_dq[row0 + tid] = dq;
+        a.row_hub[row0 + tid] = hub * iw;
+        if (a.td_out) a.td_out[row0 + tid] = td;
+    }
+    bar();
+    head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
+    bar();
+    WTRACE(wg, 0, 11);
+    {
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, c3, L.T2, LDT, L.ring, acc);
+        WTRACE(wg, 0, 12);
+        for_acc(acc, [&](int r, int c, float v, int) {
+            a.DZ1c[(row0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
+        });
+    }
+    WTRACE(wg, 0, 13);
+}
+
+__device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac, in_c = ob + ac;
+    Lds L = carve(lds, in_c);
+    const int k32c = ((in_c + 31) / 32) * 32;
+    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    WPipe pipe;
+    wpipe_init(pipe);
+    const WDesc a1 = w_nn(a.actor.W1, ob), a2 = w_nn(a.actor.W2, H), a3 = w_nt(a.actor.W2, H, 0, H);
+    const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
+    load_rows(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 4), in_c);
+    for (int t = tid; t < R * PP; t += NT) L.PRE[t] = 0.f;
+    bar();
+    const unsigned m1a = hidden_fwd(pipe, a1, a2, true, L.X, L.px, a.actor.b1, L.ring, L.T1, a.A1a, row0);
+    const unsigned m2a = hidden_fwd(pipe, a2, a2, false, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
+    actor_head(L, a.actor, ob, ac, a.high, a.Xa, row0);
+    // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
+    hidden_fwd(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, nullptr, 0);
+    hidden_fwd(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
+    head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+    if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+    bar();
+    if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
+    for (int t = tid; t < R * H; t += NT) {   // dZ2c in place
+        const int r = t >> 8, c = t & 255;
+        L.T2[r * LDT + c] = L.dq[r] * a.critic.W3[c] * dlrelu(L.T2[r * LDT + c]);
+    }
+    bar();
+    {   // dZ1c = (dZ2c W2c^T) .* lrelu'(A1c), in place over A1c (every wave is past the product's last barrier)
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, c3, c4, true, L.T2, LDT, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
+    }
+    bar();
+    {   // dQ/da = dZ1c W1c[ob:ob+ac, :]^T, through clip (identity inside the range) and tanh
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, c4, L.T1, LDT, L.ring, acc);
+        if (wv == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int c = 16 * nb + (lane & 15);
+                if (c < ac) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = (lane >> 4) * 4 + j;
+                        const float t = L.X[r * L.px + ob + c] / a.high;
+                        const float v = acc[nb][j] * (a.high * (1.f - t * t));
+                        L.PRE[r * PP + c] = v;
+                        a.dPre[(row0 + r) * ac + c] = v;
+                    }
+                }
+            }
+        }
+    }
+    bar();
+    {   // dZ2a = (PRE W3a^T) .* lrelu'(A2a): reduction over the (zero-padded) action index
+        stage_head(a.actor.W3, ac, L.ring);
+        const int r = lane & 15, kq = lane >> 4;
+        f32x4 acc[4];
+        zero_acc(acc);
+        const int ks = (ac + 3) / 4;
+        for (int kk = 0; kk < ks; ++kk) {
+            const float av = L.PRE[r * PP + 4 * kk + kq];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[nb] = mfma4(av, L.ring[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
+        }
+        bar();
+        for_acc(acc, [&](int r_, int c, float v, int bi) {
+            const float z = v * ((m2a >> bi) & 1u ? 1.f : 0.2f);
+            L.T2[r_ * LDT + c] = z;
+            a.DZ2a[(row0 + r_) * H + c] = z;
+        });
+    }
+    bar();
+    {   // dZ1a = (dZ2a W2a^T) .* lrelu'(A1a)
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, a3, L.T2, LDT, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int bi) {
+            a.DZ1a[(row0 + r) * H + c] = v * ((m1a >> bi) & 1u ? 1.f : 0.2f);
+        });
+    }
+}
+
+__device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
+    const int tid = threadIdx.x;
+    const int tiles_b = (int)(a.B / R);
+    // interpolate tiles first (the longest chain), then policy, then expert
+    const int sect = wg < tiles_b ? 2 : (wg < 2 * tiles_b ? 0 : 1);
+    const int64_t row0 = (int64_t)(wg % tiles_b) * R;   // row inside the section
+    const int64_t hrow0 = (int64_t)sect * a.B + row0;   // row of the stacked [policy | expert | interpolate] buffers
+    const int ob = a.ob, ac = a.ac, in = ob + ac;
+    const Net& n = a.net;
+    Lds L = carve(lds, in);
+    const int k32 = ((in + 31) / 32) * 32;
+    WPipe pipe;
+    wpipe_init(pipe);
+    const WDesc d1 = w_nn(n.W1, in), d2 = w_nn(n.W2, H), d3 = w_nt(n.W2, H, 0, H);
+    {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134);
+        // loads in batches (see load_rows)
+        const int r = tid >> 4, c0 = tid & 15;
+        const int64_t g = row0 + r;
+        const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g);
+        const int64_t eg = (a.e_start ? a.e_start[0] : 0) + g;
+        const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
+        for (int cb = c0; cb < k32; cb += 16 * kRowBatch) {
+            float pv[kRowBatch], ev[kRowBatch], ee[kRowBatch], m[kRowBatch], sd[kRowBatch];
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) {
+                const int c = cb + 16 * u;
+                pv[u] = 0.f; ev[u] = 0.f; ee[u] = 0.f; m[u] = 0.f; sd[u] = 1.f;
+                if (c < ob) {
+                    if (sect != 1) pv[u] = a.p_obs[pg * ob + c];
+                    if (sect != 0) ev[u] = a.e_obs[eg * ob + c];
+                    if (a.mean) { m[u] = a.mean[c]; sd[u] = a.stdv[c]; }
+                    if (sect == 2 && a.eps_ob) ee[u] = a.eps_ob[g * ob + c];
+                } else if (c < in) {
+                    if (sect != 1) pv[u] = a.p_acs[pg * ac + (c - ob)];
+                    if (sect != 0) ev[u] = a.e_acs[eg * ac + (c - ob)];
+                    if (sect == 2 && a.eps_ob) ee[u] = a.eps_ac[g * ac + (c - ob)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) {
+                const int c = cb + 16 * u;
+                if (c >= k32) continue;
+                float v = 0.f;
+                if (c < in) {
+                    float p = pv[u], e = ev[u], eps = ee[u];
+                    if (c < ob) {
+                        if (a.mean) {
+                            p = fminf(fmaxf((p - m[u]) / sd[u], -5.f), 5.f);
+                            e = fminf(fmaxf((e - m[u]) / sd[u], -5.f), 5.f);
+                        }
+                        if (sect == 2 && !a.eps_ob)
+                            eps = philox_uniform(a.rng_seed, step, RNG_EPS_OB, (uint64_t)(g * ob + c));
+                    } else if (sect == 2 && !a.eps_ob) {
+                        eps = philox_uniform(a.rng_seed, step, RNG_EPS_AC, (uint64_t)(g * ac + (c - ob)));
+                    }
+                    v = sect == 0 ? p : (sect == 1 ? e : eps * p + (1.f - eps) * e);
+                    if (sect != 2) a.X[(hrow0 + r) * in + c] = v;   // interpolate rows: X receives V below
+                }
+                L.X[r * L.px + c] = v;
+            }
+        }
+    }
+    bar();
+    if (sect != 2) {
+        // ---- policy / expert rows
+        hidden_fwd(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
+        hidden_fwd(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, a.A2, hrow0);
+        head1(L.T2, n.W3, n.b3, L.s_);
+        bar();
+        if (tid < R) {
+            const int64_t g = row0 + tid;
+            const float s = L.s_[tid];
+            float z;
+            if (a.eps_ob) {  // injected tensors
+                z = sect == 0 ? (a.fake ? a.fake[g] : 0.f) : (a.real ? a.real[g] : 1.f);
+            } else {         // drawn here (discriminator.py:89-109)
+                const uint64_t step = (uint64_t)a.rng_step[0];
+                if (sect == 0)
+                    z = a.label_smoothing == 2 ? fake_label(philox_uniform(a.rng_seed, step, RNG_FAKE, (uint64_t)g))
+                                               : 0.f;
+                else
+                    z = a.label_smoothing >= 1 ? real_label(philox_uniform(a.rng_seed, step, RNG_REAL, (uint64_t)g))
+                                               : 1.f;
+            }
+            const float sg = sigmoidf_(s);
+            const float dq = (sg - z) / (float)a.B + a.ent_scale * s * sg * (1.f - sg) / (float)(2 * a.B);
+            L.dq[tid] = dq;
+            a.DS[hrow0 + tid] = dq;
+            a.ce[hrow0 + tid] = sig_ce(s, z);
+            a.ent[hrow0 + tid] = sig_ce(s, sg);
+            a.sg[hrow0 + tid] = sg;
+        }
+        bar();
+        head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
+        bar();
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, d3, L.T2, LDT, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int) {
+            a.DZ1[(hrow0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
+        });
+        return;
+    }
+    // ---- interpolate rows: g = d score / d input, sum g^2, V = g / (B dim), tangent forward along V.
+    // The scalar k = 10 * 2 (N - 1) / N needs every tile's sums: it is applied to these rows' share of the
+    // weight gradients after this launch, not here.
+    const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
+    const WDesc t1 = w_nn(n.W1, in), t2 = w_nn(n.W2, H);
+    hidden_fwd(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
+    const unsigned m2 = hidden_fwd(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
+    if (tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
+    bar();
+    head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);                                                    // gz2
+    bar();
+    {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, d3, g0, true, L.T2, LDT, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int) {
+            const float z = v * dlrelu(L.T1[r * LDT + c]);
+            L.T2[r * LDT + c] = z;
+            a.DZ1[(hrow0 + r) * H + c] = z;
+        });
+    }
+    bar();
+    {   // g = gz1 W1^T, 256 input columns at a time, over X (dead by now)
+        auto put = [&](const f32x4 (&acc)[4], int j0) {
+            for_acc(acc, [&](int r, int c, float v, int) {
+                if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
+            });
+        };
+        f32x4 acc[4];
+        zero_acc(acc);
+        if (in > H) {
+            wprod(pipe, g0, g1, true, L.T2, LDT, L.ring, acc);
+            put(acc, 0);
+            zero_acc(acc);
+            wprod(pipe, g1, t1, true, L.T2, LDT, L.ring, acc);
+            put(acc, H);
+        } else {
+            wprod(pipe, g0, t1, true, L.T2, LDT, L.ring, acc);
+            put(acc, 0);
+        }
+    }
+    bar();
+    {
+        const int r = tid >> 4, q = tid & 15;
+        float so = 0.f, sa = 0.f;
+        for (int c = q; c < in; c += 16) {
+            const float g = L.X[r * L.px + c];
+            if (c < ob) so = fmaf(g, g, so); else sa = fmaf(g, g, sa);
+        }
+        so = sum16(so); sa = sum16(sa);
+        if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
+    }
+    bar();
+    if (tid == 0) {
+        double o = 0.0, c = 0.0;
+        for (int r = 0; r < R; ++r) { o += (double)L.red[r]; c += (double)L.red[16 + r]; }
+        a.gp_part[2 * (wg % tiles_b)] = o;
+        a.gp_part[2 * (wg % tiles_b) + 1] = c;
+    }
+    {
+        const float co = 1.f / ((float)a.B * (float)ob), ca = 1.f / ((float)a.B * (float)ac);
+        const int r = tid >> 4, c0 = tid & 15;
+        for (int c = c0; c < in; c += 16) {
+            const float v = L.X[r * L.px + c] * (c < ob ? co : ca);
+            L.X[r * L.px + c] = v;
+            a.X[(hrow0 + r) * in + c] = v;   // V takes the interpolates' place among the layer inputs
+        }
+    }
+    bar();
+    {   // a1dot = (V W1) .* m1, in place over A1
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, t1, t2, true, L.X, L.px, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int) {
+            const float z = v * dlrelu(L.T1[r * LDT + c]);
+            L.T1[r * LDT + c] = z;
+            a.A1[(hrow0 + r) * H + c] = z;
+        });
+    }
+    bar();
+    {   // a2dot = (a1dot W2) .* m2
+        f32x4 acc[4];
+        zero_acc(acc);
+        wprod(pipe, t2, L.T1, LDT, L.ring, acc);
+        for_acc(acc, [&](int r, int c, float v, int bi) {
+            a.A2[(hrow0 + r) * H + c] = v * ((m2 >> bi) & 1u ? 1.f : 0.2f);
+        });
+    }
+}
+
+struct RoleArgs {
+    AgentArgs a;
+    DiscArgs d;
+    int n_tc, n_a, n_d;
+};
+
+__global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int b = blockIdx.x;
+    if (b < s.n_tc) { role_tc(s.a, b, lds); return; }   // longest chain first
+    b -= s.n_tc;
+    if (b < s.n_a) { role_a(s.a, b, lds); return; }
+    b -= s.n_a;
+    role_d(s.d, b, lds);
+}
+
+bool net_ok(const samx_mlp* d) { return d && !d->layernorm && d->h1 == kH && d->h2 == kH; }
+
+}  // namespace
+
+bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B) {
+    return net_ok(actor) && net_ok(critic) && net_ok(reward) && ob > 0 && ac > 0 && ac <= 32 &&
+           ob + ac <= kMaxIn && B > 0 && B % kRows == 0 && actor->in_dim == ob && actor->out_dim == ac &&
+           critic->in_dim == ob + ac && critic->out_dim == 1 && reward->in_dim == ob + ac && reward->out_dim == 1 &&
+           lds_floats(ob + ac) * sizeof(float) <= 160 * 1024;
+}
+
+int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t st) {
+    RoleArgs s;
+    s.n_tc = s.n_a = s.n_d = 0;
+    int in = 0;
+    if (a && (roles & 3)) {
+        s.a = *a;
+        if (roles & 2) s.n_tc = (int)(a->B / kRows);
+        if (roles & 1) s.n_a = (int)(a->B / kRows);
+        in = a->ob + a->ac;
+    }
+    if (d && (roles & 4)) {
+        s.d = *d;
+        s.n_d = 3 * (int)(d->B / kRows);
+        in = d->ob + d->ac;
+    }
+    if (s.n_tc + s.n_a + s.n_d == 0) return SAMX_OK;
+    const size_t lds = lds_floats(in) * sizeof(float);
+    SAMX_REQUIRE(lds <= 160 * 1024, "wide role kernel needs %zu bytes of LDS", lds);
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)roles_kernel, lds)) return rc;
+    roles_kernel<<<(unsigned)(s.n_tc + s.n_a + s.n_d), NT, lds, st>>>(s);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+}  // namespace wide
+}  // namespace samx
+
+#ifdef SAMX_TRACE
+extern "C" int samx_debug_wide_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::wide::g_wtrace), sizeof(unsigned long long) * 128);
+}
+#endif

@@ -24,4 +24,13 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
                   float ent_reg_scale, float* losses_out, float* grad_out, void* ws, size_t ws_bytes,
                   const DiscSrc* src, void* stream);
 
+// 256x256 leaky-ReLU learners (Humanoid-shaped): the role-fused kernel of fused_wide.hip for the chains of
+// layer products, then the batch reductions (weight gradients) and the scalar losses.  The agent roles go
+// to st_agent, the discriminator's to st_disc (the caller forks / joins them).  ws_tc / ws_a: one
+// samx_nets_ws_bytes workspace per agent role, ws_d: samx_disc_ws_bytes.
+bool wide_step_supported(const samx_learner* L, int64_t B);
+int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
+                    size_t nets_bytes, void* ws_d, size_t disc_bytes, bool do_a, bool do_d, hipStream_t st_agent,
+                    hipStream_t st_disc);
+
 }  // namespace samx

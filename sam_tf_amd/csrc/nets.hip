@@ -5,6 +5,7 @@
 #include "samx_common.h"
 #include "gemm.h"
 #include "nets.h"
+#include "fused_wide.h"
 #include "rng.h"
 #include "../../include/samx.h"
 #include <math.h>
@@ -1263,6 +1264,125 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
     disc_losses_kernel<<<1, 1024, 0, st>>>(w.ce, w.ent, w.sg, w.gp, B, ent_reg_scale, gp_coeff,
                                            losses_out);
     SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+namespace {
+// gradient-penalty scalar k = 10 * 2 (N - 1) / N from the interpolate tiles' sums of squares
+// (discriminator.py:138-140,154); the interpolate rows' cotangents (DS, DZ2, DZ1 rows [2B, 3B)) were
+// written without it
+__global__ __launch_bounds__(256) void gp_finish_kernel(const double* __restrict__ gp_part, int tiles, int64_t B,
+                                                        int ob, int ac, float coeff, float* __restrict__ gp_out,
+                                                        float* __restrict__ DS, float* __restrict__ DZ2,
+                                                        float* __restrict__ DZ1, int h) {
+    __shared__ double sh[4];
+    double so = 0.0, sa = 0.0;
+    for (int i = threadIdx.x; i < tiles; i += 256) { so += gp_part[2 * i]; sa += gp_part[2 * i + 1]; }
+    so = block_sum_d(so, sh);
+    sa = block_sum_d(sa, sh);
+    const double N = sqrt(so / ((double)B * ob) + sa / ((double)B * ac));
+    const float k = (float)((double)coeff * 2.0 * (N - 1.0) / N);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gp_out[0] = (float)((N - 1.0) * (N - 1.0));
+    const int64_t n = B * h;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        DZ2[2 * n + t] *= k;
+        DZ1[2 * n + t] *= k;
+        if (t < B) DS[2 * B + t] = k;
+    }
+}
+}  // namespace
+
+bool wide_step_supported(const samx_learner* L, int64_t B) {
+    return wide::supported(&L->actor, &L->critic, &L->reward, L->ob_dim, L->ac_dim, B) && !L->ret_mean &&
+           L->n_step == 0 && L->d_actor_loss_scale == 0.f && B / wide::kRows <= kGpBlocks;
+}
+
+int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
+                    size_t nets_bytes, void* ws_d, size_t disc_bytes, bool do_a, bool do_d, hipStream_t st_agent,
+                    hipStream_t st_disc) {
+    const int64_t B = b->B;
+    const samx_mlp *da = &L->actor, *dc = &L->critic, *dd = &L->reward;
+    const int64_t Pa = samx_mlp_param_count(da), Pc = samx_mlp_param_count(dc);
+    const int ob = L->ob_dim, ac = L->ac_dim;
+    auto net = [](const Net& n) { return wide::Net{n.W1, n.b1, n.W2, n.b2, n.W3, n.b3, n.in, n.out}; };
+    if (do_a) {
+        Arena a1(ws_tc, nets_bytes), a2(ws_a, nets_bytes);
+        AgentWs w1 = carve_agent(a1, da, dc, nullptr, B), w2 = carve_agent(a2, da, dc, nullptr, B);
+        if (!a1.ok() || !a2.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: agent workspace too small");
+        Net na = split(da, L->params), nc = split(dc, L->params + Pa);
+        Net ta = split(da, L->targets), tc = split(dc, L->targets + Pa);
+        wide::AgentArgs a;
+        a.obs0 = b->obs0; a.acs = b->acs; a.rews = b->rews; a.dones1 = b->dones1; a.obs1 = b->obs1;
+        a.iws = b->iws; a.td_len = b->td_len; a.mean = L->mu_mean; a.stdv = L->mu_std;
+        a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
+        a.actor = net(na); a.critic = net(nc); a.targ_actor = net(ta); a.targ_critic = net(tc);
+        a.ob = ob; a.ac = ac; a.B = B;
+        a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
+        a.targ_q = o->targ_q; a.td_out = o->td;
+        a.Xc = w1.XC; a.A1c = w1.hc.A1; a.A2c = w1.hc.A2; a.DZ1c = w1.kc.DZ1; a.DZ2c = w1.kc.DZ2;
+        a.row_hub = w1.row0; a.row_dq = w1.row1;
+        a.Xa = w2.XC; a.A1a = w2.ha.A1; a.A2a = w2.ha.A2; a.DZ1a = w2.ka.DZ1; a.DZ2a = w2.ka.DZ2;
+        a.dPre = w2.dPre; a.row_q = w2.row0;
+        TRY(wide::launch_roles(&a, nullptr, 3, st_agent));
+        hipStream_t st = st_agent;
+        // critic: weight gradients (+ weight decay) and losses   (sam_agent.py:457-520)
+        float* gc = L->grads + Pa;
+        TRY(wgrad(w1.hc.A2, nc.h2, nc.h2, w1.row1, 1, 1, B, B, gc + nc.oW3, 0.f, nullptr, w1.partials,
+                  w1.partial_floats, st));
+        TRY(wgrad(w1.hc.A1, nc.h1, nc.h1, w1.kc.DZ2, nc.h2, nc.h2, B, B, gc + nc.oW2, L->wd_scale, nc.W2,
+                  w1.partials, w1.partial_floats, st));
+        TRY(wgrad(w1.XC, nc.in, nc.in, w1.kc.DZ1, nc.h1, nc.h1, B, B, gc + nc.oW1, L->wd_scale, nc.W1, w1.partials,
+                  w1.partial_floats, st));
+        if (L->wd_scale > 0.f) {
+            wd_sumsq_kernel<<<kWdBlocks, 256, 0, st>>>(nc.W1, (int64_t)nc.in * nc.h1, nc.W2, (int64_t)nc.h1 * nc.h2,
+                                                       w1.wd_part);
+            SAMX_LAUNCH_CHECK();
+        }
+        critic_losses_kernel<<<1, 1024, 0, st>>>(w1.row0, B, L->td_loss_scale, L->wd_scale, w1.wd_part, kWdBlocks,
+                                                 o->critic_losses, nullptr, 0.f);
+        SAMX_LAUNCH_CHECK();
+        // actor   (sam_agent.py:406-433)
+        float* ga = L->grads;
+        TRY(wgrad(w2.ha.A2, na.h2, na.h2, w2.dPre, ac, ac, B, B, ga + na.oW3, 0.f, nullptr, w2.partials,
+                  w2.partial_floats, st));
+        TRY(wgrad(w2.ha.A1, na.h1, na.h1, w2.ka.DZ2, na.h2, na.h2, B, B, ga + na.oW2, 0.f, nullptr, w2.partials,
+                  w2.partial_floats, st));
+        TRY(wgrad(w2.XC, ob + ac, ob, w2.ka.DZ1, na.h1, na.h1, B, B, ga + na.oW1, 0.f, nullptr, w2.partials,
+                  w2.partial_floats, st));
+        actor_losses_kernel<<<1, 1024, 0, st>>>(w2.row0, nullptr, B, L->q_actor_loss_scale, 0.f, o->actor_losses);
+        SAMX_LAUNCH_CHECK();
+    }
+    if (do_d) {
+        hipStream_t st = st_disc;
+        Arena ar(ws_d, disc_bytes);
+        DiscWs w = carve_disc(ar, dd, B);
+        if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: discriminator workspace too small");
+        Net nd = split(dd, L->params + Pa + Pc);
+        wide::DiscArgs d;
+        d.p_obs = b->p_obs; d.p_acs = b->p_acs; d.e_obs = b->e_obs; d.e_acs = b->e_acs;
+        d.eps_ob = b->eps_ob; d.eps_ac = b->eps_ac; d.real = b->real_labels; d.fake = b->fake_labels;
+        d.mean = L->d_mean; d.stdv = L->d_std;
+        d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
+        d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
+        d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
+        d.X = w.X; d.A1 = w.h.A1; d.A2 = w.h.A2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
+        d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part;
+        TRY(wide::launch_roles(nullptr, &d, 4, st));
+        const float gp_coeff = 10.f;  // discriminator.py:154
+        gp_finish_kernel<<<256, 256, 0, st>>>(w.gp_part, (int)(B / wide::kRows), B, ob, ac, gp_coeff, w.gp, w.DS,
+                                              w.k.DZ2, w.k.DZ1, nd.h1);
+        SAMX_LAUNCH_CHECK();
+        float* gd = L->grads + Pa + Pc;
+        const int64_t M = 3 * B;
+        TRY(wgrad(w.h.A2, nd.h2, nd.h2, w.DS, 1, 1, M, 2 * B, gd + nd.oW3, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.h.A1, nd.h1, nd.h1, w.k.DZ2, nd.h2, nd.h2, M, 2 * B, gd + nd.oW2, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        TRY(wgrad(w.X, nd.in, nd.in, w.k.DZ1, nd.h1, nd.h1, M, 2 * B, gd + nd.oW1, 0.f, nullptr, w.partials,
+                  w.partial_floats, st));
+        disc_losses_kernel<<<1, 1024, 0, st>>>(w.ce, w.ent, w.sg, w.gp, B, L->ent_reg_scale, gp_coeff, o->d_losses);
+        SAMX_LAUNCH_CHECK();
+    }
     return SAMX_OK;
 }
 

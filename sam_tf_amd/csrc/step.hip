@@ -679,6 +679,41 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
                                   do_d ? L->steps + 2 : nullptr, st);
     }
+    static int no_wide = -1;   // SAMX_NO_WIDE=1: 256x256 learners take the layer-wise path too (A/B comparisons)
+    if (no_wide < 0) { const char* e = getenv("SAMX_NO_WIDE"); no_wide = e ? atoi(e) : 0; }
+    if (!use_fused(L, B) && !no_wide && !t_only && !t_done && samx::wide_step_supported(L, B)) {
+        // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions; the agent roles on a side
+        // stream, the discriminator (behind its running-statistics update) on the caller's
+        hipStream_t s_agent = st;
+        SideStreams* ss = nullptr;
+        if (do_a && do_d) {
+            rc = side_streams(&ss);
+            if (rc != SAMX_OK) return rc;
+            SAMX_CHECK_HIP(hipEventRecord(ss->fork, st));
+            SAMX_CHECK_HIP(hipStreamWaitEvent(ss->s[0], ss->fork, 0));
+            s_agent = ss->s[0];
+        }
+        if (b->d_rms_sums && do_d) {  // d.obs_rms.update on this row's D batch (sam.py:389-390), committed
+            rc = samx_d_input_stats(b->p_obs, b->ring_start, b->ring_len, b->p_idx, b->e_obs, b->e_start, B,
+                                    L->ob_dim, const_cast<double*>(b->d_rms_addvec), 1, b->d_rms_sums,
+                                    const_cast<float*>(L->d_mean), const_cast<float*>(L->d_std), w.stats_ws,
+                                    w.stats_bytes, stream);
+            if (rc != SAMX_OK) return rc;
+        }
+        rc = samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes, do_a,
+                                   do_d, s_agent, st);
+        if (rc != SAMX_OK) return rc;
+        if (ss) {
+            SAMX_CHECK_HIP(hipEventRecord(ss->join[0], ss->s[0]));
+            SAMX_CHECK_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
+        }
+        if (!(part & 2)) return SAMX_OK;
+        fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
+        rc = fused::launch_seg_sumsq(f, st);
+        if (rc != SAMX_OK) return rc;
+        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
+                                  do_d ? L->steps + 2 : nullptr, st);
+    }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense
         // rows and materialised randoms, so indirection / in-kernel draws are resolved first.

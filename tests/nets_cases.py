@@ -18,6 +18,11 @@ CONFIGS = {
     's_7x5': (7, 5, 64, 64, 80),
     's_20x4': (20, 4, 64, 64, 48),
     's_13x2': (13, 2, 64, 64, 1024),
+    # 256x256 nets: the role-fused path (fused_wide.hip): narrow input, the widest action head it takes, an
+    # input that is not a multiple of 4, one tile
+    'w_20x3': (20, 3, 256, 256, 48),
+    'w_40x32': (40, 32, 256, 256, 32),
+    'w_7x17': (7, 17, 256, 256, 16),
 }
 
 

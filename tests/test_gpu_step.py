@@ -65,6 +65,8 @@ def _oracle(c, d_scale, ent, per, rms=True):
     ('C2', 0.5, 0.0, False, False, False),
     ('ragged', 0.5, 0.0, True, True, False),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
     ('C4', 0.0, 0.0, False, True, False),
+    ('w_20x3', 0.0, 0.0, False, True, False), ('w_40x32', 0.0, 1e-3, True, True, False),
+    ('w_7x17', 0.0, 0.0, True, False, False), ('w_20x3', 0.5, 0.0, True, True, False),
     # with_layernorm (launcher default, mujoco_sam_imitate.sh): two-stream GP backward; 64x64 nets on the
     # whole-network LayerNorm kernels (fused_ln.hip), the rest on the layer-wise path
     ('C2', 0.5, 1e-3, True, True, True), ('ragged', 0.5, 0.0, False, True, True),

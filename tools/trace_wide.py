@@ -1,0 +1,33 @@
+"""Phase timestamps of the 256-wide role-fused kernel (needs a libsamx.so built with -DSAMX_TRACE:
+   SAMX_EXTRA_FLAGS=-DSAMX_TRACE python -m sam_tf_amd.build --force).  Prints microseconds since the
+   target+critic workgroup 0's first timestamp (wall_clock64, 100 MHz).  SAMX_WIDE_ALONE=1: only the agent
+   roles run (no discriminator beside them)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sam_tf_amd import ops, _lib  # noqa: E402
+from sam_tf_amd.comm import TorchComm  # noqa: E402
+
+dev = torch.device('cuda', 0)
+cfg = dict(bench.CONFIGS['C4'])
+mu, d, pool, drv = bench.build_learner(cfg, TorchComm(dev), dev, 0, True)
+drv.prepare(1)
+drv.run(8)
+lib = C.CDLL(_lib.SO_PATH)
+buf = (C.c_ulonglong * 128)()
+acc = np.zeros((20, 128))
+part = 1 | (4 if os.environ.get('SAMX_WIDE_ALONE') == '1' else 0)
+for it in range(20):
+    ops.step_grads_part(drv.L, drv.batch, drv.out, part)
+    torch.cuda.synchronize()
+    assert lib.samx_debug_wide_trace(buf) == 0
+    acc[it] = np.array(buf[:], dtype=np.float64)
+t = acc[5:, :32]
+rel = (t - t[:, :1]) / 100.0
+print('target+critic', ' '.join('%d:%.2f' % (i, x) for i, x in enumerate(np.median(rel, axis=0)) if t[0, i] > 0))
