@@ -358,7 +358,8 @@ typedef struct samx_batch {  /* device inputs of one step; B rows each */
      * at once.  The discriminator normalises with the statistics of d_rms_sums + d_rms_addvec, and at
      * the end d_rms_sums (double[2*ob+1]) is advanced and learner.d_mean / d_std are rewritten (they
      * are outputs in this mode).  Single process only (N > 1 needs the all-reduce of line 55 in
-     * between) and only on the whole-network fused path, else SAMX_ERR_UNSUPPORTED. */
+     * between).  On the layer-wise path (samx_step_path == 0) samx_step_grads computes the batch's sums
+     * itself (d_rms_addvec receives them; needs p_idx and e_start). */
     double* d_rms_sums;
     const double* d_rms_addvec;
     int64_t num_entries; /* entries in the replay ring: bounds the n-step lookahead window */
@@ -382,6 +383,12 @@ typedef struct samx_step_out {
 } samx_step_out;
 
 int samx_fused_supported(const samx_learner* L, int64_t B);
+/* Which kernels samx_step_grads runs for this learner and batch size: 1 = the whole-network fused kernels
+ * (64x64 nets), 2 = the role-fused kernel for 256x256 leaky-ReLU nets without LayerNorm (one launch for the
+ * layer chains of every role, one grouped launch for the weight-gradient products, one reduction), 0 = the
+ * layer-wise GEMM path.  Paths 1 and 2 take batch.d_rms_addvec as an INPUT (the batch's sums, computed
+ * ahead), path 0 computes it. */
+int samx_step_path(const samx_learner* L, int64_t B);
 
 /* The numbers samx_step_grads draws for update number `step` (0-based reward-net update count) when
  * batch.eps_ob is NULL, written out so a checker can replay the same update.  real/fake may be NULL. */
@@ -444,6 +451,13 @@ int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t
                            const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start,
                            int64_t idx_stride, int64_t B, int ob_dim, double* addvec,
                            int64_t addvec_stride, int64_t K, void* stream);
+/* The same for any batch size: 2*B*ob_dim > 16384 takes the two-stage sums of samx_d_input_stats for the K
+ * steps in two launches; ws: K * samx_d_input_stats_ws_bytes(B, ob_dim) bytes (may be NULL for the small
+ * sizes). */
+int samx_d_input_sums_many_ws(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                              const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start,
+                              int64_t idx_stride, int64_t B, int ob_dim, double* addvec, int64_t addvec_stride,
+                              int64_t K, void* ws, size_t ws_bytes, void* stream);
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B);
 
 /* d.get_grads/get_losses + mu's get_targ_q / actor & critic losses and grads (sam.py:398-399,

@@ -116,6 +116,7 @@ SIGNATURES = {
                                  _F, _P, _P, _P, _SZ, _P]),
     'samx_reward': (C.c_int, [_MP, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P, _P, _SZ, _P]),
     'samx_fused_supported': (C.c_int, [_LP, _I64]),
+    'samx_step_path': (C.c_int, [_LP, _I64]),
     'samx_disc_randoms': (C.c_int, [C.c_uint64, _I64, _I64, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     'samx_d_input_stats': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
                                      _P, _SZ, _P]),
@@ -124,6 +125,8 @@ SIGNATURES = {
     'samx_d_input_stats_static': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P, _P, _P,
                                             _P]),
     'samx_d_input_sums_many': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _I64, _P]),
+    'samx_d_input_sums_many_ws': (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _I64, _P,
+                                            _SZ, _P]),
     'samx_step_ws_bytes': (_SZ, [_LP, _I64]),
     'samx_step_grads': (C.c_int, [_LP, _BP, _OP, _P, _SZ, _P]),
     'samx_step_grads_part': (C.c_int, [_LP, _BP, _OP, _P, _SZ, C.c_int, _P]),

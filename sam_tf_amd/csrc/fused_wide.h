@@ -30,13 +30,21 @@ struct AgentArgs {
     float *targ_q, *td_out;
     float *Xc, *A1c, *A2c, *DZ1c, *DZ2c;   // [B][ob+ac], [B][256] x 4
     float *row_hub, *row_dq;               // [B] huber * iw ; d loss / d score
+    float* w3c_part;                       // [B/16][257]: per-tile A2c^T dq (256) and sum dq: the head's gradient
     // actor role
     float *Xa, *A1a, *A2a, *DZ1a, *DZ2a;   // [B][ob+ac] (obz0 | mu(obz0)), [B][256] x 4
     float *dPre, *row_q;                   // [B][ac] ; [B] Q(obz0, mu(obz0))
+    // weight decay (network_util.py:43-56): wd_blocks extra workgroups leave float64 partial sums of squares of
+    // the critic's two hidden kernels in wd_part[wd_blocks] (0 = off)
+    double* wd_part;
+    int wd_blocks;
 };
 
 struct DiscArgs {
     const float *p_obs, *p_acs, *e_obs, *e_acs, *eps_ob, *eps_ac, *real, *fake, *mean, *stdv;
+    // rms_sums != null: the rows are normalised with the statistics of rms_sums + rms_addvec (double[2 ob + 1]
+    // each: the running sums and this batch's, helpers/mpi_running_mean_std.py:31-45) instead of mean / stdv
+    const double *rms_sums, *rms_addvec;
     const int64_t *p_idx, *e_start;
     int64_t ring_start, ring_len;
     uint64_t rng_seed;
@@ -50,6 +58,8 @@ struct DiscArgs {
     float *X, *A1, *A2, *DZ1, *DZ2;   // [3B][ob+ac], [3B][256] x 4
     float *DS, *ce, *ent, *sg;        // [3B] ; [2B] x 3
     double* gp_part;                  // [B/16][2]
+    // per-tile head gradient [3B/16][257], tiles in launch order: interpolate (sum a2dot, 0), policy, expert
+    float* w3_part;
 };
 
 bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B);

@@ -275,6 +275,21 @@ __device__ __forceinline__ void head1(const float* T, const float* __restrict__ 
     if (q == 0) s_out[r] = acc + b3[0];
 }
 
+// this tile's share of the head's gradient: slot[c] = sum_r T[r][c] dq[r] (c < 256), slot[256] = sum_r dq[r].
+// Thread t reads only column t of T: head_bwd (same thread, same column) may follow without a barrier.
+__device__ __forceinline__ void head_grad_slot(const float* T, const float* dq, float* __restrict__ slot) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s = fmaf(T[r * LDT + c], dq[r], s);
+    slot[c] = s;
+    if (c == 0) {
+        float b = 0.f;
+        for (int r = 0; r < R; ++r) b += dq[r];
+        slot[H] = b;
+    }
+}
+
 // T[r][c] = dq[r] * w3[c] * lrelu'(T[r][c]) in place, and to hbm
 __device__ __forceinline__ void head_bwd(float* T, const float* dq, const float* __restrict__ w3,
                                          float* __restrict__ hbm, int64_t row0) {
@@ -441,6 +456,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         if (a.td_out) a.td_out[row0 + tid] = td;
     }
     bar();
+    head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
     head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
     bar();
     WTRACE(wg, 0, 11);
@@ -559,6 +575,30 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc d1 = w_nn(n.W1, in), d2 = w_nn(n.W2, H), d3 = w_nt(n.W2, H, 0, H);
+    // statistics the rows are normalised with, staged in LDS (over T1, unused until the first product).
+    // d.obs_rms.update folded into the step: the batch's float64 column sums were computed ahead, every
+    // workgroup derives the mean/std that INCLUDE this batch from sums + addvec — the same arithmetic as the
+    // commit behind this launch (nets.hip wide_finish_kernel), hence the same bits.
+    const bool norm = a.rms_sums != nullptr || a.mean != nullptr;
+    float* ms = L.T1;   // [0, kMaxIn) mean, [kMaxIn, 2 kMaxIn) std
+    if (norm) {
+        for (int c = tid; c < ob; c += NT) {
+            float gm, gs;
+            if (a.rms_sums) {
+                const double cnt = a.rms_sums[2 * ob] + a.rms_addvec[2 * ob];
+                const double s1 = __dadd_rn(a.rms_sums[c], a.rms_addvec[c]),
+                             s2 = __dadd_rn(a.rms_sums[ob + c], a.rms_addvec[ob + c]);
+                const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+                gm = mean;
+                gs = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+            } else {
+                gm = a.mean[c]; gs = a.stdv[c];
+            }
+            ms[c] = gm;
+            ms[kMaxIn + c] = gs;
+        }
+        bar();
+    }
     {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134);
         // loads in batches (see load_rows)
         const int r = tid >> 4, c0 = tid & 15;
@@ -575,7 +615,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
                 if (c < ob) {
                     if (sect != 1) pv[u] = a.p_obs[pg * ob + c];
                     if (sect != 0) ev[u] = a.e_obs[eg * ob + c];
-                    if (a.mean) { m[u] = a.mean[c]; sd[u] = a.stdv[c]; }
+                    if (norm) { m[u] = ms[c]; sd[u] = ms[kMaxIn + c]; }
                     if (sect == 2 && a.eps_ob) ee[u] = a.eps_ob[g * ob + c];
                 } else if (c < in) {
                     if (sect != 1) pv[u] = a.p_acs[pg * ac + (c - ob)];
@@ -591,7 +631,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
                 if (c < in) {
                     float p = pv[u], e = ev[u], eps = ee[u];
                     if (c < ob) {
-                        if (a.mean) {
+                        if (norm) {
                             p = fminf(fmaxf((p - m[u]) / sd[u], -5.f), 5.f);
                             e = fminf(fmaxf((e - m[u]) / sd[u], -5.f), 5.f);
                         }
@@ -638,6 +678,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             a.sg[hrow0 + tid] = sg;
         }
         bar();
+        head_grad_slot(L.T2, L.dq, a.w3_part + (int64_t)wg * (H + 1));
         head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
         bar();
         f32x4 acc[4];
@@ -735,6 +776,19 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         for_acc(acc, [&](int r, int c, float v, int bi) {
             a.A2[(hrow0 + r) * H + c] = v * ((m2 >> bi) & 1u ? 1.f : 0.2f);
         });
+        // head gradient of these rows: sum_r a2dot[r][c] (without k), rows in a fixed order
+        float* slot = a.w3_part + (int64_t)wg * (H + 1);
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += acc[nb][j] * ((m2 >> (nb * 4 + j)) & 1u ? 1.f : 0.2f);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (lane < 16) slot[64 * wv + 16 * nb + lane] = sm;
+        }
+        if (tid == 0) slot[H] = 0.f;
     }
 }
 
@@ -744,6 +798,25 @@ struct RoleArgs {
     int n_tc, n_a, n_d;
 };
 
+// partial sums of squares of the decayed kernels: workgroup b of n takes elements b * NT + tid, + n * NT, ...
+__device__ inline void role_wd(const AgentArgs& a, int b) {
+    __shared__ double sh[NT / 64];
+    const int64_t n1 = (int64_t)(a.ob + a.ac) * H, n2 = (int64_t)H * H;
+    double s = 0.0;
+    for (int64_t i = (int64_t)b * NT + threadIdx.x; i < n1 + n2; i += (int64_t)a.wd_blocks * NT) {
+        const double w = (double)(i < n1 ? a.critic.W1[i] : a.critic.W2[i - n1]);
+        s += w * w;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < NT / 64; ++i) t += sh[i];
+        a.wd_part[b] = t;
+    }
+}
+
 __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int b = blockIdx.x;
@@ -751,7 +824,8 @@ __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     b -= s.n_tc;
     if (b < s.n_a) { role_a(s.a, b, lds); return; }
     b -= s.n_a;
-    role_d(s.d, b, lds);
+    if (b < s.n_d) { role_d(s.d, b, lds); return; }
+    role_wd(s.a, b - s.n_d);
 }
 
 bool net_ok(const samx_mlp* d) { return d && !d->layernorm && d->h1 == kH && d->h2 == kH; }
@@ -780,12 +854,13 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
         s.n_d = 3 * (int)(d->B / kRows);
         in = d->ob + d->ac;
     }
+    const int n_wd = (a && (roles & 2) && a->wd_part) ? a->wd_blocks : 0;
     if (s.n_tc + s.n_a + s.n_d == 0) return SAMX_OK;
     const size_t lds = lds_floats(in) * sizeof(float);
     SAMX_REQUIRE(lds <= 160 * 1024, "wide role kernel needs %zu bytes of LDS", lds);
     static LdsGrant grant;
     if (int rc = grant.ensure((const void*)roles_kernel, lds)) return rc;
-    roles_kernel<<<(unsigned)(s.n_tc + s.n_a + s.n_d), NT, lds, st>>>(s);
+    roles_kernel<<<(unsigned)(s.n_tc + s.n_a + s.n_d + n_wd), NT, lds, st>>>(s);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -48,6 +48,18 @@ struct GemmArgs {
 
 int gemm(const GemmArgs& g, hipStream_t stream);
 
+// Up to kGemmGroupMax split weight-gradient products (A and B free-contiguous, nsplit >= 2) in ONE launch;
+// only the partial sums are written ([nsplit][Mo][N] per problem, split z covers the reduction indices
+// [z * chunk, (z + 1) * chunk), chunk = gemm_split_chunk(R, nsplit)): the caller reduces them.
+// The same launch can also add up small per-tile slot arrays (extra workgroups at the end of the grid):
+// out[c] = sum over z < n of slots[z * width + c], 16 lanes per element (lane l takes z = l, l + 16, ...,
+// then a fixed xor tree).
+constexpr int kGemmGroupMax = 10, kSlotSumMax = 3;
+struct SlotSum { const float* slots; int n, width; float* out; };
+int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums = nullptr,
+                        int nsums = 0);
+inline int gemm_split_chunk(int R, int nsplit) { return ((R + nsplit - 1) / nsplit + 31) / 32 * 32; }
+
 // number of r-splits that fills the chip for a weight-gradient GEMM
 int pick_nsplit(int Mo, int N, int R);
 

@@ -204,7 +204,7 @@ __device__ __forceinline__ void wait_vm() {
 //         dependent MFMAs per wave is what such a launch waits for, and this cuts it by four.
 // A_W / B_W: the operand is staged with 16-byte DMAs (see the header).
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
-__global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz) {
     // A "step" covers SPB consecutive 32-deep stages behind ONE barrier: the 16-wave variant has only
     // four MFMAs per wave and stage, so it takes two stages per barrier (a barrier + wait + issue round
     // costs ~0.4 us there against 0.44 us of matrix-core time per stage).
@@ -225,13 +225,13 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int quad = wave & 3, slice = wave >> 2;
     const int wm = quad >> 1, wn = quad & 1;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int i0 = by * BM, j0 = bx * BN;
     const bool ones = g.a_ones_rows >= 0;
     const int Mo = g.M + (ones ? 1 : 0);
     int r_begin = 0, r_end = g.R;
     if (g.nsplit > 1) {
         int chunk = ((g.R + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
-        r_begin = blockIdx.z * chunk;
+        r_begin = bz * chunk;
         r_end = min(g.R, r_begin + chunk);
     }
     f32x16 acc;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             const int i = row_of(n);
-            if (i < Mo && jv) g.partials[((int64_t)blockIdx.z * Mo + i) * g.N + j] = val[n];
+            if (i < Mo && jv) g.partials[((int64_t)bz * Mo + i) * g.N + j] = val[n];
         }
     } else {
         float bj = 0.f, ax[NQ], ad[NQ];
@@ -430,6 +430,45 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
 #ifdef SAMX_TRACE
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_gemm_trace[62] = clock64();
 #endif
+}
+
+template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
+__global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
+    gemm_tile<A_RC, B_RC, KS, A_W, B_W>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient products (TN: both operands free-contiguous, 16-byte staging, split over the
+// reduction) in ONE launch: the partial sums of every (problem, split, tile) go to that problem's partials
+// buffer; the caller's reduction finishes them.  blockIdx.x -> (problem, tile x, tile y, split).
+struct GemmGroup {
+    GemmArgs g[kGemmGroupMax];
+    int first[kGemmGroupMax + 1];   // first block of each problem
+    int gx[kGemmGroupMax], gy[kGemmGroupMax];
+    int n;
+    SlotSum sums[kSlotSumMax];
+    int sum_first[kSlotSumMax + 1];   // first 16-lane group of each slot sum
+    int nsums;
+};
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup G) {
+    int p = 0;
+    const int b = blockIdx.x;
+    if (b >= G.first[G.n]) {   // slot sums
+        const int g = ((b - G.first[G.n]) * 256 + (int)threadIdx.x) >> 4, l = threadIdx.x & 15;
+        int q = 0;
+        while (q < G.nsums && g >= G.sum_first[q + 1]) ++q;
+        if (q >= G.nsums) return;   // whole 16-lane groups leave together
+        const SlotSum& s = G.sums[q];
+        const int c = g - G.sum_first[q];
+        float sm = 0.f;
+        for (int z = l; z < s.n; z += 16) sm += s.slots[(int64_t)z * s.width + c];
+        for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+        if (l == 0) s.out[c] = sm;
+        return;
+    }
+    while (p + 1 < G.n && b >= G.first[p + 1]) ++p;
+    const int local = b - G.first[p];
+    const int bx = local % G.gx[p], by = (local / G.gx[p]) % G.gy[p], bz = local / (G.gx[p] * G.gy[p]);
+    gemm_tile<false, false, 1, true, true>(G.g[p], bx, by, bz);
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo) {
@@ -498,6 +537,48 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace
+
+int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums) {
+    SAMX_REQUIRE(list && n > 0 && n <= kGemmGroupMax, "gemm_group_partials: 1..%d problems", kGemmGroupMax);
+    SAMX_REQUIRE(nsums >= 0 && nsums <= kSlotSumMax && (nsums == 0 || sums), "gemm_group_partials: 0..%d slot sums",
+                 kSlotSumMax);
+    GemmGroup G;
+    G.n = n;
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        const GemmArgs& g = list[p];
+        SAMX_REQUIRE(g.A && g.B && g.partials && g.M > 0 && g.N > 0 && g.R > 0 && g.nsplit >= 2,
+                     "gemm_group_partials: problem %d needs operands, a partials buffer and nsplit >= 2", p);
+        const int ea = g.M, eb = g.N;
+        SAMX_REQUIRE(g.a_si == 1 && g.b_sj == 1 && ea >= 4 && eb >= 4 && (ea % 4 == 0 || g.overread_ok) &&
+                         (eb % 4 == 0 || g.overread_ok),
+                     "gemm_group_partials: problem %d is not a free-contiguous product with 16-byte staging", p);
+        const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
+        G.g[p] = g;
+        G.gx[p] = cdiv(g.N, BN);
+        G.gy[p] = cdiv(Mo, BM);
+        G.first[p] = blocks;
+        blocks += G.gx[p] * G.gy[p] * g.nsplit;
+    }
+    G.first[n] = blocks;
+    G.nsums = nsums;
+    int groups = 0;
+    for (int q = 0; q < nsums; ++q) {
+        SAMX_REQUIRE(sums[q].slots && sums[q].out && sums[q].n > 0 && sums[q].width > 0,
+                     "gemm_group_partials: slot sum %d", q);
+        G.sums[q] = sums[q];
+        G.sum_first[q] = groups;
+        groups += sums[q].width;
+    }
+    G.sum_first[nsums] = groups;
+    blocks += (groups * 16 + 255) / 256;
+    constexpr size_t lds = (size_t)ring<1>() * 2 * TILE * sizeof(float);
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)gemm_group_kernel, lds, 64 * 1024)) return rc;
+    gemm_group_kernel<<<blocks, 256, lds, stream>>>(G);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
 
 int pick_nsplit(int Mo, int N, int R) {
     int tiles = cdiv(Mo, BM) * cdiv(N, BN);

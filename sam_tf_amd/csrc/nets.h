@@ -24,13 +24,18 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
                   float ent_reg_scale, float* losses_out, float* grad_out, void* ws, size_t ws_bytes,
                   const DiscSrc* src, void* stream);
 
-// 256x256 leaky-ReLU learners (Humanoid-shaped): the role-fused kernel of fused_wide.hip for the chains of
-// layer products, then the batch reductions (weight gradients) and the scalar losses.  The agent roles go
-// to st_agent, the discriminator's to st_disc (the caller forks / joins them).  ws_tc / ws_a: one
-// samx_nets_ws_bytes workspace per agent role, ws_d: samx_disc_ws_bytes.
+// 256x256 leaky-ReLU learners (Humanoid-shaped): ONE launch of the role-fused kernel of fused_wide.hip for
+// the chains of layer products of every role, ONE grouped launch for the weight-gradient products, ONE
+// reduction.  ws_tc / ws_a: one samx_nets_ws_bytes workspace per agent role, ws_d: samx_disc_ws_bytes.
 bool wide_step_supported(const samx_learner* L, int64_t B);
+size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B);
+// Fills learner.grads, the per-segment sums of squares (sumsq, fused::kMaxSegBlocks per optimiser) and the
+// losses, and ticks the step counters of the roles it ran.  part bit 0: the role launch and the grouped
+// products (with the head-gradient slot sums); bit 1: the reduction that finishes the gradients, with the
+// scalar losses, the statistics commit (batch.d_rms_sums: the batch's sums were computed ahead, as on the fused
+// path) and the counter tick.  Four launches per step with samx_step_apply, all on the caller's stream.
 int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
-                    size_t nets_bytes, void* ws_d, size_t disc_bytes, bool do_a, bool do_d, hipStream_t st_agent,
-                    hipStream_t st_disc);
+                    size_t nets_bytes, void* ws_d, size_t disc_bytes, void* ws_red, size_t red_bytes, float* sumsq,
+                    bool do_a, bool do_d, int part, hipStream_t st);
 
 }  // namespace samx

@@ -6,6 +6,7 @@
 #include "gemm.h"
 #include "nets.h"
 #include "fused_wide.h"
+#include "fused_small.h"
 #include "rng.h"
 #include "../../include/samx.h"
 #include <math.h>
@@ -1268,29 +1269,241 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
 }
 
 namespace {
-// gradient-penalty scalar k = 10 * 2 (N - 1) / N from the interpolate tiles' sums of squares
-// (discriminator.py:138-140,154); the interpolate rows' cotangents (DS, DZ2, DZ1 rows [2B, 3B)) were
-// written without it
-__global__ __launch_bounds__(256) void gp_finish_kernel(const double* __restrict__ gp_part, int tiles, int64_t B,
-                                                        int ob, int ac, float coeff, float* __restrict__ gp_out,
-                                                        float* __restrict__ DS, float* __restrict__ DZ2,
-                                                        float* __restrict__ DZ1, int h) {
-    __shared__ double sh[4];
-    double so = 0.0, sa = 0.0;
-    for (int i = threadIdx.x; i < tiles; i += 256) { so += gp_part[2 * i]; sa += gp_part[2 * i + 1]; }
-    so = block_sum_d(so, sh);
-    sa = block_sum_d(sa, sh);
-    const double N = sqrt(so / ((double)B * ob) + sa / ((double)B * ac));
-    const float k = (float)((double)coeff * 2.0 * (N - 1.0) / N);
-    if (blockIdx.x == 0 && threadIdx.x == 0) gp_out[0] = (float)((N - 1.0) * (N - 1.0));
-    const int64_t n = B * h;
-    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
-        DZ2[2 * n + t] *= k;
-        DZ1[2 * n + t] *= k;
-        if (t < B) DS[2 * B + t] = k;
+// ---- reduction that finishes the weight gradients of a 256x256 learner (after fused_wide.hip + the grouped
+// split products): every element of the three flat gradients = fixed-order sum of its partial sums
+// (split-GEMM partials [split][rows][cols], or per-tile head slots [tile][257]) [+ k * the interpolate rows'
+// partial sums, k = the gradient-penalty scalar 10 * 2 (N - 1) / N, discriminator.py:138-140,154]
+// [+ wd * W, network_util.py:43-56]; per-block sums of squares for the clip norm; the step counters tick.
+struct WPiece {
+    const float* p1; int n1; int64_t s1;                      // plain partial sums
+    const float* p2; int n2; int64_t s2; int64_t n2_valid;    // partial sums that take the scalar k
+    const float* wdW; float wd; int64_t wd_count;             // weight decay on the first wd_count elements
+    int64_t count;                                            // elements of this piece ([W; b] contiguous)
+};
+struct WFinishSeg {
+    WPiece pc[3];
+    int64_t n;
+    float* grad;
+    float* sumsq;
+    int nblocks;
+    int64_t* step_dev;
+};
+struct WLossArgs {
+    int64_t B;
+    const float* row_hub;             // critic (null = no agent roles)
+    const double* wd_part;
+    int wd_blocks;
+    float td_scale, wd_scale;
+    float* critic_losses;
+    const float* row_q;
+    float q_scale;
+    float* actor_losses;
+    const float *ce, *ent, *sg;       // discriminator (null ce = no discriminator role)
+    const double* gp_part;
+    int tiles, ob, ac;
+    float ent_scale, gp_coeff;
+    float* d_losses;
+};
+struct WFinishArgs {
+    WLossArgs loss;
+    int main_blocks;                  // the three workgroups behind them take the scalar losses
+    WFinishSeg seg[3];
+    int nseg, gp_seg;
+    const double* gp_part;
+    int gp_tiles, ob, ac;
+    int64_t B;
+    float gp_coeff;
+    // commit of the inline d.obs_rms.update (helpers/mpi_running_mean_std.py:31-45), or null
+    double* rms_sums;
+    const double* rms_addvec;
+    float *rms_mean, *rms_std;
+};
+// The scalar losses, by three extra workgroups of the reduction launch: the critic's (sam_agent.py:473-517,
+// weight decay network_util.py:43-56 from the role launch's partial sums), the actor's (sam_agent.py:412-430),
+// the discriminator's 8 (discriminator.py:145-158, gradient penalty from the interpolate tiles' sums).
+__device__ __forceinline__ double sum_f32_x4(const float* x, int64_t n, double* sh) {
+    double a = 0.0;
+    const int64_t nt = blockDim.x;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * nt < n; i += 4 * nt) {   // four loads in flight
+        const double v0 = x[i], v1 = x[i + nt], v2 = x[i + 2 * nt], v3 = x[i + 3 * nt];
+        a += v0 + v1 + v2 + v3;
+    }
+    for (; i < n; i += nt) a += (double)x[i];
+    return block_sum_d(a, sh);
+}
+__device__ void wide_losses(const WLossArgs& t, int which, double* sh) {
+    const int64_t B = t.B;
+    const int i = threadIdx.x;
+    if (which == 0) {
+        if (!t.row_hub) return;
+        const double l = sum_f32_x4(t.row_hub, B, sh) / (double)B * t.td_scale;
+        double wd = 0.0;
+        if (t.wd_scale > 0.f) wd = 0.5 * t.wd_scale * block_sum_d(i < t.wd_blocks ? t.wd_part[i] : 0.0, sh);
+        if (i == 0) {
+            t.critic_losses[0] = (float)l;
+            t.critic_losses[1] = (float)wd;
+            t.critic_losses[2] = (float)(l + wd);
+            t.critic_losses[3] = 0.f;
+        }
+    } else if (which == 1) {
+        if (!t.row_q) return;
+        const double q = -sum_f32_x4(t.row_q, B, sh) / (double)B * t.q_scale;
+        if (i == 0) {
+            t.actor_losses[0] = (float)q;
+            t.actor_losses[1] = 0.f;
+            t.actor_losses[2] = (float)q;
+        }
+    } else {
+        if (!t.ce) return;
+        const double pl = sum_f32_x4(t.ce, B, sh) / (double)B;
+        const double el = sum_f32_x4(t.ce + B, B, sh) / (double)B;
+        const double em = sum_f32_x4(t.ent, 2 * B, sh) / (double)(2 * B);
+        const double pa = sum_f32_x4(t.sg, B, sh) / (double)B;
+        const double ea = sum_f32_x4(t.sg + B, B, sh) / (double)B;
+        const double so = block_sum_d(i < t.tiles ? t.gp_part[2 * i] : 0.0, sh);
+        const double sa = block_sum_d(i < t.tiles ? t.gp_part[2 * i + 1] : 0.0, sh);
+        if (i == 0) {
+            const double N = sqrt(so / ((double)B * t.ob) + sa / ((double)B * t.ac));
+            const double gp = (N - 1.0) * (N - 1.0);
+            const double eloss = -(double)t.ent_scale * em;
+            float* losses = t.d_losses;
+            losses[0] = (float)pl; losses[1] = (float)el; losses[2] = (float)em; losses[3] = (float)eloss;
+            losses[4] = (float)pa; losses[5] = (float)ea; losses[6] = (float)gp;
+            losses[7] = (float)(pl + el + eloss + (double)t.gp_coeff * gp);
+        }
     }
 }
+
+__global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
+    __shared__ double shd[4];
+    const int tid = threadIdx.x;
+    int k = 0, b = blockIdx.x;
+    if (b >= f.main_blocks) { wide_losses(f.loss, b - f.main_blocks, shd); return; }
+    while (k < f.nseg - 1 && b >= f.seg[k].nblocks) { b -= f.seg[k].nblocks; ++k; }
+    const WFinishSeg& s = f.seg[k];
+    float kgp = 0.f;
+    if (k == f.gp_seg && f.gp_part) {   // every wave derives the scalar itself (same loads, same fixed tree)
+        double so = 0.0, sa = 0.0;
+        for (int i = tid & 63; i < f.gp_tiles; i += 64) { so += f.gp_part[2 * i]; sa += f.gp_part[2 * i + 1]; }
+        for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o, 64); sa += __shfl_xor(sa, o, 64); }
+        const double N = sqrt(so / ((double)f.B * f.ob) + sa / ((double)f.B * f.ac));
+        kgp = (float)((double)f.gp_coeff * 2.0 * (N - 1.0) / N);
+    }
+    if (b == 0 && tid == 0 && s.step_dev) s.step_dev[0] += 1;
+    if (k == f.gp_seg && b == 0 && f.rms_sums) {   // same arithmetic as the role kernel's loader
+        const int dim = f.ob;
+        const double cnt = f.rms_sums[2 * dim] + f.rms_addvec[2 * dim];   // every thread reads the old count first
+        __syncthreads();
+        for (int c = tid; c < dim; c += 256) {
+            const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
+                         s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
+            f.rms_sums[c] = s1;
+            f.rms_sums[dim + c] = s2;
+            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+            f.rms_mean[c] = mean;
+            f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+        }
+        if (tid == 0) f.rms_sums[2 * dim] = cnt;
+    }
+    double acc = 0.0;
+    const int64_t stride = (int64_t)s.nblocks * 256;
+    constexpr int E = 4;   // elements per thread and round: their partial-sum loads are in flight together
+    for (int64_t i0 = (int64_t)b * 256 + tid; i0 < s.n; i0 += E * stride) {
+        const float* p1[E]; const float* p2[E]; const float* pw[E];
+        int n1[E], n2[E];
+        int64_t s1[E], s2[E];
+        float wd[E], v[E], u[E];
+        int nmax1 = 0, nmax2 = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t i = i0 + e * stride;
+            p1[e] = p2[e] = pw[e] = nullptr; n1[e] = n2[e] = 0; s1[e] = s2[e] = 0; wd[e] = 0.f; v[e] = u[e] = 0.f;
+            if (i < s.n) {
+                int q = 0;
+                int64_t li = i;
+                while (q < 2 && li >= s.pc[q].count) { li -= s.pc[q].count; ++q; }
+                const WPiece& pc = s.pc[q];
+                p1[e] = pc.p1 + li; n1[e] = pc.n1; s1[e] = pc.s1;
+                if (pc.p2 && li < pc.n2_valid) { p2[e] = pc.p2 + li; n2[e] = pc.n2; s2[e] = pc.s2; }
+                if (pc.wdW && li < pc.wd_count) { pw[e] = pc.wdW + li; wd[e] = pc.wd; }
+                nmax1 = n1[e] > nmax1 ? n1[e] : nmax1;
+                nmax2 = n2[e] > nmax2 ? n2[e] : nmax2;
+            }
+        }
+        for (int z = 0; z < nmax1; z += 2) {   // splits in increasing order; 2 x E loads in flight
+            float t0[E], t1[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                t0[e] = z < n1[e] ? p1[e][z * s1[e]] : 0.f;
+                t1[e] = z + 1 < n1[e] ? p1[e][(z + 1) * s1[e]] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) { if (z < n1[e]) v[e] += t0[e]; if (z + 1 < n1[e]) v[e] += t1[e]; }
+        }
+        for (int z = 0; z < nmax2; z += 2) {
+            float t0[E], t1[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                t0[e] = z < n2[e] ? p2[e][z * s2[e]] : 0.f;
+                t1[e] = z + 1 < n2[e] ? p2[e][(z + 1) * s2[e]] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) { if (z < n2[e]) u[e] += t0[e]; if (z + 1 < n2[e]) u[e] += t1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t i = i0 + e * stride;
+            if (i < s.n) {
+                float g = v[e];
+                if (p2[e]) g += kgp * u[e];
+                if (pw[e]) g += wd[e] * pw[e][0];
+                s.grad[i] = g;
+                acc += (double)g * (double)g;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
+}
+
+int wide_nsplit(int64_t R) {   // reduction chunks of 512 rows: 16 stages per workgroup
+    int64_t n = (R + 511) / 512;
+    return (int)(n < 2 ? 2 : n);
+}
+// float layout of the reduction workspace: head slots (critic, D), then one partials buffer per product
+struct WideRed {
+    float *w3c, *w3d, *w3_sum, *P[9], *w3a_tmp;   // w3_sum: [3][257] critic, D policy+expert, D interpolates
+    int ns[9];
+    int64_t cnt[9];
+};
+WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B) {
+    WideRed w;
+    const int64_t tiles = B / wide::kRows, in = ob + ac, H = wide::kH;
+    w.w3c = ar.take<float>(tiles * (H + 1));
+    w.w3d = ar.take<float>(3 * tiles * (H + 1));
+    w.w3_sum = ar.take<float>(3 * (H + 1));
+    const int nsA = wide_nsplit(B), nsD1 = wide_nsplit(2 * B), nsD2 = nsA;
+    const int ns[9] = {nsA, nsA, nsA, nsA, nsA, nsD1, nsD2, nsD1, nsD2};
+    const int64_t cnt[9] = {(H + 1) * H, (in + 1) * H, (H + 1) * ac, (H + 1) * H, (ob + 1) * H,
+                            (H + 1) * H, H * H, (in + 1) * H, in * H};
+    for (int p = 0; p < 9; ++p) {
+        w.ns[p] = ns[p];
+        w.cnt[p] = cnt[p];
+        w.P[p] = ar.take<float>((size_t)ns[p] * cnt[p]);
+    }
+    w.w3a_tmp = ar.take<float>((H + 1) * ac);
+    return w;
+}
 }  // namespace
+
+size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B) {
+    Arena ar(nullptr, 0);
+    carve_wide_red(ar, L->ob_dim, L->ac_dim, B);
+    return align_up(ar.off, 256) + 256;
+}
 
 bool wide_step_supported(const samx_learner* L, int64_t B) {
     return wide::supported(&L->actor, &L->critic, &L->reward, L->ob_dim, L->ac_dim, B) && !L->ret_mean &&
@@ -1298,20 +1511,67 @@ bool wide_step_supported(const samx_learner* L, int64_t B) {
 }
 
 int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
-                    size_t nets_bytes, void* ws_d, size_t disc_bytes, bool do_a, bool do_d, hipStream_t st_agent,
-                    hipStream_t st_disc) {
+                    size_t nets_bytes, void* ws_d, size_t disc_bytes, void* ws_red, size_t red_bytes, float* sumsq,
+                    bool do_a, bool do_d, int part, hipStream_t st) {
+    const bool run = (part & 1) != 0;
+    static_assert(kWdBlocks <= 256 && kGpBlocks <= 256, "one 256-thread workgroup adds the partial sums");
     const int64_t B = b->B;
     const samx_mlp *da = &L->actor, *dc = &L->critic, *dd = &L->reward;
-    const int64_t Pa = samx_mlp_param_count(da), Pc = samx_mlp_param_count(dc);
-    const int ob = L->ob_dim, ac = L->ac_dim;
+    const int64_t Pa = samx_mlp_param_count(da), Pc = samx_mlp_param_count(dc), Pd = samx_mlp_param_count(dd);
+    const int ob = L->ob_dim, ac = L->ac_dim, in = ob + ac, H = wide::kH;
+    const int tiles = (int)(B / wide::kRows);
+    const float gp_coeff = 10.f;  // discriminator.py:154
     auto net = [](const Net& n) { return wide::Net{n.W1, n.b1, n.W2, n.b2, n.W3, n.b3, n.in, n.out}; };
+    Arena ared(ws_red, red_bytes);
+    WideRed wr = carve_wide_red(ared, ob, ac, B);
+    if (!ared.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: reduction workspace too small");
+    GemmArgs gl[9];
+    int ng = 0;
+    auto prob = [&](int p, const float* A, int64_t lda, int M, const float* Bm, int64_t ldb, int N, int64_t R,
+                    int64_t ones) {
+        GemmArgs g;
+        g.A = A; g.a_si = 1; g.a_sr = lda;
+        g.B = Bm; g.b_sr = ldb; g.b_sj = 1;
+        g.C = wr.P[p]; g.ldc = N;   // unused: only partials are written
+        g.M = M; g.N = N; g.R = (int)R;
+        g.a_ones_rows = (int)ones;
+        g.nsplit = wr.ns[p];
+        g.partials = wr.P[p];
+        g.overread_ok = true;
+        gl[ng++] = g;
+    };
+    WFinishArgs f;
+    f.nseg = 0; f.gp_seg = -1; f.gp_part = nullptr; f.gp_tiles = tiles; f.ob = ob; f.ac = ac; f.B = B;
+    f.gp_coeff = gp_coeff;
+    f.rms_sums = nullptr; f.rms_addvec = nullptr; f.rms_mean = f.rms_std = nullptr;
+    wide::AgentArgs a;
+    a.wd_part = nullptr; a.wd_blocks = 0;
+    wide::DiscArgs d;
+    AgentWs w1{}, w2{};
+    DiscWs wdsc{};
+    Net nc;
+    const bool w3a_group = ac >= 4;
+    auto piece = [](const float* p1, int n1, int64_t s1, int64_t count) {
+        WPiece pc;
+        pc.p1 = p1; pc.n1 = n1; pc.s1 = s1; pc.p2 = nullptr; pc.n2 = 0; pc.s2 = 0; pc.n2_valid = 0;
+        pc.wdW = nullptr; pc.wd = 0.f; pc.wd_count = 0; pc.count = count;
+        return pc;
+    };
+    auto seg = [&](int k, int64_t n, float* grad) -> WFinishSeg& {
+        WFinishSeg& s = f.seg[f.nseg++];
+        s.n = n; s.grad = grad; s.nblocks = fused::seg_blocks(n);
+        s.sumsq = sumsq + k * fused::kMaxSegBlocks;
+        s.step_dev = L->steps + k;
+        return s;
+    };
     if (do_a) {
         Arena a1(ws_tc, nets_bytes), a2(ws_a, nets_bytes);
-        AgentWs w1 = carve_agent(a1, da, dc, nullptr, B), w2 = carve_agent(a2, da, dc, nullptr, B);
+        w1 = carve_agent(a1, da, dc, nullptr, B);
+        w2 = carve_agent(a2, da, dc, nullptr, B);
         if (!a1.ok() || !a2.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: agent workspace too small");
-        Net na = split(da, L->params), nc = split(dc, L->params + Pa);
+        Net na = split(da, L->params);
+        nc = split(dc, L->params + Pa);
         Net ta = split(da, L->targets), tc = split(dc, L->targets + Pa);
-        wide::AgentArgs a;
         a.obs0 = b->obs0; a.acs = b->acs; a.rews = b->rews; a.dones1 = b->dones1; a.obs1 = b->obs1;
         a.iws = b->iws; a.td_len = b->td_len; a.mean = L->mu_mean; a.stdv = L->mu_std;
         a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
@@ -1320,67 +1580,90 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
         a.targ_q = o->targ_q; a.td_out = o->td;
         a.Xc = w1.XC; a.A1c = w1.hc.A1; a.A2c = w1.hc.A2; a.DZ1c = w1.kc.DZ1; a.DZ2c = w1.kc.DZ2;
-        a.row_hub = w1.row0; a.row_dq = w1.row1;
+        a.row_hub = w1.row0; a.row_dq = w1.row1; a.w3c_part = wr.w3c;
         a.Xa = w2.XC; a.A1a = w2.ha.A1; a.A2a = w2.ha.A2; a.DZ1a = w2.ka.DZ1; a.DZ2a = w2.ka.DZ2;
         a.dPre = w2.dPre; a.row_q = w2.row0;
-        TRY(wide::launch_roles(&a, nullptr, 3, st_agent));
-        hipStream_t st = st_agent;
-        // critic: weight gradients (+ weight decay) and losses   (sam_agent.py:457-520)
-        float* gc = L->grads + Pa;
-        TRY(wgrad(w1.hc.A2, nc.h2, nc.h2, w1.row1, 1, 1, B, B, gc + nc.oW3, 0.f, nullptr, w1.partials,
-                  w1.partial_floats, st));
-        TRY(wgrad(w1.hc.A1, nc.h1, nc.h1, w1.kc.DZ2, nc.h2, nc.h2, B, B, gc + nc.oW2, L->wd_scale, nc.W2,
-                  w1.partials, w1.partial_floats, st));
-        TRY(wgrad(w1.XC, nc.in, nc.in, w1.kc.DZ1, nc.h1, nc.h1, B, B, gc + nc.oW1, L->wd_scale, nc.W1, w1.partials,
-                  w1.partial_floats, st));
-        if (L->wd_scale > 0.f) {
-            wd_sumsq_kernel<<<kWdBlocks, 256, 0, st>>>(nc.W1, (int64_t)nc.in * nc.h1, nc.W2, (int64_t)nc.h1 * nc.h2,
-                                                       w1.wd_part);
-            SAMX_LAUNCH_CHECK();
-        }
-        critic_losses_kernel<<<1, 1024, 0, st>>>(w1.row0, B, L->td_loss_scale, L->wd_scale, w1.wd_part, kWdBlocks,
-                                                 o->critic_losses, nullptr, 0.f);
-        SAMX_LAUNCH_CHECK();
-        // actor   (sam_agent.py:406-433)
-        float* ga = L->grads;
-        TRY(wgrad(w2.ha.A2, na.h2, na.h2, w2.dPre, ac, ac, B, B, ga + na.oW3, 0.f, nullptr, w2.partials,
-                  w2.partial_floats, st));
-        TRY(wgrad(w2.ha.A1, na.h1, na.h1, w2.ka.DZ2, na.h2, na.h2, B, B, ga + na.oW2, 0.f, nullptr, w2.partials,
-                  w2.partial_floats, st));
-        TRY(wgrad(w2.XC, ob + ac, ob, w2.ka.DZ1, na.h1, na.h1, B, B, ga + na.oW1, 0.f, nullptr, w2.partials,
-                  w2.partial_floats, st));
-        actor_losses_kernel<<<1, 1024, 0, st>>>(w2.row0, nullptr, B, L->q_actor_loss_scale, 0.f, o->actor_losses);
-        SAMX_LAUNCH_CHECK();
+        // weight-gradient products: critic W2, W1 ; actor W3, W2, W1
+        prob(0, w1.hc.A1, H, H, w1.kc.DZ2, H, H, B, B);
+        prob(1, w1.XC, in, in, w1.kc.DZ1, H, H, B, B);
+        if (w3a_group) prob(2, w2.ha.A2, H, H, w2.dPre, ac, ac, B, B);
+        prob(3, w2.ha.A1, H, H, w2.ka.DZ2, H, H, B, B);
+        prob(4, w2.XC, in, ob, w2.ka.DZ1, H, H, B, B);
+        WFinishSeg& sa = seg(0, Pa, L->grads);
+        sa.pc[0] = piece(wr.P[4], wr.ns[4], wr.cnt[4], wr.cnt[4]);
+        sa.pc[1] = piece(wr.P[3], wr.ns[3], wr.cnt[3], wr.cnt[3]);
+        sa.pc[2] = w3a_group ? piece(wr.P[2], wr.ns[2], wr.cnt[2], wr.cnt[2])
+                             : piece(wr.w3a_tmp, 1, wr.cnt[2], wr.cnt[2]);
+        WFinishSeg& sc = seg(1, Pc, L->grads + Pa);
+        sc.pc[0] = piece(wr.P[1], wr.ns[1], wr.cnt[1], wr.cnt[1]);
+        sc.pc[0].wdW = nc.W1; sc.pc[0].wd = L->wd_scale; sc.pc[0].wd_count = (int64_t)in * H;
+        sc.pc[1] = piece(wr.P[0], wr.ns[0], wr.cnt[0], wr.cnt[0]);
+        sc.pc[1].wdW = nc.W2; sc.pc[1].wd = L->wd_scale; sc.pc[1].wd_count = (int64_t)H * H;
+        sc.pc[2] = piece(wr.w3_sum, 1, H + 1, H + 1);
+        if (L->wd_scale <= 0.f) { sc.pc[0].wdW = nullptr; sc.pc[1].wdW = nullptr; }
     }
     if (do_d) {
-        hipStream_t st = st_disc;
         Arena ar(ws_d, disc_bytes);
-        DiscWs w = carve_disc(ar, dd, B);
+        wdsc = carve_disc(ar, dd, B);
+        DiscWs& w = wdsc;
         if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: discriminator workspace too small");
         Net nd = split(dd, L->params + Pa + Pc);
-        wide::DiscArgs d;
         d.p_obs = b->p_obs; d.p_acs = b->p_acs; d.e_obs = b->e_obs; d.e_acs = b->e_acs;
         d.eps_ob = b->eps_ob; d.eps_ac = b->eps_ac; d.real = b->real_labels; d.fake = b->fake_labels;
         d.mean = L->d_mean; d.stdv = L->d_std;
+        d.rms_sums = b->d_rms_sums; d.rms_addvec = b->d_rms_addvec;
+        f.rms_sums = b->d_rms_sums; f.rms_addvec = b->d_rms_addvec;
+        f.rms_mean = const_cast<float*>(L->d_mean); f.rms_std = const_cast<float*>(L->d_std);
         d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
         d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
         d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
         d.X = w.X; d.A1 = w.h.A1; d.A2 = w.h.A2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
-        d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part;
-        TRY(wide::launch_roles(nullptr, &d, 4, st));
-        const float gp_coeff = 10.f;  // discriminator.py:154
-        gp_finish_kernel<<<256, 256, 0, st>>>(w.gp_part, (int)(B / wide::kRows), B, ob, ac, gp_coeff, w.gp, w.DS,
-                                              w.k.DZ2, w.k.DZ1, nd.h1);
-        SAMX_LAUNCH_CHECK();
-        float* gd = L->grads + Pa + Pc;
-        const int64_t M = 3 * B;
-        TRY(wgrad(w.h.A2, nd.h2, nd.h2, w.DS, 1, 1, M, 2 * B, gd + nd.oW3, 0.f, nullptr, w.partials,
-                  w.partial_floats, st));
-        TRY(wgrad(w.h.A1, nd.h1, nd.h1, w.k.DZ2, nd.h2, nd.h2, M, 2 * B, gd + nd.oW2, 0.f, nullptr, w.partials,
-                  w.partial_floats, st));
-        TRY(wgrad(w.X, nd.in, nd.in, w.k.DZ1, nd.h1, nd.h1, M, 2 * B, gd + nd.oW1, 0.f, nullptr, w.partials,
-                  w.partial_floats, st));
-        disc_losses_kernel<<<1, 1024, 0, st>>>(w.ce, w.ent, w.sg, w.gp, B, L->ent_reg_scale, gp_coeff, o->d_losses);
+        d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part; d.w3_part = wr.w3d;
+        // D W2 / W1: policy + expert rows (with the bias row), then the interpolate rows (take the scalar k)
+        prob(5, w.h.A1, H, H, w.k.DZ2, H, H, 2 * B, 2 * B);
+        prob(6, w.h.A1 + 2 * B * H, H, H, w.k.DZ2 + 2 * B * H, H, H, B, -1);
+        prob(7, w.X, in, in, w.k.DZ1, H, H, 2 * B, 2 * B);
+        prob(8, w.X + 2 * B * in, in, in, w.k.DZ1 + 2 * B * H, H, H, B, -1);
+        WFinishSeg& sd = seg(2, Pd, L->grads + Pa + Pc);
+        sd.pc[0] = piece(wr.P[7], wr.ns[7], wr.cnt[7], wr.cnt[7]);
+        sd.pc[0].p2 = wr.P[8]; sd.pc[0].n2 = wr.ns[8]; sd.pc[0].s2 = wr.cnt[8]; sd.pc[0].n2_valid = wr.cnt[8];
+        sd.pc[1] = piece(wr.P[5], wr.ns[5], wr.cnt[5], wr.cnt[5]);
+        sd.pc[1].p2 = wr.P[6]; sd.pc[1].n2 = wr.ns[6]; sd.pc[1].s2 = wr.cnt[6]; sd.pc[1].n2_valid = wr.cnt[6];
+        sd.pc[2] = piece(wr.w3_sum + (H + 1), 1, H + 1, H + 1);
+        sd.pc[2].p2 = wr.w3_sum + 2 * (H + 1); sd.pc[2].n2 = 1; sd.pc[2].s2 = H + 1; sd.pc[2].n2_valid = H;
+        f.gp_seg = f.nseg - 1; f.gp_part = w.gp_part;
+    }
+    if (run) {
+        // every role in ONE launch (the decayed kernels' sums of squares ride along), then ONE for all
+        // weight-gradient products and the head-gradient slot sums
+        if (do_a && L->wd_scale > 0.f) { a.wd_part = w1.wd_part; a.wd_blocks = kWdBlocks; }
+        TRY(wide::launch_roles(do_a ? &a : nullptr, do_d ? &d : nullptr, (do_a ? 3 : 0) | (do_d ? 4 : 0), st));
+        if (do_a && !w3a_group)   // an action head narrower than 16 bytes: the plain split product
+            TRY(wgrad(w2.ha.A2, H, H, w2.dPre, ac, ac, B, B, wr.w3a_tmp, 0.f, nullptr, w2.partials,
+                      w2.partial_floats, st));
+        SlotSum sl[3];
+        int nsl = 0;
+        if (do_a) sl[nsl++] = SlotSum{wr.w3c, tiles, H + 1, wr.w3_sum};
+        if (do_d) {
+            sl[nsl++] = SlotSum{wr.w3d + (int64_t)tiles * (H + 1), 2 * tiles, H + 1, wr.w3_sum + (H + 1)};
+            sl[nsl++] = SlotSum{wr.w3d, tiles, H + 1, wr.w3_sum + 2 * (H + 1)};
+        }
+        TRY(gemm_group_partials(gl, ng, st, sl, nsl));
+    }
+    if (part & 2) {   // the reduction, the statistics commit, the counters, the scalar losses
+        WLossArgs& t = f.loss;
+        t.B = B;
+        t.row_hub = do_a ? w1.row0 : nullptr;
+        t.wd_part = w1.wd_part; t.wd_blocks = kWdBlocks;
+        t.td_scale = L->td_loss_scale; t.wd_scale = L->wd_scale; t.critic_losses = o->critic_losses;
+        t.row_q = do_a ? w2.row0 : nullptr; t.q_scale = L->q_actor_loss_scale; t.actor_losses = o->actor_losses;
+        t.ce = do_d ? wdsc.ce : nullptr; t.ent = wdsc.ent; t.sg = wdsc.sg; t.gp_part = wdsc.gp_part;
+        t.tiles = tiles; t.ob = ob; t.ac = ac; t.ent_scale = L->ent_reg_scale; t.gp_coeff = gp_coeff;
+        t.d_losses = o->d_losses;
+        int blocks = 0;
+        for (int k = 0; k < f.nseg; ++k) blocks += f.seg[k].nblocks;
+        f.main_blocks = blocks;
+        wide_finish_kernel<<<blocks + 3, 256, 0, st>>>(f);
         SAMX_LAUNCH_CHECK();
     }
     return SAMX_OK;

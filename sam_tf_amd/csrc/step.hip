@@ -31,6 +31,8 @@ struct StepWs {
     double *ret_add1, *ret_add2;
     void* stats_ws;  // layer-wise path: samx_d_input_stats scratch (inline d.obs_rms update)
     size_t stats_bytes;
+    void* wide_red;  // 256x256 path: head slots + split partials of the grouped weight-gradient launch
+    size_t wide_red_bytes;
 };
 
 // Two side streams per device for the layer-wise path: the discriminator, target+critic and actor
@@ -61,6 +63,12 @@ int side_streams(SideStreams** out) {
     return SAMX_OK;
 }
 
+bool use_fused(const samx_learner* L, int64_t B);
+bool use_wide(const samx_learner* L, int64_t B) {
+    static int no_wide = -1;   // SAMX_NO_WIDE=1: 256x256 learners take the layer-wise path too (A/B comparisons)
+    if (no_wide < 0) { const char* e = getenv("SAMX_NO_WIDE"); no_wide = e ? atoi(e) : 0; }
+    return !no_wide && !use_fused(L, B) && samx::wide_step_supported(L, B);
+}
 bool use_fused(const samx_learner* L, int64_t B) {
     const bool ln = L->actor.layernorm != 0;
     return fused::supported(&L->actor, B) && fused::supported(&L->critic, B) &&
@@ -101,6 +109,8 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.ret_add1 = ar.take<double>(4); w.ret_add2 = ar.take<double>(4);
     w.stats_bytes = f ? 0 : samx_d_input_stats_ws_bytes(B, L->ob_dim);
     w.stats_ws = ar.take<char>(w.stats_bytes);
+    w.wide_red_bytes = (!f && samx::wide_step_supported(L, B)) ? samx::wide_reduce_ws_bytes(L, B) : 0;
+    w.wide_red = ar.take<char>(w.wide_red_bytes);
     return w;
 }
 
@@ -310,8 +320,12 @@ __global__ __launch_bounds__(256) void d_input_partials_kernel(
     const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
     const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0,
     const int64_t* __restrict__ e_start, int64_t B, int dim, double* __restrict__ part,
-    const double* __restrict__ sums) {
+    const double* __restrict__ sums, int64_t idx_stride, int64_t part_stride) {
     const int G = gridDim.x, g = blockIdx.x;
+    // blockIdx.z: the step of a multi-step launch (a single step has strides 0)
+    if (p_idx) p_idx += blockIdx.z * idx_stride;
+    if (e_start) e_start += blockIdx.z * idx_stride;
+    part += blockIdx.z * part_stride;
     const int64_t e0 = e_start ? e_start[0] : 0;
     // snapshot of the running count for the commit kernel (slot behind the partials)
     if (sums && g == 0 && blockIdx.y == 0 && threadIdx.x == 0) part[(int64_t)G * 2 * dim] = sums[2 * dim];
@@ -357,8 +371,11 @@ __global__ __launch_bounds__(64) void d_input_commit_kernel(const double* __rest
                                                             int dim, double* __restrict__ addvec, int commit,
                                                             double* __restrict__ sums,
                                                             float* __restrict__ mean_out,
-                                                            float* __restrict__ std_out) {
+                                                            float* __restrict__ std_out, int64_t part_stride,
+                                                            int64_t addvec_stride) {
     const int col = blockIdx.x, lane = threadIdx.x;
+    part += blockIdx.y * part_stride;       // blockIdx.y: the step of a multi-step launch
+    addvec += blockIdx.y * addvec_stride;
     double a = 0.0, q = 0.0;
     for (int g = lane; g < G; g += 64) {
         a = __dadd_rn(a, part[((int64_t)g * 2) * dim + col]);
@@ -432,9 +449,11 @@ int d_input_stats_impl(const char* who, const float* replay_obs0, int64_t ring_s
                         samx_d_input_stats_ws_bytes(B, ob_dim));
         double* part = (double*)ws;
         d_input_partials_kernel<<<dim3(G, (ob_dim + 255) / 256), 256, 0, st>>>(
-            replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, part, commit ? sums : nullptr);
+            replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, part, commit ? sums : nullptr,
+            0, 0);
         SAMX_LAUNCH_CHECK();
-        d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out);
+        d_input_commit_kernel<<<ob_dim, 64, 0, st>>>(part, G, B, ob_dim, addvec, commit, sums, mean_out, std_out,
+                                                     0, 0);
         SAMX_LAUNCH_CHECK();
         return SAMX_OK;
     }
@@ -563,6 +582,36 @@ int samx_d_input_sums_many(const float* replay_obs0, int64_t ring_start, int64_t
     return SAMX_OK;
 }
 
+int samx_d_input_sums_many_ws(const float* replay_obs0, int64_t ring_start, int64_t ring_len,
+                              const int64_t* p_idx, const float* pool_obs0, const int64_t* e_start,
+                              int64_t idx_stride, int64_t B, int ob_dim, double* addvec, int64_t addvec_stride,
+                              int64_t K, void* ws, size_t ws_bytes, void* stream) {
+    if (2 * B * (int64_t)ob_dim <= 16384)
+        return samx_d_input_sums_many(replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, idx_stride, B,
+                                      ob_dim, addvec, addvec_stride, K, stream);
+    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0 && ob_dim <= 1024 && K > 0 && K <= 65535,
+                 "samx_d_input_sums_many_ws: bad arguments");
+    SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
+                 "samx_d_input_sums_many_ws: bad ring geometry");
+    SAMX_REQUIRE(idx_stride >= 0 && addvec_stride >= 2 * ob_dim + 1, "samx_d_input_sums_many_ws: bad strides");
+    const size_t per = samx_d_input_stats_ws_bytes(B, ob_dim);
+    SAMX_REQUIRE(ws, "samx_d_input_sums_many_ws: this size needs a workspace (K * samx_d_input_stats_ws_bytes)");
+    if (ws_bytes < per * (size_t)K)
+        return fail(SAMX_ERR_WORKSPACE, "samx_d_input_sums_many_ws: workspace %zu < %zu", ws_bytes, per * (size_t)K);
+    const int G = stat_groups(B);
+    const int64_t pstride = (int64_t)(per / sizeof(double));
+    hipStream_t st = (hipStream_t)stream;
+    d_input_partials_kernel<<<dim3(G, (ob_dim + 255) / 256, (unsigned)K), 256, 0, st>>>(
+        replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, ob_dim, (double*)ws, nullptr, idx_stride,
+        pstride);
+    SAMX_LAUNCH_CHECK();
+    d_input_commit_kernel<<<dim3(ob_dim, (unsigned)K), 64, 0, st>>>((const double*)ws, G, B, ob_dim, addvec, 0,
+                                                                   nullptr, nullptr, nullptr, pstride,
+                                                                   addvec_stride);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
 int samx_td_errors_rows(const samx_mlp* dc, const float* pc, const float* obs0, const float* acs,
                         const int64_t* idx, int64_t ring_start, int64_t ring_len, const float* tc1s,
                         const float* mean, const float* stdv, int64_t B, int ob_dim, float* td_out,
@@ -607,6 +656,12 @@ size_t samx_td_errors_rows_ws_bytes(const samx_mlp* dc, int64_t B) {
 }
 
 int samx_fused_supported(const samx_learner* L, int64_t B) { return L && use_fused(L, B) ? 1 : 0; }
+
+int samx_step_path(const samx_learner* L, int64_t B) {
+    if (!L || B <= 0) return 0;
+    if (use_fused(L, B)) return 1;
+    return use_wide(L, B) ? 2 : 0;
+}
 
 size_t samx_step_ws_bytes(const samx_learner* L, int64_t B) {
     if (!L || B <= 0) return 0;
@@ -665,54 +720,25 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
 
     SAMX_REQUIRE((b->d_rms_sums == nullptr) == (b->d_rms_addvec == nullptr),
                  "samx_step_grads: d_rms_sums/d_rms_addvec go together");
+    const bool wide = use_wide(L, B);   // 256x256 learners (fused_wide.hip); statistics as on the fused path
     if (b->d_rms_sums) {
         SAMX_REQUIRE(L->d_mean && L->d_std, "samx_step_grads: inline statistics need learner.d_mean/d_std");
-        // fused path: d_rms_addvec holds the row's sums (computed ahead).  Layer-wise path: the sums are
+        // fused and 256x256 paths: d_rms_addvec holds the row's sums (computed ahead).  Layer-wise path: the sums are
         // computed HERE, on the discriminator's stream, and d_rms_addvec receives them.
-        SAMX_REQUIRE(use_fused(L, B) || (b->p_idx && b->e_start),
+        SAMX_REQUIRE(use_fused(L, B) || wide || (b->p_idx && b->e_start),
                      "samx_step_grads: inline statistics on the layer-wise path need p_idx and e_start");
     }
-    if (!use_fused(L, B) && !(part & 1)) {  // reduction part only
+    if (!use_fused(L, B) && !wide && !(part & 1)) {  // reduction part only
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;
         return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
                                   do_d ? L->steps + 2 : nullptr, st);
     }
-    static int no_wide = -1;   // SAMX_NO_WIDE=1: 256x256 learners take the layer-wise path too (A/B comparisons)
-    if (no_wide < 0) { const char* e = getenv("SAMX_NO_WIDE"); no_wide = e ? atoi(e) : 0; }
-    if (!use_fused(L, B) && !no_wide && !t_only && !t_done && samx::wide_step_supported(L, B)) {
-        // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions; the agent roles on a side
-        // stream, the discriminator (behind its running-statistics update) on the caller's
-        hipStream_t s_agent = st;
-        SideStreams* ss = nullptr;
-        if (do_a && do_d) {
-            rc = side_streams(&ss);
-            if (rc != SAMX_OK) return rc;
-            SAMX_CHECK_HIP(hipEventRecord(ss->fork, st));
-            SAMX_CHECK_HIP(hipStreamWaitEvent(ss->s[0], ss->fork, 0));
-            s_agent = ss->s[0];
-        }
-        if (b->d_rms_sums && do_d) {  // d.obs_rms.update on this row's D batch (sam.py:389-390), committed
-            rc = samx_d_input_stats(b->p_obs, b->ring_start, b->ring_len, b->p_idx, b->e_obs, b->e_start, B,
-                                    L->ob_dim, const_cast<double*>(b->d_rms_addvec), 1, b->d_rms_sums,
-                                    const_cast<float*>(L->d_mean), const_cast<float*>(L->d_std), w.stats_ws,
-                                    w.stats_bytes, stream);
-            if (rc != SAMX_OK) return rc;
-        }
-        rc = samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes, do_a,
-                                   do_d, s_agent, st);
-        if (rc != SAMX_OK) return rc;
-        if (ss) {
-            SAMX_CHECK_HIP(hipEventRecord(ss->join[0], ss->s[0]));
-            SAMX_CHECK_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
-        }
-        if (!(part & 2)) return SAMX_OK;
-        fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
-        rc = fused::launch_seg_sumsq(f, st);
-        if (rc != SAMX_OK) return rc;
-        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
-                                  do_d ? L->steps + 2 : nullptr, st);
+    if (wide && !t_only && !t_done) {
+        // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions, all on the caller's stream
+        return samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes,
+                                     w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, part & 3, st);
     }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense

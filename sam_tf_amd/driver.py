@@ -88,6 +88,9 @@ class UpdateStepDriver(object):
         # N > 1 also packs K steps per host iteration: the D-input sums of all K steps are computed and
         # all-reduced ONCE (they do not depend on the learner), which leaves one collective per step.
         self.fused = self.L.fused(B)
+        # 256x256 learners (samx_step_path 2): layer-wise in how the driver plans launches and collectives,
+        # fused in how the D-input statistics ride inside the step (one process)
+        self.wide = self.L.path(B) == 2
         m = 1
         while 2 * m * self.S <= int(steps_per_launch):
             m *= 2
@@ -163,11 +166,12 @@ class UpdateStepDriver(object):
         self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
-        self.inline_stats = bool(self.fused and self.d.hps.rmsify_obs)
+        self.inline_stats = bool((self.fused or (self.wide and self.world == 1)) and self.d.hps.rmsify_obs)
         self.sums_small = 2 * B * self.mu.ob_dim <= 16384   # what the one-workgroup sums kernels hold (samx.h)
         # layer-wise path, one process: samx_step_grads computes and commits the row's D statistics itself,
         # on the discriminator's stream, while the agent roles already run (no separate stats segment)
-        self.inline_stats_lw = bool(not self.fused and self.world == 1 and self.d.hps.rmsify_obs)
+        self.inline_stats_lw = bool(not self.fused and not self.wide and self.world == 1 and
+                                    self.d.hps.rmsify_obs)
         r = self.d.obs_rms if (self.inline_stats or self.inline_stats_lw) else None
         if r is not None:  # the K batches' [sum, sumsq, count], filled by ONE kernel at the head of a launch
             self.addvecs = torch.zeros(self.K, 2 * self.mu.ob_dim + 1, dtype=torch.float64, device=self.dev)
@@ -211,14 +215,9 @@ class UpdateStepDriver(object):
         without a D update carry index words 0 and their sums are not used)."""
         if self.inline_stats:
             rb, B = self.mu.replay_buffer, self.B
-            if self.sums_small:
-                ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], B,
-                                      self.pool.obs0, self.addvecs[:K])
-            else:   # large batches of wide observations: the two-stage sums, row by row (no commit)
-                for k in range(K):
-                    w = self.words[k]
-                    ops.d_input_stats(rb.store['obs0'], self._batch_start, w[:B], self.pool.obs0,
-                                      w[2 * B:2 * B + 1], B, self.addvecs[k], commit=False)
+            # (large batches of wide observations: the two-stage sums of the K rows in two launches)
+            ops.d_input_sums_many(rb.store['obs0'], self._batch_start, self.words[:K], B,
+                                  self.pool.obs0, self.addvecs[:K])
 
     def _seg_lookahead(self, K):
         """The n-step lookahead of all K rows of the launch (rows without an agent update carry index

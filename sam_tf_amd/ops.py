@@ -491,6 +491,10 @@ class LearnerState(object):
     def fused(self, B):
         return bool(_L().samx_fused_supported(C.byref(self.c), int(B)))
 
+    def path(self, B):
+        """0 layer-wise, 1 whole-network fused (64x64), 2 role-fused 256x256 (samx_step_path)."""
+        return int(_L().samx_step_path(C.byref(self.c), int(B)))
+
     def ws(self, B):
         if B not in self._ws:
             n = _L().samx_step_ws_bytes(C.byref(self.c), int(B))
@@ -591,10 +595,18 @@ def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
     _chk(replay_obs0, F32, (ring_len, ob), 'replay_obs0'); _chk(pool_obs0, F32, (pool_obs0.shape[0], ob), 'pool')
     _chk(words, I64, (K, W), 'words'); _chk(addvecs, F64, (K, 2 * ob + 1), 'addvecs')
     assert W >= 2 * B + 1
-    check(_L().samx_d_input_sums_many(ptr(replay_obs0), int(ring_start), int(ring_len),
-                                      C.c_void_p(words.data_ptr()), ptr(pool_obs0),
-                                      C.c_void_p(words.data_ptr() + 8 * 2 * B), W, int(B), int(ob),
-                                      ptr(addvecs), 2 * ob + 1, K, stream_ptr()))
+    ws = None
+    if 2 * B * ob > 16384:   # two-stage sums: per-step partials
+        key = (int(B), int(ob), int(K), str(replay_obs0.device))
+        if key not in _STATS_WS:
+            n = int(_L().samx_d_input_stats_ws_bytes(int(B), int(ob))) * int(K)
+            _STATS_WS[key] = torch.empty(n, dtype=torch.uint8, device=replay_obs0.device)
+        ws = _STATS_WS[key]
+    check(_L().samx_d_input_sums_many_ws(ptr(replay_obs0), int(ring_start), int(ring_len),
+                                         C.c_void_p(words.data_ptr()), ptr(pool_obs0),
+                                         C.c_void_p(words.data_ptr() + 8 * 2 * B), W, int(B), int(ob),
+                                         ptr(addvecs), 2 * ob + 1, K, ptr(ws), ws.numel() if ws is not None else 0,
+                                         stream_ptr()))
 
 
 def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec,
