@@ -1,6 +1,11 @@
 // Role-fused kernel for 256x256 leaky-ReLU networks (Humanoid-shaped configuration: ob 376, ac 17,
-// batch 1024).  One workgroup (4 waves) owns 16 batch rows and runs the ENTIRE chain of layer products of
-// its role for them:
+// batch 1024).  One workgroup owns 16 batch rows and runs the ENTIRE chain of layer products of its role
+// for them.  It has 8 waves, two per SIMD: waves 0-3 COMPUTE (fragment reads, MFMAs, epilogues), waves 4-7
+// LOAD (they stream the weights global -> registers -> LDS ring and do nothing else), so a SIMD always has
+// a wave that can issue while the other waits for memory.  Both halves are instantiated from the SAME role
+// source (template parameter CW) and therefore meet at the same barriers; everything that is not the weight
+// stream is compiled only into the compute half (`if (cw)`), which also keeps the two halves' registers apart.
+// Roles:
 //   TC  target actor + target critic on obs1 -> TD target, then the online critic on (obs0, acs): forward,
 //       huber loss, backward to the first pre-activation            (sam_agent.py:196-205,457-520)
 //   A   actor forward, critic forward on [obz0 | mu(obz0)], backward through the critic to the action,
@@ -24,13 +29,15 @@
 #include "fused_wide.h"
 #include "rng.h"
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace samx {
 namespace wide {
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;                // threads per workgroup
+constexpr int NC = 256;                // compute threads (waves 0-3); threads NC .. NT-1 are the loader waves
 constexpr int R = kRows;
 constexpr int H = kH;
 constexpr int LDT = 260;               // pitch of a [16][256] tile
@@ -41,10 +48,13 @@ constexpr int PP = 36;                 // pitch of the [16][ac <= 32] tile of th
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Phase timestamps of workgroup 0 of each role (profiling builds only: -DSAMX_TRACE; never shipped)
 #ifdef SAMX_TRACE
-__device__ unsigned long long g_wtrace[128];
+__device__ unsigned long long g_wtrace[256];
 #define WTRACE(w_, role, i) do { if ((w_) == 0 && threadIdx.x == 0) g_wtrace[(role) * 32 + (i)] = wall_clock64(); } while (0)
+// per weight stage of block 0 (the first target+critic workgroup): entries 128 + stream index
+#define WTRACE_STAGE(s_) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (s_) < 128) g_wtrace[128 + (s_)] = wall_clock64(); } while (0)
 #else
 #define WTRACE(w_, role, i) do { } while (0)
+#define WTRACE_STAGE(s_) do { } while (0)
 #endif
 typedef __attribute__((address_space(3))) float lds_float;
 typedef const __attribute__((address_space(1))) float glb_float;
@@ -61,8 +71,16 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// barrier that does not drain the DMAs in flight (a __syncthreads() would)
-__device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Barrier that does not drain the global loads in flight (a __syncthreads() would).  The wait is the BUILTIN
+// (vmcnt 63, expcnt 7, lgkmcnt 0) so that the compiler's wait-count bookkeeping sees it: behind an inline-asm
+// wait it assumed the fragment reads of the previous stage were still pending and made the first MFMAs of a
+// stage wait for reads issued for the NEXT one (which queue behind the loader waves' LDS writes).
+__device__ __forceinline__ void bar() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("s_barrier" ::: "memory");
+}
+// wave-uniform (scalar) role of this wave
+__device__ __forceinline__ bool is_compute() { return __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NC; }
 __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
@@ -84,11 +102,10 @@ __device__ __forceinline__ int64_t ring_row(const int64_t* idx, int64_t start, i
 // Ends with a barrier: afterwards every wave is done with A and with the ring.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte-aligned address
 
-// One 32-deep weight stage, register-staged: 8 x 16 bytes per lane (the whole workgroup moves 32 KB).
-// LDS-DMA was measured first and dropped here: a 1 KiB DMA instruction costs the issuing wave ~130 cycles,
-// 8 per wave and stage = as long as the stage's 32 MFMAs, and the two do not overlap inside one wave;
+// One 32-deep weight stage (32 KB), register-staged by ONE loader wave: 32 x 16 bytes per lane.
+// LDS-DMA was measured first and dropped here: a 1 KiB DMA instruction costs the issuing wave ~130 cycles;
 // plain 16-byte loads issue in a few cycles and land while the MFMAs run.
-struct WRegs { f32x4 q[8]; };
+struct WRegs { f32x4 q[32]; };
 
 // one layer product's weight operand:
 //   nt = false: B[k][j] = W[k * ldw + jg0 + j], rows k < K (clamped: the padded A columns are zero)
@@ -101,128 +118,186 @@ struct WDesc {
 };
 __device__ __forceinline__ int wstages(const WDesc& d) { return (d.K + 31) >> 5; }
 
+// a wave-uniform pointer in SGPRs: loads through it take the scalar-base form (one VGPR offset per lane
+// instead of a 64-bit VGPR address per load: 32 loads in flight would otherwise hold 64 address registers)
+typedef const __attribute__((address_space(1))) f32x4u glb_f32x4u;
+__device__ __forceinline__ glb_float* uniform_ptr(const float* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (glb_float*)(((uint64_t)hi << 32) | lo);   // stays a GLOBAL pointer (a generic one loads through flat)
+}
+__device__ __forceinline__ f32x4 load16(glb_float* base_uniform, unsigned off_floats) {
+    return *(glb_f32x4u*)(base_uniform + off_floats);
+}
+
+// (The lane index goes through an opaque asm so that the per-lane offsets are recomputed where they are
+// used: hoisted out of the stage loop they would hold dozens of registers next to the 128 of the stage.)
+__device__ __forceinline__ int opaque_lane() {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+// No row clamps: a stage may read up to 31 rows (NN) / 255 rows (NT) beyond the matrix.  In the flat
+// [W1 | b1 | W2 | b2 | W3 | b3] layout (samx_mlp) every 256-wide W1 / W2 is followed by more than 256 KB of the
+// same parameter vector, so the reads stay inside it; what they fetch is multiplied by zero-padded activation
+// columns (NN) or lands in output columns >= nvalid that are never stored (NT).
+// Address arithmetic per load is what bounds a loader wave (32 loads per stage): ONE scalar base per stage and
+// per-lane offset register, rows through immediates (NN: 4 rows per 4 KB immediate window, 8 scalar adds) or
+// scalar adds (NT: one per load).
 __device__ __forceinline__ void wstage_load(WRegs& x, const WDesc& d, int t) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = opaque_lane();
     const int k0 = t << 5;
     if (!d.nt) {
+        const float* base = d.W + (int64_t)k0 * H + d.jg0;
+        const unsigned o = 4u * lane;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int kr = k0 + wv + 4 * q;
-            kr = kr < d.K ? kr : d.K - 1;
-            x.q[q] = *(const f32x4u*)(d.W + (int64_t)kr * d.ldw + d.jg0 + 4 * lane);
-        }
+        for (int q = 0; q < 32; ++q)   // one instruction = one 1 KB row of W
+            x.q[q] = load16(uniform_ptr(base + (q >> 2) * (4 * H)) + (q & 3) * H, o);
     } else {
+        const float* base = d.W + (int64_t)d.jg0 * H + k0;
+        const unsigned o = (unsigned)((lane >> 3) * H + 4 * (lane & 7));
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int j = d.jg0 + 8 * (wv + 4 * q) + (lane >> 3);
-            j = j < d.N ? j : d.N - 1;
-            x.q[q] = *(const f32x4u*)(d.W + (int64_t)j * d.ldw + k0 + 4 * (lane & 7));
-        }
+        for (int q = 0; q < 32; ++q)   // one instruction = 128 bytes of each of 8 rows of W
+            x.q[q] = load16(uniform_ptr(base + q * (8 * H)), o);
     }
 }
 __device__ __forceinline__ void wstage_store(const WRegs& x, bool nt, float* S) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = opaque_lane();
     if (!nt) {
+        float* p = S + 4 * lane;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *(f32x4*)(S + (wv + 4 * q) * WP + 4 * lane) = x.q[q];
+        for (int q = 0; q < 32; ++q) *(f32x4*)(p + q * WP) = x.q[q];
     } else {
+        // row jl = 8 q + (lane >> 3), chunk (lane & 7) ^ ((jl >> 1) & 7) = sw ^ 4 (q & 1): two bases + immediates
+        const int sw = (lane & 7) ^ (lane >> 4);
+        float* p0 = S + (lane >> 3) * 32 + (sw << 2);
+        float* p1 = S + (lane >> 3) * 32 + ((sw ^ 4) << 2);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int jl = 8 * (wv + 4 * q) + (lane >> 3);
-            *(f32x4*)(S + jl * 32 + (((lane & 7) ^ ((jl >> 1) & 7)) << 2)) = x.q[q];
-        }
+        for (int q = 0; q < 32; ++q) *(f32x4*)(((q & 1) ? p1 : p0) + q * 256) = x.q[q];
     }
 }
 
-// The weight stream of a chain of products: stages are numbered through the chain (pipe.s), stage s lives
-// in ring slot s % 3, is loaded into registers three stages ahead and written to LDS two stages ahead —
-// about 64 KB per workgroup in flight, across product boundaries (`next`): a product's epilogue runs
-// while the first stages of the next one land.
+// The weight stream of a chain of products: stages are numbered through the chain (pipe.s).  Stage s lives
+// in ring slot s % 3 and belongs to loader wave s % 4, which issues its 32 loads five stages ahead and writes
+// it to LDS two stages ahead: three stages (96 KB) are in flight per workgroup, one per loader wave, each in
+// that wave's ONE register set (no register set is ever indexed at run time).  The stream runs across
+// product boundaries (`next`): a product's epilogue runs while the first stages of the next one land.
+constexpr int AHEAD = 5;   // a stage's loads are issued this many stages before it is read
 struct WPipe {
-    WRegs x0, x1;
+    WRegs x;       // loader waves: the stage this wave holds in flight
     int s;         // stream index of the next product's first stage
-    bool primed;   // its stages 0 and 1 are in LDS and stage 2 is in flight in (flip ? x1 : x0)
-    bool flip;
+    bool primed;   // its stages 0 and 1 are in LDS and stages 2 .. AHEAD-1 are in flight
 };
-__device__ __forceinline__ void wpipe_init(WPipe& p) { p.s = 0; p.primed = false; p.flip = false; }
+__device__ __forceinline__ void wpipe_init(WPipe& p) { p.s = 0; p.primed = false; }
 
-// E: the register set that holds stage 2 on entry, O: the other one.  Even iterations load stage t+3 into O
-// and store stage t+2 from E, odd iterations the other way round (all register indices static).
-__device__ __forceinline__ void wprod_run(WRegs& E, WRegs& O, WPipe& pipe, const WDesc cur, const WDesc next,
-                                          const bool has_next, const float* A, int lda, float* ring,
-                                          f32x4 (&acc)[4]) {
+// LOADER waves: one barrier per stage plus a final one, exactly as wcompute_run.
+__device__ __forceinline__ void wload_run(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                          float* ring) {
+    const int T = wstages(cur), s0 = pipe.s;
+    const int U = T + (has_next ? AHEAD : 0);   // stages this call may load (cur's, then the first of next)
+    const int w = __builtin_amdgcn_readfirstlane(((int)threadIdx.x - NC) >> 6);
+    auto mine = [&](int u) { return ((s0 + u) & 3) == w; };
+    auto ld = [&](int u) {
+        if (u < T) wstage_load(pipe.x, cur, u); else wstage_load(pipe.x, next, u - T);
+    };
+    auto st = [&](int u) {
+        wstage_store(pipe.x, u < T ? cur.nt : next.nt, ring + ((s0 + u) % NSTG) * STAGE_F);
+    };
+    if (!pipe.primed) {   // stages 0 and 1 straight to LDS (two waves side by side), 2 .. AHEAD-1 in flight
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (u < U && mine(u)) { ld(u); st(u); }
+#pragma unroll
+        for (int u = 2; u < AHEAD; ++u)
+            if (u < U && mine(u)) ld(u);
+    }
+#pragma nounroll
+    for (int t = 0; t < T; ++t) {
+        // every compute wave is done with stage t-1: its slot takes stage t+2
+        bar();
+        if (t + AHEAD < U && mine(t + AHEAD)) ld(t + AHEAD);   // never the wave that stores now (AHEAD - 2 = 3)
+        if (t + 2 < U && mine(t + 2)) st(t + 2);
+    }
+    bar();
+}
+
+// COMPUTE waves.  After the barrier that opens stage t, stage t (written during stage t-2) and stage t+1
+// (written during stage t-1) are both in LDS: the fragments of stage t+1 are read while the MFMAs of stage
+// t run from the registers filled one stage earlier (one wave per SIMD computes: nobody else would hide the
+// LDS latency).
+struct WFrag { f32x4 a4[2], b4[2][4]; };
+__device__ __forceinline__ void wcompute_run(const WPipe& pipe, const WDesc cur, const float* A, int lda,
+                                             const float* ring, f32x4 (&acc)[4]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     const int T = wstages(cur), s0 = pipe.s;
-    const int U = T + (has_next ? 3 : 0);   // stages this call may load (cur's, then the first three of next)
-    auto ld = [&](int u, WRegs& x) {
-        if (u < T) wstage_load(x, cur, u); else wstage_load(x, next, u - T);
-    };
-    auto st = [&](int u, const WRegs& x) {
-        wstage_store(x, u < T ? cur.nt : next.nt, ring + ((s0 + u) % NSTG) * STAGE_F);
-    };
-    if (!pipe.primed) {
-        ld(0, E);
-        if (1 < U) ld(1, O);
-        st(0, E);
-        if (1 < U) st(1, O);
-        if (2 < U) ld(2, E);
-    }
-    auto iter = [&](int t, WRegs& LD, const WRegs& ST) {
-        // every wave is done with stage t-1 and has written its share of stage t (and t+1)
-        bar();
-        if (t + 3 < U) ld(t + 3, LD);
+    auto rd = [&](int t, WFrag& f) {
         const float* S = ring + ((s0 + t) % NSTG) * STAGE_F;
         const int k0 = t << 5;
-        // all fragment reads of the stage are issued before the first MFMA (counted lgkmcnt waits let the
-        // first MFMAs start while the later reads are still in flight: one wave per SIMD has nobody else to
-        // hide the LDS latency behind)
-        f32x4 a4[2], b4[2][4];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            a4[g] = *(const f32x4*)(A + r * lda + k0 + 16 * g + 4 * kq);
+            f.a4[g] = *(const f32x4*)(A + r * lda + k0 + 16 * g + 4 * kq);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const int jl = 64 * wv + 16 * nb + r;
                 if (cur.nt) {
-                    b4[g][nb] = *(const f32x4*)(S + jl * 32 + (((4 * g + kq) ^ ((jl >> 1) & 7)) << 2));
+                    f.b4[g][nb] = *(const f32x4*)(S + jl * 32 + (((4 * g + kq) ^ ((jl >> 1) & 7)) << 2));
                 } else {
                     const float* p = S + (16 * g + 4 * kq) * WP + jl;
-                    b4[g][nb][0] = p[0]; b4[g][nb][1] = p[WP]; b4[g][nb][2] = p[2 * WP]; b4[g][nb][3] = p[3 * WP];
+                    f.b4[g][nb][0] = p[0]; f.b4[g][nb][1] = p[WP]; f.b4[g][nb][2] = p[2 * WP];
+                    f.b4[g][nb][3] = p[3 * WP];
                 }
             }
         }
-        // consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair costs 40 cycles, not 32);
-        // blocks beyond nvalid compute finite values that are never stored
+    };
+    // consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair costs 40 cycles, not 32);
+    // blocks beyond nvalid compute finite values that are never stored
+    auto mm = [&](const WFrag& f) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(a4[g][m], b4[g][nb][m], acc[nb]);
-        if (t + 2 < U) st(t + 2, ST);
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(f.a4[g][m], f.b4[g][nb][m], acc[nb]);
     };
-    for (int t = 0; t < T; t += 2) {
-        iter(t, O, E);
-        if (t + 1 < T) iter(t + 1, E, O);
+    WFrag f0, f1;
+    bar();
+    WTRACE_STAGE(s0);
+    rd(0, f0);
+    if (1 < T) rd(1, f1);
+    mm(f0);
+#pragma nounroll
+    for (int t = 1; t < T; t += 2) {
+        bar();
+        WTRACE_STAGE(s0 + t);
+        if (t + 1 < T) rd(t + 1, f0);
+        mm(f1);
+        if (t + 1 < T) {
+            bar();
+            WTRACE_STAGE(s0 + t + 1);
+            if (t + 2 < T) rd(t + 2, f1);
+            mm(f0);
+        }
     }
     bar();
-    pipe.s = s0 + T;
-    pipe.primed = has_next;
-    if (T & 1) pipe.flip = !pipe.flip;
 }
 
-// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for this wave's four 16-column blocks; A in LDS with
-// pitch lda (a multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).
+// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for compute wave w's four 16-column blocks; A in LDS with
+// pitch lda (a multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).  Called by ALL waves.
 // Ends with a barrier: afterwards every wave is done with A (the ring slots of `next` stay live).
+template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc next, bool has_next, const float* A,
                                       int lda, float* ring, f32x4 (&acc)[4]) {
-    if (wstages(cur) < 3 || wstages(next) < 3) has_next = false;   // short products do not chain
-    if (pipe.flip) wprod_run(pipe.x1, pipe.x0, pipe, cur, next, has_next, A, lda, ring, acc);
-    else wprod_run(pipe.x0, pipe.x1, pipe, cur, next, has_next, A, lda, ring, acc);
+    if (wstages(cur) < AHEAD || wstages(next) < AHEAD) has_next = false;   // short products do not chain
+    if constexpr (CW) wcompute_run(pipe, cur, A, lda, ring, acc);
+    else wload_run(pipe, cur, next, has_next, ring);
+    pipe.s += wstages(cur);
+    pipe.primed = has_next;
 }
+template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const float* A, int lda, float* ring,
                                       f32x4 (&acc)[4]) {   // last product of a chain
-    wprod(pipe, cur, cur, false, A, lda, ring, acc);
+    wprod<CW>(pipe, cur, cur, false, A, lda, ring, acc);
 }
 
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
@@ -230,7 +305,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
     for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// f(row, col, value, bit index) over this wave's accumulator elements
+// f(row, col, value, bit index) over this (compute) wave's accumulator elements
 template <typename F>
 __device__ __forceinline__ void for_acc(const f32x4 (&acc)[4], F f) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -240,30 +315,34 @@ __device__ __forceinline__ void for_acc(const f32x4 (&acc)[4], F f) {
         for (int j = 0; j < 4; ++j) f((lane >> 4) * 4 + j, 64 * wv + 16 * nb + (lane & 15), acc[nb][j], nb * 4 + j);
 }
 
+// (ldw is H for every product: the loaders use it as a compile-time constant)
 __device__ __forceinline__ WDesc w_nn(const float* W, int K) { return WDesc{W, H, K, H, 0, H, false}; }
 __device__ __forceinline__ WDesc w_nt(const float* W, int N, int jg0, int nvalid) {
     return WDesc{W, H, H, N, jg0, nvalid, true};
 }
 
 // hidden layer: out = lrelu(A W + b) into the LDS tile T and, if hbm, to hbm[(row0 + r)][256].
-// Returns this lane's 16 mask bits (value >= 0).
+// Called by all waves; returns this (compute) lane's 16 mask bits (value >= 0).
+template <bool CW>
 __device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
                                                const float* A, int lda, const float* __restrict__ b, float* ring,
                                                float* T, float* __restrict__ hbm, int64_t row0) {
     f32x4 acc[4];
     zero_acc(acc);
-    wprod(pipe, cur, next, has_next, A, lda, ring, acc);
+    wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
     unsigned bits = 0;
-    for_acc(acc, [&](int r, int c, float v, int bi) {
-        const float a = lrelu(v + b[c]);
-        T[r * LDT + c] = a;
-        if (hbm) hbm[(row0 + r) * H + c] = a;
-        bits |= (a >= 0.f ? 1u : 0u) << bi;
-    });
+    if constexpr (CW)
+        for_acc(acc, [&](int r, int c, float v, int bi) {
+            const float a = lrelu(v + b[c]);
+            T[r * LDT + c] = a;
+            if (hbm) hbm[(row0 + r) * H + c] = a;
+            bits |= (a >= 0.f ? 1u : 0u) << bi;
+        });
     bar();   // T is complete for every reader that follows
     return bits;
 }
 
+// The helpers below (head1 .. head_bwd, load_rows) are for the compute waves only: threadIdx.x < NC.
 // s[r] = <T[r], w3> + b3  (1-output head; w3 / b3 from global memory)
 __device__ __forceinline__ void head1(const float* T, const float* __restrict__ w3, const float* __restrict__ b3,
                                       float* s_out) {
@@ -293,7 +372,7 @@ __device__ __forceinline__ void head_grad_slot(const float* T, const float* dq, 
 // T[r][c] = dq[r] * w3[c] * lrelu'(T[r][c]) in place, and to hbm
 __device__ __forceinline__ void head_bwd(float* T, const float* dq, const float* __restrict__ w3,
                                          float* __restrict__ hbm, int64_t row0) {
-    for (int t = threadIdx.x; t < R * H; t += NT) {
+    for (int t = threadIdx.x; t < R * H; t += NC) {
         const int r = t >> 8, c = t & 255;
         const float v = dq[r] * w3[c] * dlrelu(T[r * LDT + c]);
         T[r * LDT + c] = v;
@@ -303,7 +382,7 @@ __device__ __forceinline__ void head_bwd(float* T, const float* dq, const float*
 
 // the whole head matrix W3[256][out <= 32] (contiguous) into ring slot 0 as it lies: S[k * out + j]
 __device__ __forceinline__ void stage_head(const float* __restrict__ W3, int out, float* ring) {
-    const int n4 = 64 * out;   // 16-byte chunks
+    const int n4 = 64 * out;   // 16-byte chunks; every thread of the workgroup copies (called by all waves)
     for (int t = threadIdx.x; t < n4; t += NT) *(f32x4*)(ring + 4 * t) = *(const f32x4u*)(W3 + 4 * t);
     bar();
 }
@@ -364,12 +443,14 @@ __device__ __forceinline__ void load_rows(const Lds& L, int k32, const float* __
     }
 }
 
-// actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac)
+// actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac);
+// called by all waves
+template <bool CW>
 __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, int ac, float high,
                                            float* __restrict__ hbm, int64_t row0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     stage_head(n.W3, ac, L.ring);
-    if (16 * wv < ac) {
+    if (CW && 16 * wv < ac) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int jc = min(16 * wv + r, ac - 1);
         for (int k = 0; k < H; k += 4) acc = mfma4(L.T2[r * LDT + k + kq], L.ring[(k + kq) * ac + jc], acc);
@@ -390,19 +471,21 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool CW>
 __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
+    constexpr bool cw = CW;
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
     const int k32c = ((in_c + 31) / 32) * 32;
-    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
     const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
     const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
-    if (tid < R) {
+    if (cw && tid < R) {
         const int64_t prs = ring_row(a.idx, a.ring_start, a.ring_len, row0 + tid);
         L.rw[tid] = a.rews[prs];
         L.dn[tid] = a.dones1[prs];
@@ -411,39 +494,42 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     }
     // ---- TD target with the target nets on obs1
     WTRACE(wg, 0, 0);
-    load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
+#ifdef SAMX_TRACE
+    if (cw && wg == 0 && tid == 0) g_wtrace[120] = clock64();   // shader clock beside the 100 MHz wall clock
+#endif
+    if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
     bar();
     WTRACE(wg, 0, 1);
-    hidden_fwd(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
+    hidden_fwd<CW>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
     WTRACE(wg, 0, 2);
-    hidden_fwd(pipe, ta2, ta2, false, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    hidden_fwd<CW>(pipe, ta2, ta2, false, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
     WTRACE(wg, 0, 3);
-    actor_head(L, a.targ_actor, ob, ac, a.high, nullptr, 0);
+    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0);
     WTRACE(wg, 0, 4);
-    hidden_fwd(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
+    hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
     WTRACE(wg, 0, 5);
-    hidden_fwd(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
+    hidden_fwd<CW>(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
     WTRACE(wg, 0, 6);
-    head1(L.T2, a.targ_critic.W3, a.targ_critic.b3, L.s_);
+    if (cw) head1(L.T2, a.targ_critic.W3, a.targ_critic.b3, L.s_);
     bar();
     WTRACE(wg, 0, 7);
-    if (tid < R) {
+    if (cw && tid < R) {
         const float gam = a.td_len ? powf(a.gamma, L.tl[tid]) : a.gamma;
         const float t = L.rw[tid] + gam * ((1.f - L.dn[tid]) * L.s_[tid]);   // sam_agent.py:202-205
         a.targ_q[row0 + tid] = t;
         L.tq[tid] = t;
     }
     // ---- online critic on (obz0, acs): forward, loss, backward
-    load_rows(L, k32c, a.obs0, a.acs, a.mean, a.stdv, ob, ac, ac, pr, a.Xc, row0 + (tid >> 4), in_c);
+    if (cw) load_rows(L, k32c, a.obs0, a.acs, a.mean, a.stdv, ob, ac, ac, pr, a.Xc, row0 + (tid >> 4), in_c);
     bar();
     WTRACE(wg, 0, 8);
-    hidden_fwd(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, a.A1c, row0);
+    hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, a.A1c, row0);
     WTRACE(wg, 0, 9);
-    hidden_fwd(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, a.A2c, row0);
+    hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, a.A2c, row0);
     WTRACE(wg, 0, 10);
-    head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+    if (cw) head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
     bar();
-    if (tid < R) {
+    if (cw && tid < R) {
         const float td = L.s_[tid] - L.tq[tid];
         const float iw = L.iw[tid];
         const float ad = fabsf(td);
@@ -456,64 +542,78 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         if (a.td_out) a.td_out[row0 + tid] = td;
     }
     bar();
-    head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
-    head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
+    if (cw) {
+        head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
+        head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
+    }
     bar();
     WTRACE(wg, 0, 11);
     {
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, c3, L.T2, LDT, L.ring, acc);
+        wprod<CW>(pipe, c3, L.T2, LDT, L.ring, acc);
         WTRACE(wg, 0, 12);
-        for_acc(acc, [&](int r, int c, float v, int) {
-            a.DZ1c[(row0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
-        });
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int) {
+                a.DZ1c[(row0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
+            });
     }
     WTRACE(wg, 0, 13);
+#ifdef SAMX_TRACE
+    if (cw && wg == 0 && tid == 0) g_wtrace[121] = clock64();
+#endif
 }
 
+template <bool CW>
 __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr bool cw = CW;
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
     const int k32c = ((in_c + 31) / 32) * 32;
-    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4));
+    const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc a1 = w_nn(a.actor.W1, ob), a2 = w_nn(a.actor.W2, H), a3 = w_nt(a.actor.W2, H, 0, H);
     const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
     const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
-    load_rows(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 4), in_c);
-    for (int t = tid; t < R * PP; t += NT) L.PRE[t] = 0.f;
+    if (cw) {
+        load_rows(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 4), in_c);
+        for (int t = tid; t < R * PP; t += NC) L.PRE[t] = 0.f;
+    }
     bar();
-    const unsigned m1a = hidden_fwd(pipe, a1, a2, true, L.X, L.px, a.actor.b1, L.ring, L.T1, a.A1a, row0);
-    const unsigned m2a = hidden_fwd(pipe, a2, a2, false, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
-    actor_head(L, a.actor, ob, ac, a.high, a.Xa, row0);
+    const unsigned m1a = hidden_fwd<CW>(pipe, a1, a2, true, L.X, L.px, a.actor.b1, L.ring, L.T1, a.A1a, row0);
+    const unsigned m2a = hidden_fwd<CW>(pipe, a2, a2, false, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
+    actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0);
     // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
-    hidden_fwd(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, nullptr, 0);
-    hidden_fwd(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
-    head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
-    if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+    hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, nullptr, 0);
+    hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
+    if (cw) {
+        head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+        if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+    }
     bar();
-    if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
-    for (int t = tid; t < R * H; t += NT) {   // dZ2c in place
-        const int r = t >> 8, c = t & 255;
-        L.T2[r * LDT + c] = L.dq[r] * a.critic.W3[c] * dlrelu(L.T2[r * LDT + c]);
+    if (cw) {
+        if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
+        for (int t = tid; t < R * H; t += NC) {   // dZ2c in place
+            const int r = t >> 8, c = t & 255;
+            L.T2[r * LDT + c] = L.dq[r] * a.critic.W3[c] * dlrelu(L.T2[r * LDT + c]);
+        }
     }
     bar();
     {   // dZ1c = (dZ2c W2c^T) .* lrelu'(A1c), in place over A1c (every wave is past the product's last barrier)
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, c3, c4, true, L.T2, LDT, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
+        wprod<CW>(pipe, c3, c4, true, L.T2, LDT, L.ring, acc);
+        if (cw) for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
     }
     bar();
     {   // dQ/da = dZ1c W1c[ob:ob+ac, :]^T, through clip (identity inside the range) and tanh
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, c4, L.T1, LDT, L.ring, acc);
-        if (wv == 0) {
+        wprod<CW>(pipe, c4, L.T1, LDT, L.ring, acc);
+        if (cw && wv == 0) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 const int c = 16 * nb + (lane & 15);
@@ -537,32 +637,37 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         f32x4 acc[4];
         zero_acc(acc);
         const int ks = (ac + 3) / 4;
-        for (int kk = 0; kk < ks; ++kk) {
-            const float av = L.PRE[r * PP + 4 * kk + kq];
+        if (cw)
+            for (int kk = 0; kk < ks; ++kk) {
+                const float av = L.PRE[r * PP + 4 * kk + kq];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                acc[nb] = mfma4(av, L.ring[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
-        }
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[nb] = mfma4(av, L.ring[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
+            }
         bar();
-        for_acc(acc, [&](int r_, int c, float v, int bi) {
-            const float z = v * ((m2a >> bi) & 1u ? 1.f : 0.2f);
-            L.T2[r_ * LDT + c] = z;
-            a.DZ2a[(row0 + r_) * H + c] = z;
-        });
+        if (cw)
+            for_acc(acc, [&](int r_, int c, float v, int bi) {
+                const float z = v * ((m2a >> bi) & 1u ? 1.f : 0.2f);
+                L.T2[r_ * LDT + c] = z;
+                a.DZ2a[(row0 + r_) * H + c] = z;
+            });
     }
     bar();
     {   // dZ1a = (dZ2a W2a^T) .* lrelu'(A1a)
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, a3, L.T2, LDT, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int bi) {
-            a.DZ1a[(row0 + r) * H + c] = v * ((m1a >> bi) & 1u ? 1.f : 0.2f);
-        });
+        wprod<CW>(pipe, a3, L.T2, LDT, L.ring, acc);
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int bi) {
+                a.DZ1a[(row0 + r) * H + c] = v * ((m1a >> bi) & 1u ? 1.f : 0.2f);
+            });
     }
 }
 
+template <bool CW>
 __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
+    constexpr bool cw = CW;
     const int tiles_b = (int)(a.B / R);
     // interpolate tiles first (the longest chain), then policy, then expert
     const int sect = wg < tiles_b ? 2 : (wg < 2 * tiles_b ? 0 : 1);
@@ -582,7 +687,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const bool norm = a.rms_sums != nullptr || a.mean != nullptr;
     float* ms = L.T1;   // [0, kMaxIn) mean, [kMaxIn, 2 kMaxIn) std
     if (norm) {
-        for (int c = tid; c < ob; c += NT) {
+        for (int c = tid; c < ob; c += NT) {   // every thread of the workgroup
             float gm, gs;
             if (a.rms_sums) {
                 const double cnt = a.rms_sums[2 * ob] + a.rms_addvec[2 * ob];
@@ -599,7 +704,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         }
         bar();
     }
-    {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134);
+    if (cw) {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134);
         // loads in batches (see load_rows)
         const int r = tid >> 4, c0 = tid & 15;
         const int64_t g = row0 + r;
@@ -650,11 +755,11 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     bar();
     if (sect != 2) {
         // ---- policy / expert rows
-        hidden_fwd(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
-        hidden_fwd(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, a.A2, hrow0);
-        head1(L.T2, n.W3, n.b3, L.s_);
+        hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
+        hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, a.A2, hrow0);
+        if (cw) head1(L.T2, n.W3, n.b3, L.s_);
         bar();
-        if (tid < R) {
+        if (cw && tid < R) {
             const int64_t g = row0 + tid;
             const float s = L.s_[tid];
             float z;
@@ -678,15 +783,18 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             a.sg[hrow0 + tid] = sg;
         }
         bar();
-        head_grad_slot(L.T2, L.dq, a.w3_part + (int64_t)wg * (H + 1));
-        head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
+        if (cw) {
+            head_grad_slot(L.T2, L.dq, a.w3_part + (int64_t)wg * (H + 1));
+            head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
+        }
         bar();
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, d3, L.T2, LDT, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int) {
-            a.DZ1[(hrow0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
-        });
+        wprod<CW>(pipe, d3, L.T2, LDT, L.ring, acc);
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int) {
+                a.DZ1[(hrow0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
+            });
         return;
     }
     // ---- interpolate rows: g = d score / d input, sum g^2, V = g / (B dim), tangent forward along V.
@@ -694,44 +802,46 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     // weight gradients after this launch, not here.
     const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
     const WDesc t1 = w_nn(n.W1, in), t2 = w_nn(n.W2, H);
-    hidden_fwd(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
-    const unsigned m2 = hidden_fwd(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
-    if (tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
+    hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
+    const unsigned m2 = hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
+    if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
     bar();
-    head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);                                                    // gz2
+    if (cw) head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);                                            // gz2
     bar();
     {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, d3, g0, true, L.T2, LDT, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int) {
-            const float z = v * dlrelu(L.T1[r * LDT + c]);
-            L.T2[r * LDT + c] = z;
-            a.DZ1[(hrow0 + r) * H + c] = z;
-        });
+        wprod<CW>(pipe, d3, g0, true, L.T2, LDT, L.ring, acc);
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int) {
+                const float z = v * dlrelu(L.T1[r * LDT + c]);
+                L.T2[r * LDT + c] = z;
+                a.DZ1[(hrow0 + r) * H + c] = z;
+            });
     }
     bar();
     {   // g = gz1 W1^T, 256 input columns at a time, over X (dead by now)
         auto put = [&](const f32x4 (&acc)[4], int j0) {
-            for_acc(acc, [&](int r, int c, float v, int) {
-                if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
-            });
+            if (cw)
+                for_acc(acc, [&](int r, int c, float v, int) {
+                    if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
+                });
         };
         f32x4 acc[4];
         zero_acc(acc);
         if (in > H) {
-            wprod(pipe, g0, g1, true, L.T2, LDT, L.ring, acc);
+            wprod<CW>(pipe, g0, g1, true, L.T2, LDT, L.ring, acc);
             put(acc, 0);
             zero_acc(acc);
-            wprod(pipe, g1, t1, true, L.T2, LDT, L.ring, acc);
+            wprod<CW>(pipe, g1, t1, true, L.T2, LDT, L.ring, acc);
             put(acc, H);
         } else {
-            wprod(pipe, g0, t1, true, L.T2, LDT, L.ring, acc);
+            wprod<CW>(pipe, g0, t1, true, L.T2, LDT, L.ring, acc);
             put(acc, 0);
         }
     }
     bar();
-    {
+    if (cw) {
         const int r = tid >> 4, q = tid & 15;
         float so = 0.f, sa = 0.f;
         for (int c = q; c < in; c += 16) {
@@ -742,13 +852,13 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
     }
     bar();
-    if (tid == 0) {
+    if (cw && tid == 0) {
         double o = 0.0, c = 0.0;
         for (int r = 0; r < R; ++r) { o += (double)L.red[r]; c += (double)L.red[16 + r]; }
         a.gp_part[2 * (wg % tiles_b)] = o;
         a.gp_part[2 * (wg % tiles_b) + 1] = c;
     }
-    {
+    if (cw) {
         const float co = 1.f / ((float)a.B * (float)ob), ca = 1.f / ((float)a.B * (float)ac);
         const int r = tid >> 4, c0 = tid & 15;
         for (int c = c0; c < in; c += 16) {
@@ -761,24 +871,27 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     {   // a1dot = (V W1) .* m1, in place over A1
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, t1, t2, true, L.X, L.px, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int) {
-            const float z = v * dlrelu(L.T1[r * LDT + c]);
-            L.T1[r * LDT + c] = z;
-            a.A1[(hrow0 + r) * H + c] = z;
-        });
+        wprod<CW>(pipe, t1, t2, true, L.X, L.px, L.ring, acc);
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int) {
+                const float z = v * dlrelu(L.T1[r * LDT + c]);
+                L.T1[r * LDT + c] = z;
+                a.A1[(hrow0 + r) * H + c] = z;
+            });
     }
     bar();
     {   // a2dot = (a1dot W2) .* m2
         f32x4 acc[4];
         zero_acc(acc);
-        wprod(pipe, t2, L.T1, LDT, L.ring, acc);
-        for_acc(acc, [&](int r, int c, float v, int bi) {
-            a.A2[(hrow0 + r) * H + c] = v * ((m2 >> bi) & 1u ? 1.f : 0.2f);
-        });
+        wprod<CW>(pipe, t2, L.T1, LDT, L.ring, acc);
+        if (cw)
+            for_acc(acc, [&](int r, int c, float v, int bi) {
+                a.A2[(hrow0 + r) * H + c] = v * ((m2 >> bi) & 1u ? 1.f : 0.2f);
+            });
         // head gradient of these rows: sum_r a2dot[r][c] (without k), rows in a fixed order
         float* slot = a.w3_part + (int64_t)wg * (H + 1);
         const int lane = tid & 63, wv = tid >> 6;
+        if (cw)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             float sm = 0.f;
@@ -792,10 +905,16 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     }
 }
 
+// Placement: blocks b and b + 8 share an XCD (and its 4 MiB L2), so the 8 residue classes of blockIdx.x are
+// dealt to the roles — classes [0, g_tc) run target+critic tiles, [g_tc, g_tc + g_a) actor tiles, the rest
+// discriminator tiles — and an XCD's L2 only has to hold the weights of ONE role (with every role on every
+// XCD the five networks plus the activation stores overflow it and the weight stream comes from the Infinity
+// Cache at less than half the rate).  Affinity only: nothing depends on where a block runs.
 struct RoleArgs {
     AgentArgs a;
     DiscArgs d;
     int n_tc, n_a, n_d;
+    int g_tc, g_a, per;   // residue classes per role; blocks per class
 };
 
 // partial sums of squares of the decayed kernels: workgroup b of n takes elements b * NT + tid, + n * NT, ...
@@ -819,13 +938,23 @@ __device__ inline void role_wd(const AgentArgs& a, int b) {
 
 __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int b = blockIdx.x;
-    if (b < s.n_tc) { role_tc(s.a, b, lds); return; }   // longest chain first
-    b -= s.n_tc;
-    if (b < s.n_a) { role_a(s.a, b, lds); return; }
-    b -= s.n_a;
-    if (b < s.n_d) { role_d(s.d, b, lds); return; }
-    role_wd(s.a, b - s.n_d);
+    const int b = blockIdx.x;
+    const bool cw = is_compute();   // scalar: waves 0-3 compute, waves 4-7 load
+    if (b >= 8 * s.per) { role_wd(s.a, b - 8 * s.per); return; }
+    const int g = b & 7, j = b >> 3;
+    if (g < s.g_tc) {
+        const int wg = j * s.g_tc + g;
+        if (wg >= s.n_tc) return;
+        if (cw) role_tc<true>(s.a, wg, lds); else role_tc<false>(s.a, wg, lds);
+    } else if (g < s.g_tc + s.g_a) {
+        const int wg = j * s.g_a + (g - s.g_tc);
+        if (wg >= s.n_a) return;
+        if (cw) role_a<true>(s.a, wg, lds); else role_a<false>(s.a, wg, lds);
+    } else {
+        const int wg = j * (8 - s.g_tc - s.g_a) + (g - s.g_tc - s.g_a);   // interpolate tiles come first
+        if (wg >= s.n_d) return;
+        if (cw) role_d<true>(s.d, wg, lds); else role_d<false>(s.d, wg, lds);
+    }
 }
 
 bool net_ok(const samx_mlp* d) { return d && !d->layernorm && d->h1 == kH && d->h2 == kH; }
@@ -856,11 +985,29 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
     }
     const int n_wd = (a && (roles & 2) && a->wd_part) ? a->wd_blocks : 0;
     if (s.n_tc + s.n_a + s.n_d == 0) return SAMX_OK;
+    {   // residue classes in proportion to the roles' tiles (each present role gets at least one)
+        const int n[3] = {s.n_tc, s.n_a, s.n_d};
+        int g[3] = {0, 0, 0}, left = 8;
+        for (int i = 0; i < 3; ++i)
+            if (n[i] > 0) { g[i] = 1; --left; }
+        while (left > 0) {   // one more class to the role with the most tiles per class
+            int best = 0;
+            double load = -1.0;
+            for (int i = 0; i < 3; ++i)
+                if (n[i] > 0 && (double)n[i] / g[i] > load) { load = (double)n[i] / g[i]; best = i; }
+            ++g[best];
+            --left;
+        }
+        s.g_tc = g[0]; s.g_a = g[1];
+        s.per = 0;
+        for (int i = 0; i < 3; ++i)
+            if (n[i] > 0 && (n[i] + g[i] - 1) / g[i] > s.per) s.per = (n[i] + g[i] - 1) / g[i];
+    }
     const size_t lds = lds_floats(in) * sizeof(float);
     SAMX_REQUIRE(lds <= 160 * 1024, "wide role kernel needs %zu bytes of LDS", lds);
     static LdsGrant grant;
     if (int rc = grant.ensure((const void*)roles_kernel, lds)) return rc;
-    roles_kernel<<<(unsigned)(s.n_tc + s.n_a + s.n_d + n_wd), NT, lds, st>>>(s);
+    roles_kernel<<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -870,6 +1017,6 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
 
 #ifdef SAMX_TRACE
 extern "C" int samx_debug_wide_trace(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::wide::g_wtrace), sizeof(unsigned long long) * 128);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::wide::g_wtrace), sizeof(unsigned long long) * 256);
 }
 #endif

@@ -20,8 +20,8 @@ mu, d, pool, drv = bench.build_learner(cfg, TorchComm(dev), dev, 0, True)
 drv.prepare(1)
 drv.run(8)
 lib = C.CDLL(_lib.SO_PATH)
-buf = (C.c_ulonglong * 128)()
-acc = np.zeros((20, 128))
+buf = (C.c_ulonglong * 256)()
+acc = np.zeros((20, 256))
 part = 1 | (4 if os.environ.get('SAMX_WIDE_ALONE') == '1' else 0)
 for it in range(20):
     ops.step_grads_part(drv.L, drv.batch, drv.out, part)
@@ -31,3 +31,12 @@ for it in range(20):
 t = acc[5:, :32]
 rel = (t - t[:, :1]) / 100.0
 print('target+critic', ' '.join('%d:%.2f' % (i, x) for i, x in enumerate(np.median(rel, axis=0)) if t[0, i] > 0))
+st = acc[5:, 128:]
+n = int((st[0] > 0).sum())
+d = np.median(np.diff(st[:, :n], axis=1), axis=0) / 100.0
+print('stage starts (us between consecutive weight stages of target+critic workgroup 0; product boundaries show as '
+      'the larger gaps):')
+print(' '.join('%d:%.2f' % (i, x) for i, x in enumerate(d)))
+cyc = np.median(acc[5:, 121] - acc[5:, 120])
+us = np.median(t[:, 13] - t[:, 0]) / 100.0
+print('shader clock over the target+critic role: %.0f cycles in %.2f us = %.2f GHz' % (cyc, us, cyc / us / 1e3))
