@@ -344,14 +344,22 @@ __device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, con
 
 // The helpers below (head1 .. head_bwd, load_rows) are for the compute waves only: threadIdx.x < NC.
 // s[r] = <T[r], w3> + b3  (1-output head; w3 / b3 from global memory)
-__device__ __forceinline__ void head1(const float* T, const float* __restrict__ w3, const float* __restrict__ b3,
-                                      float* s_out) {
+// The head's weights travel ahead (head_issue before the product that fills T, head1 after it): their loads
+// would otherwise be a bare L2 round trip in the middle of the chain.
+struct HeadRegs { float w[H / 16], b; };
+__device__ __forceinline__ void head_issue(HeadRegs& h, const float* __restrict__ w3, const float* __restrict__ b3) {
+    const int q = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) h.w[i] = w3[q + 16 * i];
+    h.b = b3[0];
+}
+__device__ __forceinline__ void head1(const float* T, const HeadRegs& h, float* s_out) {
     const int r = threadIdx.x >> 4, q = threadIdx.x & 15;
     float acc = 0.f;
 #pragma unroll
-    for (int c = q; c < H; c += 16) acc = fmaf(T[r * LDT + c], w3[c], acc);
+    for (int i = 0; i < H / 16; ++i) acc = fmaf(T[r * LDT + q + 16 * i], h.w[i], acc);
     acc = sum16(acc);
-    if (q == 0) s_out[r] = acc + b3[0];
+    if (q == 0) s_out[r] = acc + h.b;
 }
 
 // this tile's share of the head's gradient: slot[c] = sum_r T[r][c] dq[r] (c < 256), slot[256] = sum_r dq[r].
@@ -380,10 +388,30 @@ __device__ __forceinline__ void head_bwd(float* T, const float* dq, const float*
     }
 }
 
-// the whole head matrix W3[256][out <= 32] (contiguous) into ring slot 0 as it lies: S[k * out + j]
-__device__ __forceinline__ void stage_head(const float* __restrict__ W3, int out, float* ring) {
-    const int n4 = 64 * out;   // 16-byte chunks; every thread of the workgroup copies (called by all waves)
-    for (int t = threadIdx.x; t < n4; t += NT) *(f32x4*)(ring + 4 * t) = *(const f32x4u*)(W3 + 4 * t);
+// the whole head matrix W3[256][out <= 32] (contiguous) into one ring slot as it lies: S[k * out + j].
+// With a primed weight stream (stages 0 and 1 of the next product in LDS) the free slot is
+// free_slot(ring, pipe): stage 2 lands there only after the next product's first barrier.
+__device__ __forceinline__ float* free_slot(float* ring, const WPipe& pipe) {
+    return ring + ((pipe.s + 2) % NSTG) * STAGE_F;
+}
+// Two halves (every thread of the workgroup, all waves): the loads go out before the product in front,
+// the LDS writes and the barrier come after it.
+struct HeadStage { f32x4 q[4]; };   // 64 * out <= 2048 chunks of 16 bytes over 512 threads
+__device__ __forceinline__ void stage_head_issue(HeadStage& hs, const float* __restrict__ W3, int out) {
+    const int n4 = 64 * out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = min((int)threadIdx.x + NT * i, n4 - 1);
+        hs.q[i] = *(const f32x4u*)(W3 + 4 * t);
+    }
+}
+__device__ __forceinline__ void stage_head_commit(const HeadStage& hs, int out, float* slot) {
+    const int n4 = 64 * out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = threadIdx.x + NT * i;
+        if (t < n4) *(f32x4*)(slot + 4 * t) = hs.q[i];
+    }
     bar();
 }
 
@@ -391,7 +419,8 @@ struct Lds {
     float *ring, *X, *T1, *T2, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl;
     int px;
 };
-__host__ __device__ inline int pitch_x(int in) { return ((in + 31) / 32) * 32 + 4; }
+// (the full width whatever the input: rows_commit writes all kMaxIn columns)
+__host__ __device__ inline int pitch_x(int) { return kMaxIn + 4; }
 __host__ __device__ inline size_t lds_floats(int in) {
     return (size_t)NSTG * STAGE_F + (size_t)R * pitch_x(in) + 2 * R * LDT + R * PP + 16 * 8 + 64;
 }
@@ -409,51 +438,111 @@ __device__ inline Lds carve(float* p, int in) {
 }
 
 // rows [obz | acs] of the batch into X[16][px], zero up to k32 columns; optional dense copy to HBM.
-// Thread t owns row t >> 4 and the columns (t & 15) + 16 i; the loads go out in batches of kRowBatch before
-// anything waits (a load -> use per column would pay one memory round trip per column).
-constexpr int kRowBatch = 13;
+// Thread t owns row t >> 4 and the columns (t & 15) + 16 u.  Two halves: rows_issue sends ALL the row loads
+// (raw values, one register per column) and returns; rows_commit normalises and writes.  A role issues the
+// next input's rows before a product that does not need X and commits them after it: the HBM gather's
+// latency (2-3 us) hides behind the product.
+constexpr int kRowRegs = kMaxIn / 16;   // 26
+struct RowRegs { float v[kRowRegs]; };
+// (thread index through an opaque asm, as in the loaders: the per-column predicates must be recomputed where
+// they are used — kept live from the issue to the commit across a product they spill by the hundred)
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+__device__ __forceinline__ void rows_issue(RowRegs& x, int k32, const float* __restrict__ obs,
+                                           const float* __restrict__ acs, int ob, int ac, int acw, int64_t prow) {
+    // branch-free: every column loads from a valid address (columns beyond the row re-read its last element;
+    // rows_commit zeroes them) — a branch per column costs more than the loads
+    const int c0 = opaque_tid() & 15;
+    const float* ro = obs + prow * ob;
+    const float* ra = acw > 0 ? acs + prow * ac : ro;
+    const int amax = acw > 0 ? acw - 1 : 0;
+#pragma unroll
+    for (int u = 0; u < kRowRegs; ++u) {
+        const int c = c0 + 16 * u;
+        const bool isob = c < ob;
+        const int ci = isob ? c : min(c - ob, amax);
+        x.v[u] = (isob ? ro : ra)[ci];
+    }
+}
+// Straight-line on purpose (one uniform branch on `mean` around everything, selects inside): the role
+// kernels run at the SGPR limit, and every branch region reloads its spilled scalars.  All kRowRegs columns
+// are written — X rows always have the full pitch (pitch_x) and columns >= ob + acw get zeros.
+template <bool NORM>
+__device__ __forceinline__ void rows_commit_impl(const Lds& L, RowRegs& x, const float* __restrict__ mean,
+                                                 const float* __restrict__ stdv, int ob, int acw) {
+    const int t = opaque_tid();
+    const int r = t >> 4, c0 = t & 15;
+    constexpr int HB = kRowRegs / 2;   // the statistics come in two batches (13 + 13 columns)
+    float* xr = L.X + r * L.px + c0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float m[HB], sd[HB];
+        if (NORM) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int ci = min(c0 + 16 * (h * HB + i), ob - 1);
+                m[i] = mean[ci]; sd[i] = stdv[ci];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int u = h * HB + i, c = c0 + 16 * u;
+            float v = x.v[u];
+            if (NORM) {
+                const float vn = fminf(fmaxf((v - m[i]) / sd[i], -5.f), 5.f);   // computed for every lane
+                v = c < ob ? vn : v;
+            }
+            v = c < ob + acw ? v : 0.f;
+            x.v[u] = v;
+            xr[16 * u] = v;
+        }
+    }
+}
+__device__ __forceinline__ void rows_commit(const Lds& L, RowRegs& x, int k32, const float* __restrict__ mean,
+                                            const float* __restrict__ stdv, int ob, int acw,
+                                            float* __restrict__ hbm, int64_t hrow, int ldh) {
+    if (mean) rows_commit_impl<true>(L, x, mean, stdv, ob, acw);
+    else rows_commit_impl<false>(L, x, mean, stdv, ob, acw);
+    // the HBM copy last: stores count in vmcnt like loads, and a store between two columns would make the
+    // next column's statistics wait for its write acknowledgement
+    if (hbm) {
+        const int c0 = opaque_tid() & 15;
+        float* hr = hbm + hrow * ldh + c0;
+#pragma unroll
+        for (int u = 0; u < kRowRegs; ++u)
+            if (c0 + 16 * u < ob + acw) hr[16 * u] = x.v[u];
+    }
+}
 __device__ __forceinline__ void load_rows(const Lds& L, int k32, const float* __restrict__ obs,
                                           const float* __restrict__ acs, const float* __restrict__ mean,
                                           const float* __restrict__ stdv, int ob, int ac, int acw, int64_t prow,
                                           float* __restrict__ hbm, int64_t hrow, int ldh) {
-    const int r = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    for (int cb = c0; cb < k32; cb += 16 * kRowBatch) {
-        float v[kRowBatch], m[kRowBatch], sd[kRowBatch];
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            const int c = cb + 16 * u;
-            v[u] = 0.f; m[u] = 0.f; sd[u] = 1.f;
-            if (c < ob) {
-                v[u] = obs[prow * ob + c];
-                if (mean) { m[u] = mean[c]; sd[u] = stdv[c]; }
-            } else if (c < ob + acw) {
-                v[u] = acs[prow * ac + (c - ob)];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            const int c = cb + 16 * u;
-            if (c < k32) {
-                float x = v[u];
-                if (mean && c < ob) x = fminf(fmaxf((x - m[u]) / sd[u], -5.f), 5.f);
-                L.X[r * L.px + c] = x;
-                if (hbm && c < ob + acw) hbm[hrow * ldh + c] = x;
-            }
-        }
-    }
+    RowRegs x;
+    rows_issue(x, k32, obs, acs, ob, ac, acw, prow);
+    rows_commit(L, x, k32, mean, stdv, ob, acw, hbm, hrow, ldh);
 }
 
 // actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac);
 // called by all waves
 template <bool CW>
 __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, int ac, float high,
-                                           float* __restrict__ hbm, int64_t row0) {
+                                           float* __restrict__ hbm, int64_t row0, float* slot,
+                                           const HeadStage& hs) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-    stage_head(n.W3, ac, L.ring);
+    stage_head_commit(hs, ac, slot);
     if (CW && 16 * wv < ac) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int jc = min(16 * wv + r, ac - 1);
-        for (int k = 0; k < H; k += 4) acc = mfma4(L.T2[r * LDT + k + kq], L.ring[(k + kq) * ac + jc], acc);
+        f32x4 a4[4];   // four independent chains (a dependent 16x16x4 pair costs 40 cycles), summed at the end
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < H; k += 16)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a4[i] = mfma4(L.T2[r * LDT + k + 4 * i + kq], slot[(k + 4 * i + kq) * ac + jc], a4[i]);
+        const f32x4 acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         const int c = 16 * wv + (lane & 15);
         if (c < ac) {
             const float b = n.b3[c];
@@ -502,15 +591,23 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     WTRACE(wg, 0, 1);
     hidden_fwd<CW>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
     WTRACE(wg, 0, 2);
-    hidden_fwd<CW>(pipe, ta2, ta2, false, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    HeadStage hs;
+    stage_head_issue(hs, a.targ_actor.W3, ac);
+    hidden_fwd<CW>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
     WTRACE(wg, 0, 3);
-    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0);
+    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
     WTRACE(wg, 0, 4);
     hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
     WTRACE(wg, 0, 5);
+    RowRegs x0;   // the online critic's input rows travel while the target critic's second layer runs
+    HeadRegs hd;
+    if (cw) {
+        rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
+        head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
+    }
     hidden_fwd<CW>(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
     WTRACE(wg, 0, 6);
-    if (cw) head1(L.T2, a.targ_critic.W3, a.targ_critic.b3, L.s_);
+    if (cw) head1(L.T2, hd, L.s_);
     bar();
     WTRACE(wg, 0, 7);
     if (cw && tid < R) {
@@ -520,14 +617,17 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         L.tq[tid] = t;
     }
     // ---- online critic on (obz0, acs): forward, loss, backward
-    if (cw) load_rows(L, k32c, a.obs0, a.acs, a.mean, a.stdv, ob, ac, ac, pr, a.Xc, row0 + (tid >> 4), in_c);
+    WTRACE(wg, 0, 14);
+    if (cw) rows_commit(L, x0, k32c, a.mean, a.stdv, ob, ac, a.Xc, row0 + (tid >> 4), in_c);
+    WTRACE(wg, 0, 15);
     bar();
     WTRACE(wg, 0, 8);
     hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, a.A1c, row0);
     WTRACE(wg, 0, 9);
+    if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
     hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, a.A2c, row0);
     WTRACE(wg, 0, 10);
-    if (cw) head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+    if (cw) head1(L.T2, hd, L.s_);
     bar();
     if (cw && tid < R) {
         const float td = L.s_[tid] - L.tq[tid];
@@ -584,13 +684,17 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
     bar();
     const unsigned m1a = hidden_fwd<CW>(pipe, a1, a2, true, L.X, L.px, a.actor.b1, L.ring, L.T1, a.A1a, row0);
-    const unsigned m2a = hidden_fwd<CW>(pipe, a2, a2, false, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
-    actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0);
+    HeadStage hs;
+    stage_head_issue(hs, a.actor.W3, ac);
+    const unsigned m2a = hidden_fwd<CW>(pipe, a2, c1, true, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
+    actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0, free_slot(L.ring, pipe), hs);
     // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
     hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, nullptr, 0);
+    HeadRegs hd;
+    if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
     hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
     if (cw) {
-        head1(L.T2, a.critic.W3, a.critic.b3, L.s_);
+        head1(L.T2, hd, L.s_);
         if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
     }
     bar();
@@ -612,7 +716,8 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     {   // dQ/da = dZ1c W1c[ob:ob+ac, :]^T, through clip (identity inside the range) and tanh
         f32x4 acc[4];
         zero_acc(acc);
-        wprod<CW>(pipe, c4, L.T1, LDT, L.ring, acc);
+        stage_head_issue(hs, a.actor.W3, ac);   // for the backward through the action head below
+        wprod<CW>(pipe, c4, a3, true, L.T1, LDT, L.ring, acc);
         if (cw && wv == 0) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -632,7 +737,8 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
     bar();
     {   // dZ2a = (PRE W3a^T) .* lrelu'(A2a): reduction over the (zero-padded) action index
-        stage_head(a.actor.W3, ac, L.ring);
+        float* slot = free_slot(L.ring, pipe);
+        stage_head_commit(hs, ac, slot);
         const int r = lane & 15, kq = lane >> 4;
         f32x4 acc[4];
         zero_acc(acc);
@@ -642,7 +748,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
                 const float av = L.PRE[r * PP + 4 * kk + kq];
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[nb] = mfma4(av, L.ring[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
+                    acc[nb] = mfma4(av, slot[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
             }
         bar();
         if (cw)
@@ -664,6 +770,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
 }
 
+constexpr int kRowBatch = 13;   // discriminator rows: loads go out in batches of 13 columns per thread
 template <bool CW>
 __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
@@ -756,8 +863,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     if (sect != 2) {
         // ---- policy / expert rows
         hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
+        HeadRegs hd;
+        if (cw) head_issue(hd, n.W3, n.b3);
         hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, a.A2, hrow0);
-        if (cw) head1(L.T2, n.W3, n.b3, L.s_);
+        if (cw) head1(L.T2, hd, L.s_);
         bar();
         if (cw && tid < R) {
             const int64_t g = row0 + tid;
