@@ -204,6 +204,7 @@ def other_configs(comm, device, args):
             ach = flops_per_step(cfg) / dom / 1e12
             o = {'steps_per_s': steps / el, 'ms_per_step': el / steps * 1e3, 'steps': steps, 'warmup': warm,
                  'fused_whole_network_path': bool(drv.fused),
+                 'step_path': 'fused-64' if drv.fused else ('role-fused-256' if drv.wide else 'layer-wise'),
                  'finite_params': all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params)),
                  'roofline': {'bound': 'latency' if drv.fused else 'mfma', 'frac': ach / PEAK_FP32_TFLOPS,
                               'achieved_tflops': ach, 'kernel_us': dom * 1e6,
@@ -315,6 +316,9 @@ def main():
                        'steps_per_graph_launch': drv.K, 'collectives': collectives, 'finite_params': finite},
             'roofline': {'bound': 'latency' if drv.fused else 'mfma',
                          'kernel': ('samx::fused::step_kernel (whole-network fused, all three roles)' if drv.fused
+                                    else ('samx::wide::roles_kernel (the layer chains of every role, one launch) + '
+                                          'samx::gemm_group_kernel (all weight-gradient products, one launch)')
+                                    if drv.wide
                                     else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
                                          'on three streams'),
                          'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',

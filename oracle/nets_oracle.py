@@ -97,8 +97,48 @@ def init_params(d, rs, kind):
     return p
 
 
+class _Kinks(object):
+    """Leaky-ReLU kink bookkeeping for parity tests at size (test infrastructure, like the rest of oracle/).
+    A pre-activation within fp32 rounding distance of 0 gets mask 1 or 0.2 depending on the last bits of an
+    fp32 sum, which no fp64 restatement can predict: at batch 1024 x 512 units x 6 passes a few such units occur
+    in every update.  While `active`, lrelu() numbers its calls, lists the units with |z| < delta as
+    (call, row, unit), and takes the OTHER branch for the units named in `flip` — so a test can ask 'is the
+    difference to the device result exactly the effect of these undecidable units?'."""
+    active = False
+    delta = 2e-6
+    calls = 0
+    near = []
+    flip = frozenset()
+
+
+KINKS = _Kinks
+
+
+def kinks_begin(flip=(), delta=None):
+    """Start bookkeeping for ONE gradient function call (call numbers restart at 0)."""
+    KINKS.active, KINKS.calls, KINKS.near, KINKS.flip = True, 0, [], frozenset(flip)
+    if delta is not None:
+        KINKS.delta = delta
+
+
+def kinks_end():
+    KINKS.active = False
+    return list(KINKS.near)
+
+
 def lrelu(x):
-    return torch.maximum(x, LEAK * x)
+    if not KINKS.active or x.dim() != 2:
+        return torch.maximum(x, LEAK * x)
+    call = KINKS.calls
+    KINKS.calls += 1
+    xd = x.detach()
+    for r, u in (xd.abs() < KINKS.delta).nonzero().tolist():
+        KINKS.near.append((call, r, u))
+    pos = xd >= 0
+    for c, r, u in KINKS.flip:
+        if c == call:
+            pos[r, u] = ~pos[r, u]
+    return torch.where(pos, x, LEAK * x)
 
 
 def layer_norm(x, beta, gamma):

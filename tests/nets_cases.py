@@ -34,6 +34,59 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
 
 
+# ---- per-variable norm (north_star: "gradients ... within 1e-5 relative"): every variable of a network
+# (W1, b1, [beta1, gamma1], W2, b2, [beta2, gamma2], W3, b3) is held to the bar against ITS OWN max-norm, so a
+# small-magnitude variable cannot hide behind a large one.  The observed maxima are collected per test and
+# written out at session end (tests/conftest.py -> gpurun_out/parity_margins.json; the kept copy lives in
+# profiles/).
+MARGINS = {}
+
+
+def record_margin(tag, var, value):
+    key = '%s/%s' % (tag, var)
+    MARGINS[key] = max(MARGINS.get(key, 0.0), float(value))
+
+
+def per_var_relerr(got, exp, desc):
+    """name -> max|got - exp| / max|exp| over that variable of the flat vector of network `desc`."""
+    got, exp = np.asarray(got, dtype=np.float64).ravel(), np.asarray(exp, dtype=np.float64).ravel()
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    out = {}
+    for name, (off, shape) in NO.param_slices(desc).items():
+        n = int(np.prod(shape))
+        out[name] = relerr(got[off:off + n], exp[off:off + n])
+    return out
+
+
+def assert_per_var(got, exp, desc, tol, tag, abs_tol=0.0):
+    """Assert every variable within tol of the oracle (max|got - exp| <= tol * max|exp| + abs_tol); a variable
+    that is identically zero in the oracle (e.g. nothing flows into it) must be zero to tol in absolute terms
+    (relerr's denominator falls back to 1).  abs_tol: see adam_allowance."""
+    got, exp = np.asarray(got, dtype=np.float64).ravel(), np.asarray(exp, dtype=np.float64).ravel()
+    errs = per_var_relerr(got, exp, desc)
+    bad = {}
+    for name, (off, shape) in NO.param_slices(desc).items():
+        n = int(np.prod(shape))
+        record_margin(tag, name, errs[name])
+        den = np.max(np.abs(exp[off:off + n]))
+        if not np.max(np.abs(got[off:off + n] - exp[off:off + n])) <= tol * (den if den > 0 else 1.0) + abs_tol:
+            bad[name] = errs[name]
+    assert not bad, '%s: per-variable error beyond %g relative (+ %g absolute): %r (all: %r)' % (
+        tag, tol, abs_tol, bad, errs)
+    return errs
+
+
+def adam_allowance(K, lr, frac=0.01):
+    """Absolute allowance for WEIGHTS after K Adam steps.  Adam's step lr * m / (sqrt(v) + eps) normalises every
+    element to O(lr) whatever its gradient's size, so an element whose gradient is far below its variable's max
+    (or within reach of eps = 1e-8) turns the fp32-vs-fp64 rounding difference of that gradient — 1e-6 of the
+    VARIABLE's max, i.e. possibly 100 % of the element — into a fraction of lr.  Zero-initialised biases and the
+    U(+-3e-3) heads are all displacement after a few steps, so their own max-norm is K * lr itself.  Gradients,
+    the well-conditioned quantity, are held to the plain per-variable bar at every step; weights get this
+    allowance of `frac` (1 %) of the largest displacement K steps can produce."""
+    return frac * K * lr
+
+
 KINK_MARGIN = 1e-4
 
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.nets_cases import relerr
+from tests.nets_cases import adam_allowance, assert_per_var, per_var_relerr, record_margin, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,12 @@ class OracleLearner(object):
         self.rms_d = d.obs_rms.sums.cpu().numpy().copy()
         self.hps = mu.hps
         self.per = per
+        self.last_g = {}   # the unclipped gradients of the last update, per optimiser
+        # Undecidable leaky-ReLU units (nets_oracle.KINKS): gpu_g = the device's unclipped gradients of the update
+        # being mirrored (set by the caller before step(); None = no accounting)
+        self.gpu_g = None
+        self.near_units = 0          # units met within KINKS.delta of the kink
+        self.flipped_units = 0       # of those, the ones the device decided the other way
         self.ret_sums = mu.ret_rms.sums.cpu().numpy().copy() if mu.hps.rmsify_rets else None
         if mu.hps.n_step_returns:  # a ring view for the lookahead (memory.py:113-160)
             from oracle.replay_oracle import ReplayOracle
@@ -53,6 +59,39 @@ class OracleLearner(object):
             for r in self.rb.rings.values():
                 r.length = rb.length; r.start = rb.start
             self.rb.max_priority = rb.max_priority
+
+    def with_kinks(self, key, fn, desc, tol=1e-5):
+        """fn() -> (losses, flat grad, ...) of one optimiser's gradient function.  With the device's gradient at
+        hand: if the two differ beyond tol in some variable AND the pass met units within fp32 rounding distance
+        of the lrelu kink, the difference must be exactly the effect of taking the other branch at some of those
+        units (least squares over the units' individual effects: every coefficient 0 or 1); the oracle then
+        follows the device's decision, so that its state stays comparable.  Anything else is left for the
+        caller's per-variable assertion to report."""
+        NO = self.NO
+        if self.gpu_g is None or key not in self.gpu_g:
+            return fn()
+        NO.kinks_begin()
+        out = fn()
+        near = NO.kinks_end()
+        self.near_units += len(near)
+        gpu, g = np.asarray(self.gpu_g[key], dtype=np.float64), out[1]
+        ok = lambda a, b: all(v < tol for v in per_var_relerr(a, b, desc).values())
+        if not near or len(near) > 16 or ok(gpu, g):
+            return out
+        deltas = []
+        for u in near:
+            NO.kinks_begin(flip=[u])
+            deltas.append(fn()[1] - g)
+            NO.kinks_end()
+        coef = np.linalg.lstsq(np.stack(deltas, axis=1), gpu - g, rcond=None)[0]
+        if not all(min(abs(c), abs(c - 1.0)) < 0.05 for c in coef):
+            return out   # not explained by whole flips: the caller's assertion fails with the plain gradient
+        flips = [u for u, c in zip(near, coef) if c > 0.5]
+        NO.kinks_begin(flip=flips)
+        out = fn()
+        NO.kinks_end()
+        self.flipped_units += len(flips)
+        return out
 
     def rows(self, idxs):
         phys = (self.start + idxs) % self.limit
@@ -81,8 +120,10 @@ class OracleLearner(object):
         for _ in range(self.world):  # every rank contributes its rows (here: identical replicas)
             self.rms_d = NO.rms_update(self.rms_d, np.concatenate((p['obs0'], e_obs)), ob)
         mean, std = NO.rms_mean_std(self.rms_d, ob)
-        dl, g = NO.disc_loss_grad(self.pd, self.dc, p['obs0'], p['acs'], e_obs, e_acs, eps_ob, eps_ac,
-                                  real, np.zeros(len(real)), mean, std)
+        dl, g = self.with_kinks('d', lambda: NO.disc_loss_grad(
+            self.pd, self.dc, p['obs0'], p['acs'], e_obs, e_acs, eps_ob, eps_ac, real, np.zeros(len(real)), mean,
+            std), self.dc)
+        self.last_g['d'] = g
         self.pd = self.adam('d', self.pd, g, hp.d_lr)
         return dl
 
@@ -123,11 +164,13 @@ class OracleLearner(object):
                 p[ow:ow + h2], p[ob3:ob3 + 1] = NO.popart(p[ow:ow + h2], p[ob3:ob3 + 1], ret[0], ret[1], *new)
                 setattr(self, name, p)
             ret = new
-        al, ga = NO.actor_loss_grad(self.pa, self.da, self.pc, self.dc, None, None, b['obs0'], mean, std,
-                                    1.0, hp.q_actor_loss_scale, 0.0, ret=ret)
-        cl, gc, _ = NO.critic_loss_grad(self.pc, self.dc, b['obs0'], b['acs'], iws, tq, mean, std,
-                                        hp.wd_scale, hp.td_loss_1_scale, ret=ret, tcns=tqn,
-                                        tdn_scale=hp.td_loss_n_scale)
+        al, ga = self.with_kinks('a', lambda: NO.actor_loss_grad(
+            self.pa, self.da, self.pc, self.dc, None, None, b['obs0'], mean, std, 1.0, hp.q_actor_loss_scale, 0.0,
+            ret=ret), self.da)
+        cl, gc, _ = self.with_kinks('c', lambda: NO.critic_loss_grad(
+            self.pc, self.dc, b['obs0'], b['acs'], iws, tq, mean, std, hp.wd_scale, hp.td_loss_1_scale, ret=ret,
+            tcns=tqn, tdn_scale=hp.td_loss_n_scale), self.dc)
+        self.last_g['a'], self.last_g['c'] = ga, gc
         self.pa = self.adam('a', self.pa, ga, hp.actor_lr)
         self.pc = self.adam('c', self.pc, gc, hp.critic_lr)
         if self.per:
@@ -142,10 +185,28 @@ class OracleLearner(object):
         return dict(actor_losses=al, critic_losses=cl, idx_a=idx_a)
 
 
+def _assert_weights(mu, d, ref, K, tag, nets=('actor', 'critic', 'targ_actor', 'targ_critic', 'reward')):
+    """Post-update weights, every variable against its own max-norm (+ the Adam allowance of nets_cases)."""
+    hp = mu.hps if mu is not None else d.hps
+    al = lambda lr, f=1.0: adam_allowance(K, lr) * f
+    if 'actor' in nets:
+        assert_per_var(mu.actor.get_flat(), ref.pa, ref.da, 1e-5, tag + '/actor', al(hp.actor_lr))
+    if 'critic' in nets:
+        assert_per_var(mu.critic.get_flat(), ref.pc, ref.dc, 1e-5, tag + '/critic', al(hp.critic_lr))
+    if 'targ_actor' in nets:
+        assert_per_var(mu.targ_actor.get_flat(), ref.pa_t, ref.da, 1e-5, tag + '/targ_actor',
+                       al(hp.actor_lr, hp.polyak * K))
+    if 'targ_critic' in nets:
+        assert_per_var(mu.targ_critic.get_flat(), ref.pc_t, ref.dc, 1e-5, tag + '/targ_critic',
+                       al(hp.critic_lr, hp.polyak * K))
+    if 'reward' in nets:
+        assert_per_var(d.reward_nn.get_flat(), ref.pd, ref.dc, 1e-5, tag + '/reward', al(d.hps.d_lr))
+
+
 @pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
                                       'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper', 'ragged-launcher',
-                                      'raggedper-ret'])
+                                      'raggedper-ret', 'C4'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
@@ -176,7 +237,11 @@ def test_k_steps_match_oracle(cfg_name, graph):
         assert drv.fused   # LayerNorm included: whole-network kernels of fused_ln.hip
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
-    K = 6
+    # C4: the Humanoid-shaped configuration at its full batch (1024 rows, 256x256 nets) through the real driver
+    # (captured graph, role-fused 256-wide kernels, two-stage D-input sums of the launch head)
+    K = 3 if base == 'C4' else 6
+    if base == 'C4':
+        assert drv.wide and drv.inline_stats and not drv.sums_small
     worst_td = 0.0
     for k in range(K):
         drv.step()
@@ -184,10 +249,21 @@ def test_k_steps_match_oracle(cfg_name, graph):
         h = lambda t: t.cpu().numpy()
         e0 = int(drv.e_start.item())
         eps_ob, eps_ac, real, _ = drv.step_randoms(k)   # what the kernels drew for update k
+        # The driver samples its own rows, so the row redraw of nets_cases.keep_off_the_kink is not available
+        # here; at full size every update meets units within fp32 rounding distance of the lrelu kink.  The
+        # oracle is told the device's gradients and accounts for those units one by one (with_kinks).
+        ref.gpu_g = {key: h(drv.L.seg(drv.L.grads, seg)) for seg, key in enumerate('acd')}
         out = ref.step(h(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
                        h(eps_ac), h(real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
         if cfg['per']:
             assert np.array_equal(out['idx_a'], h(drv.idx_a)), 'PER indices differ at step %d' % k
+        # the unclipped gradients of THIS update, every variable against its own max-norm
+        gtag = 'k_steps/%s%s/grads' % (cfg_name, '-graph' if graph else '')
+        # (rmsify_rets: the mixed-scale TD error q * std + mean - target cancels O(1) terms; the critic's b3
+        # gradient is ONE number, the signed sum of those errors over the batch — it gets 1e-4)
+        gtol = 1e-4 if cfg['ret'] else 1e-5
+        for seg, (key, desc) in enumerate((('a', ref.da), ('c', ref.dc), ('d', ref.dc))):
+            assert_per_var(h(drv.L.seg(drv.L.grads, seg)), ref.last_g[key], desc, gtol, '%s_%s' % (gtag, key))
         o = drv.outputs()
         # With return normalisation the actor loss is -mean(Q*std + mean): O(1) terms that nearly
         # cancel at initialisation, so its error is measured against the terms' scale, not the remainder
@@ -198,12 +274,12 @@ def test_k_steps_match_oracle(cfg_name, graph):
                 assert got.shape == (4,)
             assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), floor if name == 'actor_losses' else 1e-3)) \
                 < 1e-5, (name, k, got, exp)
-    # post-update weights after K steps
-    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
-    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
-    assert relerr(mu.targ_actor.get_flat(), ref.pa_t) < 1e-5
-    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
-    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    # post-update weights after K steps: every variable against its own max-norm
+    tag = 'k_steps/%s%s' % (cfg_name, '-graph' if graph else '')
+    record_margin(tag, 'units_within_2e-6_of_the_kink', ref.near_units)
+    record_margin(tag, 'units_decided_the_other_way_on_the_device', ref.flipped_units)
+    assert ref.flipped_units <= max(2, ref.near_units // 2), (ref.flipped_units, ref.near_units)
+    _assert_weights(mu, d, ref, K, tag)
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
     if cfg['ret']:
         assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
@@ -214,8 +290,9 @@ def test_k_steps_match_oracle(cfg_name, graph):
         # (or a pre-activation at the lrelu kink) flips with the last fp32 bit, which the mixed-scale
         # TD error of rmsify_rets amplifies: parameters stay < 1e-6 off, the moments get 3e-5
         mtol = 3e-5 if cfg['ret'] else 1e-5
-        assert relerr(opt.m.cpu().numpy(), ref.opt[key][0]) < mtol
-        assert relerr(opt.v.cpu().numpy(), ref.opt[key][1]) < 2 * mtol
+        desc = ref.da if key == 'a' else ref.dc
+        assert_per_var(opt.m.cpu().numpy(), ref.opt[key][0], desc, mtol, tag + '/adam_m_' + key)
+        assert_per_var(opt.v.cpu().numpy(), ref.opt[key][1], desc, 2 * mtol, tag + '/adam_v_' + key)
     if cfg['per']:
         assert mu.replay_buffer.max_priority == ref.rb.max_priority
         assert np.array_equal(mu.replay_buffer.tree_values('sum'), ref.rb.sum_tree.v)
@@ -391,10 +468,8 @@ def test_training_step_schedule_matches_oracle(cfg_name, d_steps, g_steps):
                 continue
             got, exp = h(o[name]).astype(np.float64), out[name]
             assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-5, (name, row, got, exp)
-    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
-    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
-    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
-    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    _assert_weights(mu, d, ref, 2 * drv.S, 'training_step/%s-d%d-g%d' % (cfg_name, d_steps, g_steps),
+                    nets=('actor', 'critic', 'targ_critic', 'reward'))
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
     if cfg['per']:
         assert np.array_equal(mu.replay_buffer.tree_values('sum'), ref.rb.sum_tree.v)
@@ -575,10 +650,7 @@ def test_two_rank_plan_matches_oracle(cfg_name):
             got, exp = h(o[name]).astype(np.float64), out[name]
             floor = 1.0 if opt and name == 'actor_losses' else 1e-3   # see test_k_steps_match_oracle
             assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), floor)) < 1e-5, (name, k, got, exp)
-    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
-    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
-    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
-    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    _assert_weights(mu, d, ref, K, 'two_rank/%s' % cfg_name, nets=('actor', 'critic', 'targ_critic', 'reward'))
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
     if opt:
         assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
@@ -791,10 +863,8 @@ def test_agent_train_matches_oracle(cfg_name, world):
             assert np.max(np.abs(got - want) / np.maximum(np.abs(want), floor if name == 'actor_losses' else 1e-3)) \
                 < 1e-5, (name, k, got, want)
         assert np.linalg.norm(out['actor_grads']) <= mu.hps.clip_norm * (1 + 1e-5)
-    assert relerr(mu.actor.get_flat(), ref.pa) < 1e-5
-    assert relerr(mu.critic.get_flat(), ref.pc) < 1e-5
-    assert relerr(mu.targ_actor.get_flat(), ref.pa_t) < 1e-5
-    assert relerr(mu.targ_critic.get_flat(), ref.pc_t) < 1e-5
+    _assert_weights(mu, d, ref, 3, 'agent_train/%s-w%d' % (cfg_name, world),
+                    nets=('actor', 'critic', 'targ_actor', 'targ_critic'))
     if opt:
         assert relerr(mu.ret_rms.sums.cpu().numpy(), ref.ret_sums) < 1e-6
 
@@ -828,6 +898,6 @@ def test_discriminator_feed_path_matches_oracle(cfg_name, world):
         eps_ob, eps_ac, real, fake = d.draw_randoms(B)
         assert fake is None
         ref.d_step(idx, e_obs, e_acs, h(eps_ob), h(eps_ac), h(real) if real is not None else np.ones(B))
-    assert relerr(d.reward_nn.get_flat(), ref.pd) < 1e-5
+    _assert_weights(None, d, ref, 3, 'd_feed/%s-w%d' % (cfg_name, world), nets=('reward',))
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
-    assert relerr(d.optimizer.m.cpu().numpy(), ref.opt['d'][0]) < 1e-5
+    assert_per_var(d.optimizer.m.cpu().numpy(), ref.opt['d'][0], ref.dc, 1e-5, 'd_feed/%s-w%d/adam_m' % (cfg_name, world))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.nets_cases import make_case, relerr
+from tests.nets_cases import assert_per_var, make_case, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -65,6 +65,7 @@ def _oracle(c, d_scale, ent, per, rms=True):
     ('C2', 0.5, 0.0, False, False, False),
     ('ragged', 0.5, 0.0, True, True, False),   # 33x70 nets, B = 37: not fusable -> layer-wise fallback
     ('C4', 0.0, 0.0, False, True, False),
+    ('C5', 0.0, 1e-3, True, True, False),      # 400x300 nets, batch 8192: the layer-wise path at size
     ('w_20x3', 0.0, 0.0, False, True, False), ('w_40x32', 0.0, 1e-3, True, True, False),
     ('w_7x17', 0.0, 0.0, True, False, False), ('w_20x3', 0.5, 0.0, True, True, False),
     # with_layernorm (launcher default, mujoco_sam_imitate.sh): two-stream GP backward; 64x64 nets on the
@@ -90,9 +91,66 @@ def test_step_grads_vs_oracle(name, d_scale, ent, per, rms, ln):
     assert relerr(out.t['targ_q'].cpu().numpy(), exp['targ_q']) < TOL
     assert relerr(out.t['td'].cpu().numpy(), exp['td']) < TOL
     g = L.grads.cpu().numpy()
-    for k in range(3):
-        assert relerr(L.seg(torch.as_tensor(g), k).numpy(), L.seg(torch.as_tensor(exp['grads']), k).numpy()) < TOL, k
+    tag = 'step_grads/%s%s%s' % (name, '-ln' if ln else '', '-dscale' if d_scale else '')
+    for k, (net, desc) in enumerate((('actor', c['da']), ('critic', c['dc']), ('reward', c['dd']))):
+        # every variable of every network against its own max-norm
+        assert_per_var(L.seg(torch.as_tensor(g), k).numpy(), L.seg(torch.as_tensor(exp['grads']), k).numpy(), desc,
+                       TOL, '%s/%s' % (tag, net))
     assert L.steps.tolist() == [1, 1, 1]
+
+
+@pytest.mark.parametrize('name', ['C2', 'C4', 'C3'])
+def test_masks_without_kink_redraw(name):
+    """The other parity cases redraw rows whose pre-activations come within 1e-4 of the leaky-ReLU kink
+    (nets_cases.keep_off_the_kink).  Here nothing is redrawn.  The importance weights of the ABI select ONE
+    row of the critic's batch (iws one-hot), so the step kernels return that row's own gradient; it is compared
+    with the fp64 oracle's for every row within the margin of the kink and for a sample of the others.  A row
+    whose gradient differs is a row whose lrelu mask differs from the oracle's: allowed only among the
+    near-kink rows, and only for a handful (|z| below fp32 rounding, expected 0-1 per batch)."""
+    from oracle import nets_oracle as NO
+    from sam_tf_amd import ops
+    c = make_case(name, off_kink=False)
+    P, D, B = c['P'], c['D'], c['B']
+    t64 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    ob0 = NO.obz(t64(D['obs0']), t64(c['mean']), t64(c['std'])).numpy()
+    margin = NO.min_abs_preact(P['pc'], c['dc'], np.concatenate([ob0, D['acs']], axis=1))
+    near = np.where(margin < 1e-4)[0]
+    rs = np.random.RandomState(5)
+    far = rs.choice(np.where(margin >= 1e-4)[0], size=6, replace=False)
+    assert near.size <= B // 8, 'case has implausibly many near-kink rows: %d' % near.size
+    mk = lambda d: ops.mlp_desc(d.in_dim, d.h1, d.h2, d.out_dim, d.layernorm)
+    L = ops.LearnerState(mk(c['da']), mk(c['dc']), mk(c['dd']), c['ob'], c['ac'], dict(HP, wd_scale=0.0))
+    L.params.copy_(_dev(np.concatenate([P['pa'], P['pc'], P['pd']])))
+    L.targets.copy_(_dev(np.concatenate([P['pa_t'], P['pc_t']])))
+    for k in ('mu_mean', 'd_mean'):
+        L.set_ptr(k, _dev(c['mean']))
+    for k in ('mu_std', 'd_std'):
+        L.set_ptr(k, _dev(c['std']))
+    iws = torch.zeros(B, dtype=torch.float32, device='cuda')
+    batch = ops.make_batch(B, p_obs=_dev(D['obs0']), p_acs=_dev(D['acs']), e_obs=_dev(D['e_obs']),
+                           e_acs=_dev(D['e_acs']), eps_ob=_dev(D['eps_ob']), eps_ac=_dev(D['eps_ac']),
+                           real_labels=_dev(D['real']), fake_labels=_dev(D['fake']), obs0=_dev(D['obs0']),
+                           acs=_dev(D['acs']), rews=_dev(D['rews']), dones1=_dev(D['dones1']),
+                           obs1=_dev(D['obs1']), iws=iws)
+    out = ops.make_step_out(B)
+    tq = NO.targ_q(P['pa_t'], P['pc_t'], c['da'], c['dc'], D['obs1'], D['rews'][:, None], D['dones1'][:, None],
+                   np.ones((B, 1)), c['mean'], c['std'], 0.99, 0.4)
+    differs = []
+    for r in list(near) + list(far):
+        iws.zero_()
+        iws[r] = 1.0
+        ops.step_grads(L, batch, out)
+        torch.cuda.synchronize()
+        got = L.seg(L.grads, 1).cpu().numpy()
+        w = np.zeros((B, 1), dtype=np.float32); w[r] = 1.0
+        _, exp, _ = NO.critic_loss_grad(P['pc'], c['dc'], D['obs0'], D['acs'], w, tq, c['mean'], c['std'], 0.0)
+        if relerr(got, exp) >= 1e-5:
+            differs.append(int(r))
+    assert not set(differs) & set(int(r) for r in far), 'rows away from the kink differ: %r' % differs
+    assert len(differs) <= 3, 'near-kink rows with a different mask: %r of %d candidates' % (differs, near.size)
+    from tests.nets_cases import record_margin
+    record_margin('masks_without_redraw/%s' % name, 'near_kink_rows', near.size)
+    record_margin('masks_without_redraw/%s' % name, 'rows_with_other_mask', len(differs))
 
 
 @pytest.mark.parametrize('world', [1, 4])
@@ -152,9 +210,9 @@ def test_fused_matches_layerwise(ln):
 def test_indirect_rows_and_kernel_randoms_match_dense():
     """samx_step_grads reading rows in place through ring indices / the expert slice and drawing its
     own D randoms == the same call on gathered rows with the materialised randoms (bit for bit on
-    the fused path, to rounding on the layer-wise path)."""
+    the fused paths, to rounding on the layer-wise path)."""
     from sam_tf_amd import ops
-    for name in ('C2', 'ragged'):
+    for name in ('C2', 'ragged', 'w_20x3', 'C4'):   # fused 64-wide, layer-wise, role-fused 256-wide (two sizes)
         c, L, dense, out = _setup(name, 0.0, 0.0, True)
         B, ob, ac = c['B'], c['ob'], c['ac']
         rs = np.random.RandomState(5)
@@ -186,8 +244,8 @@ def test_indirect_rows_and_kernel_randoms_match_dense():
                              rews=rows(st['rews'], idx_a).view(-1), dones1=rows(st['dones1'], idx_a).view(-1),
                              obs1=rows(st['obs1'], idx_a), iws=iws)
         ops.step_grads(L, den, out)
-        if name == 'C2':
-            assert torch.equal(g_ind, L.grads)
+        if name != 'ragged':
+            assert torch.equal(g_ind, L.grads), name
             for k in l_ind:
                 assert torch.equal(l_ind[k], out.t[k]), k
         else:
