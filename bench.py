@@ -69,7 +69,8 @@ def build_learner(cfg, comm, device, seed, use_graph):
                    prioritized_replay=cfg['per'], seed=seed,
                    with_layernorm=bool(cfg.get('ln', False)),
                    rmsify_rets=bool(cfg.get('ret', False)), enable_popart=bool(cfg.get('ret', False)),
-                   n_step_returns=bool(cfg.get('nstep', 0)), n=int(cfg.get('nstep', 0)) or 96)
+                   n_step_returns=bool(cfg.get('nstep', 0)), n=int(cfg.get('nstep', 0)) or 96,
+                   **cfg.get('hps', {}))
     d = Discriminator('d', env, hps, comm, device=device)
     mu = SAMAgent('mu', comm, env, hps, d, device=device)
     # synthetic transitions: obs ~ N(0,1), acs ~ U(-1,1), rews ~ U(0,5),
@@ -99,7 +100,8 @@ def build_learner(cfg, comm, device, seed, use_graph):
             idx = rs.randint(0, rb.num_entries, size=cfg['B'])
             rb.update_priorities(idx, np.abs(rs.randn(cfg['B'])) + 1e-6)
     drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph, d_steps=int(cfg.get('d_steps', 1)),
-                           g_steps=int(cfg.get('g_steps', 1)))
+                           g_steps=int(cfg.get('g_steps', 1)), window=cfg.get('window'),
+                           pn_adapt_frequency=cfg.get('pn_adapt_frequency'))
     return mu, d, pool, drv
 
 

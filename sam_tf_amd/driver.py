@@ -25,6 +25,18 @@ carry a D and an agent update side by side, then agent-only rows.  The two updat
 parameters (d_actor_loss_scale = 0, or an untied reward-net copy), so this is the reference's
 "all D updates, then all agent updates" with every update sequence in its own order; the host RNG draws
 keep the reference's order.  `step()` / `run(n)` count rows.
+
+The other things the reference's training step does between updates (sam.py:330-367,408-415):
+  * `window`: every d_step first trains D on pairs from the most recent `window` transitions
+    (RB.sample_recent, np.random.choice), then on uniform pairs — two D rows per d_step, the first with its
+    index words drawn the way np.random.choice draws them (randint over the window, mapped to ring offsets);
+  * adaptive parameter noise: every `pn_adapt_frequency` training steps mu.adapt_param_noise(comm) runs after
+    the D updates and before the agent updates.  It reads the actor as it is BEFORE that training step's
+    agent updates and nothing the D updates write, so it is executed at the head of the launch that starts that
+    training step, with its replay draw placed between the D draws and the agent draws of the step (host RNG
+    order kept); such a training step is always the first of its launch;
+  * a reward net TIED to the actor loss (d_actor_loss_scale != 0, tie_actor_reward_net): the agent update reads
+    the D update of the same training step, so no row carries both: all D rows, then all agent rows.
 """
 import random as _random
 
@@ -62,17 +74,25 @@ class UpdateStepDriver(object):
 
     D, A = 1, 2   # role bits of a row
 
-    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16, d_steps=1, g_steps=1):
+    def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16, d_steps=1, g_steps=1,
+                 window=None, pn_adapt_frequency=None):
         self.mu, self.d, self.pool = mu, d, expert_pool
         assert d_steps >= 1 and g_steps >= 1
-        if mu.hps.d_actor_loss_scale != 0 and mu.hps.tie_actor_reward_net:
-            raise NotImplementedError('a reward net shared between the discriminator and the actor loss makes '
-                                      'the agent update read the discriminator update of the same step: '
-                                      'use SAMAgent.train() / Discriminator.optimize() in sequence')
-        both = min(d_steps, g_steps)
+        self.window = None if window is None else int(window)
+        assert self.window is None or self.window > mu.hps.batch_size, "must have window > batch_size"  # sam.py:334
+        # the D updates of a training step, in order: per d_step [recent-window pairs,] uniform pairs
+        self.dseq = (['w', 'u'] if self.window is not None else ['u']) * int(d_steps)
+        self.nD = len(self.dseq)
+        tied = mu.hps.d_actor_loss_scale != 0 and mu.hps.tie_actor_reward_net
+        both = 0 if tied else min(self.nD, g_steps)   # tied: the agent update reads this step's D updates
         self.d_steps, self.g_steps = int(d_steps), int(g_steps)
-        self.sched = [self.D] * (d_steps - both) + [self.D | self.A] * both + [self.A] * (g_steps - both)
+        self.sched = [self.D] * (self.nD - both) + [self.D | self.A] * both + [self.A] * (g_steps - both)
         self.S = len(self.sched)
+        # adaptive parameter noise (sam.py:408-415): due when train_step_in_iter % frequency == 0
+        self.pn_freq = int(pn_adapt_frequency) if (pn_adapt_frequency and mu.param_noise is not None) else 0
+        self.train_step_in_iter = 0   # the reference's `training_step` (start_iteration() resets it)
+        self.pn_log = []              # (pn_dist, pn_cur_std) per adaption, what sam.py:412-415 appends
+        self._cache = None            # the host draws of the training step in progress (_draw_training_step)
         self.L = mu.L
         self.comm = mu.comm
         self.world = self.comm.Get_size()
@@ -415,31 +435,60 @@ class UpdateStepDriver(object):
         slot.np_e[k] = self.pool.pointer
         self.pool.pointer += self.B
 
-    def _draw_rng(self, slot, K, phase):
+    def _draw_training_step(self, t_index):
+        """Every host draw of ONE training step, in the reference's order: per D update the policy pairs
+        (sam.py:372-377 -> memory.py:90; recent-window pairs: memory.py:95-111) and the expert batch
+        (np.random.shuffle when the pool wraps, demo_dataset.py:33-40); the parameter-noise adaption with its own
+        replay batch when due (sam.py:408-415); then the agent updates' batches (memory.py:90, or memory.py:278
+        with `random` for PER).  Rows consume them as they are launched."""
+        rb = self.mu.replay_buffer
+        B, N = self.B, rb.num_entries
+        c = {'d': [], 'a': []}
+        for kind in self.dseq:
+            idx = self._d_indices(kind, N)
+            if self.pool.pointer + B >= self.pool.num_entries:
+                self.pool.init_pointer()
+            c['d'].append((idx, self.pool.pointer))
+            self.pool.pointer += B
+        if self.pn_freq and t_index % self.pn_freq == 0:
+            self._adapt_param_noise()
+        for _ in range(self.g_steps):
+            c['a'].append(rb.draw_uniforms(B) if self.per else np.random.randint(low=0, high=N, size=B))
+        return c
+
+    def _draw_rng(self, slot, K, phase, t_index=None):
         rb = self.mu.replay_buffer
         B, N = self.B, rb.num_entries
         roles = self._roles(K, phase)
-        if K == 1:
-            # one row, drawn in the reference's order inside a step: D's policy pairs (sam.py:372-377 ->
-            # memory.py:90), the expert batch (np.random.shuffle when the pool wraps), then the agent's
-            # batch in mu.train() (memory.py:90, or memory.py:278 with `random` for PER)
-            slot.np_e[0] = 0
-            if roles[0] & self.D:
-                slot.np_idx_p[0] = np.random.randint(low=0, high=N, size=B)
-                self._expert_rows(slot, 0)
-            else:
-                slot.np_idx_p[0] = 0
-            if roles[0] & self.A:
-                if self.per:
-                    slot.np_u[0] = rb.draw_uniforms(B)                             # memory.py:278
-                else:
-                    slot.np_idx_a[0] = np.random.randint(low=0, high=N, size=B)
+        t_index = self.train_step_in_iter if t_index is None else t_index
+        T = (phase + K + self.S - 1) // self.S
+        plain = self.window is None and not (self.pn_freq and any((t_index + t) % self.pn_freq == 0
+                                                                 for t in range(T)))
+        if K == 1 or not plain or self.per:
+            assert K == 1 or phase == 0
+            ptr0 = self.pool.pointer
+            for k in range(K):
+                pos = (phase + k) % self.S
+                if pos == 0 or self._cache is None:
+                    self._cache = self._draw_training_step(t_index)
+                    t_index += 1
+                slot.np_e[k] = 0
+                slot.np_idx_p[k] = 0
+                if roles[k] & self.D:
+                    slot.np_idx_p[k], slot.np_e[k] = self._cache['d'].pop(0)
+                if roles[k] & self.A:
+                    if self.per:
+                        slot.np_u[k] = self._cache['a'].pop(0)
+                    else:
+                        slot.np_idx_a[k] = self._cache['a'].pop(0)
+            assert K == 1 or self.pool.pointer >= ptr0, \
+                "a reshuffle of the expert pool cannot fall inside a multi-row launch"
             return
         # whole training steps, no reshuffle inside (run() guarantees it) and uniform replay: per training
         # step the reference draws d_steps D batches, then g_steps agent batches, all from np.random —
         # one call of that total size consumes the generator exactly like the separate calls
         assert phase == 0 and K % self.S == 0 and not self.per
-        T, d, g = K // self.S, self.d_steps, self.g_steps
+        T, d, g = K // self.S, self.nD, self.g_steps
         draws = np.random.randint(low=0, high=N, size=(T, d + g, B))
         if self.S == 1:   # one D + agent row per training step: the draws ARE the rows' index words
             slot.np_idx[:K] = draws
@@ -461,6 +510,32 @@ class UpdateStepDriver(object):
                     slot.np_idx_a[k] = draws[t, d + na]
                     na += 1
                 k += 1
+
+    # ---- the D updates' index source, the parameter-noise adaption
+    def _d_indices(self, kind, N):
+        if kind == 'u':
+            return np.random.randint(low=0, high=N, size=self.B)
+        # RB.sample_recent (memory.py:95-111): np.random.choice(idxs, size) = idxs[randint(0, len(idxs), size)]
+        rb = self.mu.replay_buffer
+        width = self.window if self.window <= N else N
+        idxs = (rb.latest_entry_idx - np.arange(start=width - 1, stop=-1, step=-1) + rb.limit) % rb.limit
+        return idxs.astype(np.int64)[np.random.randint(0, width, size=self.B)]
+
+    def _pn_due(self, t_ahead):
+        """Is the adaption due in the training step t_ahead steps after the one the next row belongs to?"""
+        return bool(self.pn_freq) and (self.train_step_in_iter + t_ahead) % self.pn_freq == 0
+
+    def _adapt_param_noise(self):
+        """mu.adapt_param_noise at its place in the host RNG order (sam.py:408-415).  The device work is
+        stream-ordered behind every earlier launch and ahead of the launch being drawn."""
+        self.flush()   # the replay trees as the previous agent update left them (PER sampling reads them)
+        self.mu.adapt_param_noise(self.comm)
+        self.pn_log.append((self.mu.pn_dist, self.mu.pn_cur_std))
+
+    def start_iteration(self):
+        """The reference restarts `training_step` at 0 in every iteration (sam.py:323)."""
+        assert self.step_no % self.S == 0, "an iteration starts at a training-step boundary"
+        self.train_step_in_iter = 0
 
     def _noop_update(self):
         """A priority update that changes nothing (leaf 0 rewritten with its own value): what the
@@ -573,12 +648,17 @@ class UpdateStepDriver(object):
             if refresh and not self.per_graph_io:
                 self._td_host.copy_(self.td_post, non_blocking=True)
                 self._idx_host.copy_(self.idx_a, non_blocking=True)
-            if more:  # the next row's host RNG draws do not depend on this row: make them now,
-                      # while the GPU works (same generators, same order)
+            # the next row's host RNG draws do not depend on this row: make them now, while the GPU works
+            # (same generators, same order) — unless a parameter-noise adaption (device work that must see
+            # this row's update) comes with them
+            nphase = (phase + 1) % self.S
+            t_next = self.train_step_in_iter + (phase + 1) // self.S
+            adapt_next = bool(self.pn_freq) and nphase == 0 and t_next % self.pn_freq == 0
+            if more and not adapt_next:
                 nxt = self.slots[(self.launch_no + 1) % len(self.slots)]
                 if nxt.used:
                     nxt.event.synchronize()
-                self._draw_rng(nxt, 1, (phase + 1) % self.S)
+                self._draw_rng(nxt, 1, nphase, t_next)
                 nxt.predrawn = True
             if refresh:
                 torch.cuda.current_stream().synchronize()
@@ -589,6 +669,7 @@ class UpdateStepDriver(object):
                 self._pending = (idxs, leaf)
         self.step_no += K
         self.launch_no += 1
+        self.train_step_in_iter += (phase + K) // self.S
 
     def step(self):
         """One row (with d_steps = g_steps = 1: one update step); the replay trees are up to date when
@@ -605,7 +686,8 @@ class UpdateStepDriver(object):
             # the next reshuffle of the expert pool (host work between two rows, kept out of a launch)
             K = self.K if self.step_no % S == 0 else 1
             while K > 1 and (K > n or K % S or
-                             pool.pointer + (K // S) * self.d_steps * B >= pool.num_entries):
+                             pool.pointer + (K // S) * self.nD * B >= pool.num_entries or
+                             any(self._pn_due(t) for t in range(1, K // S))):   # a due adaption heads its launch
                 K = K // 2 if (K // 2) % S == 0 else 1
             self._launch(K, more=n > K)
             n -= K

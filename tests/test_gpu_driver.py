@@ -38,6 +38,11 @@ class OracleLearner(object):
         self.rms_d = d.obs_rms.sums.cpu().numpy().copy()
         self.hps = mu.hps
         self.per = per
+        # the reward net inside the actor loss (sam_agent.py:88,191-194): the discriminator's own (tied: the
+        # agent update reads the D updates of the same training step) or the agent's frozen copy
+        self.pd_frozen = None
+        if mu.hps.d_actor_loss_scale != 0 and not mu.hps.tie_actor_reward_net:
+            self.pd_frozen = mu.d_params.cpu().numpy().astype(np.float64)
         self.last_g = {}   # the unclipped gradients of the last update, per optimiser
         # Undecidable leaky-ReLU units (nets_oracle.KINKS): gpu_g = the device's unclipped gradients of the update
         # being mirrored (set by the caller before step(); None = no accounting)
@@ -164,9 +169,11 @@ class OracleLearner(object):
                 p[ow:ow + h2], p[ob3:ob3 + 1] = NO.popart(p[ow:ow + h2], p[ob3:ob3 + 1], ret[0], ret[1], *new)
                 setattr(self, name, p)
             ret = new
+        ds = hp.d_actor_loss_scale
+        pd_a = None if ds == 0 else (self.pd if self.pd_frozen is None else self.pd_frozen)
         al, ga = self.with_kinks('a', lambda: NO.actor_loss_grad(
-            self.pa, self.da, self.pc, self.dc, None, None, b['obs0'], mean, std, 1.0, hp.q_actor_loss_scale, 0.0,
-            ret=ret), self.da)
+            self.pa, self.da, self.pc, self.dc, pd_a, self.dc if ds else None, b['obs0'], mean, std, 1.0,
+            hp.q_actor_loss_scale, ds, ret=ret), self.da)
         cl, gc, _ = self.with_kinks('c', lambda: NO.critic_loss_grad(
             self.pc, self.dc, b['obs0'], b['acs'], iws, tq, mean, std, hp.wd_scale, hp.td_loss_1_scale, ret=ret,
             tcns=tqn, tdn_scale=hp.td_loss_n_scale), self.dc)
@@ -423,7 +430,8 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
         assert torch.equal(a.cpu(), b.cpu())
 
 
-@pytest.mark.parametrize('cfg_name,d_steps,g_steps', [('C1', 1, 3), ('C3', 1, 3), ('C1', 2, 1), ('ragged', 1, 2)])
+@pytest.mark.parametrize('cfg_name,d_steps,g_steps', [('C1', 1, 3), ('C3', 1, 3), ('C1', 2, 1), ('ragged', 1, 2),
+                                                      ('C1-tied', 1, 2), ('ragged-tied', 2, 1)])
 def test_training_step_schedule_matches_oracle(cfg_name, d_steps, g_steps):
     """d_steps discriminator updates and g_steps agent updates per training step (sam.py:323-433; the
     launcher runs 1 and 3): rows with role subsets, each row checked against the oracle, weights after
@@ -431,13 +439,17 @@ def test_training_step_schedule_matches_oracle(cfg_name, d_steps, g_steps):
     import bench
     from sam_tf_amd.comm import TorchComm
     from sam_tf_amd.driver import UpdateStepDriver
+    cfg_name, _, tied = cfg_name.partition('-')
     if cfg_name == 'ragged':  # layer-wise path
         cfg = dict(ob=5, ac=2, h=(33, 70), B=37, per=False, mem=2048, name='ragged')
     else:
         cfg = dict(bench.CONFIGS[cfg_name], mem=2048)
+    if tied:   # the actor loss differentiates through the discriminator's OWN reward net (sam_agent.py:88,191-194):
+        # every agent update reads the D updates of its training step -> D rows first, no row carries both
+        cfg['hps'] = dict(d_actor_loss_scale=0.5, tie_actor_reward_net=True)
     mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, True)
     drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=d_steps, g_steps=g_steps)
-    both = min(d_steps, g_steps)
+    both = 0 if tied else min(d_steps, g_steps)
     assert drv.sched == [1] * (d_steps - both) + [3] * both + [2] * (g_steps - both)
     ref = OracleLearner(mu, d, pool, cfg['per'])
     np.random.seed(11); random.seed(11)
@@ -486,6 +498,107 @@ def test_training_step_schedule_matches_oracle(cfg_name, d_steps, g_steps):
             else:
                 np.random.randint(low=0, high=N, size=B)
     assert np.array_equal(after_np, np.random.randint(0, 1 << 30, 4)) and after_py == random.random()
+
+
+@pytest.mark.parametrize('per', [False, True])
+def test_window_and_param_noise_rows_keep_the_host_rng_order(per):
+    """sam.py:330-367,408-415: with `window` every d_step first updates D on pairs from the most recent
+    transitions (RB.sample_recent), and every pn_adapt_frequency training steps mu.adapt_param_noise runs between
+    the D updates and the agent updates.  The driver must consume np.random exactly as that loop does — same
+    calls, same order — whether it launches row by row or packs training steps; and the adaption's distance must
+    be the oracle's for the batch it drew and the perturbed actor it made."""
+    import bench
+    from oracle import nets_oracle as NO
+    from sam_tf_amd.comm import TorchComm
+    cfg = dict(bench.CONFIGS['C3' if per else 'C1'], mem=2048, d_steps=1, g_steps=2, window=300,
+               pn_adapt_frequency=2, hps=dict(noise_type='adaptive-param_0.2'))
+    results = []
+    for packed in (False, True):
+        mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, True)
+        assert mu.param_noise is not None and drv.sched == [3, 3] and drv.dseq == ['w', 'u']
+        np.random.seed(21); random.seed(21)
+        pool.pointer = 0
+        N, B = mu.replay_buffer.num_entries, drv.B
+        calls, real_randint = [], np.random.randint
+        box = {}
+        real_adapt = mu.adapt_param_noise
+
+        def logged_randint(low=0, high=None, size=None, **kw):
+            out = real_randint(low, high, size, **kw)
+            if not box.get('preparing'):   # prepare() draws warm-up indices and then restores the generator
+                calls.append((int(high), tuple(np.atleast_1d(size).tolist())))
+            return out
+
+        real_sample = mu.replay_buffer.sample
+
+        def logged_sample(*a, **k):
+            box['batch'] = real_sample(*a, **k)
+            return box['batch']
+
+        def logged_adapt(comm):
+            n0 = len(calls)
+            real_adapt(comm)
+            assert calls[n0:] == ([] if per else [(N, (B,))])   # RB.sample's draw (PER samples with `random`)
+            calls.append('adapt')
+            # the distance against the oracle: actor vs perturbed actor on the batch the adaption drew
+            h1, h2 = mu.hps.hid_widths
+            da = NO.MLP(mu.ob_dim, h1, h2, mu.ac_dim, False)
+            mean, std = (t.cpu().numpy() for t in mu._mean_std())
+            acts = [NO.actor_act(NO.unflatten(torch.as_tensor(p.astype(np.float64)), da),
+                                 NO.obz(torch.as_tensor(box['batch']['obs0'].astype(np.float64)),
+                                        torch.as_tensor(mean.astype(np.float64)),
+                                        torch.as_tensor(std.astype(np.float64))), da, 1.0).numpy()
+                    for p in (mu.actor.get_flat(), mu.apnp_actor.get_flat())]
+            want = float(np.sqrt(np.mean(np.square(acts[0] - acts[1]))))
+            assert mu.pn_dist == pytest.approx(want, rel=1e-5), (mu.pn_dist, want)
+        real_prepare = drv.prepare
+
+        def quiet_prepare(*a, **k):
+            box['preparing'] = True
+            try:
+                real_prepare(*a, **k)
+            finally:
+                box['preparing'] = False
+        drv.prepare = quiet_prepare
+        np.random.randint, mu.adapt_param_noise, mu.replay_buffer.sample = logged_randint, logged_adapt, logged_sample
+        try:
+            T = 5
+            if packed:
+                drv.prepare_all()
+                drv.run(T * drv.S)
+            else:
+                for _ in range(T * drv.S):
+                    drv.step()
+        finally:
+            np.random.randint = real_randint
+        torch.cuda.synchronize()
+        # the reference's loop: per training step  choice(window) , randint(N)  [adapt: randint(N)]  then g agent
+        # draws (uniform replay: randint(N); prioritized: `random`, not np.random)
+        expect = []
+        for t in range(T):
+            expect += [(300, (B,)), (N, (B,))]
+            if t % 2 == 0:
+                expect += ([] if per else [(N, (B,))]) + ['adapt']
+            if not per:
+                expect += [(N, (B,))] * 2
+        flat = []
+        for c in calls:   # a packed launch may draw several equal-sized batches in one call
+            if c != 'adapt' and len(c[1]) > 1:
+                flat += [(c[0], (c[1][-1],))] * int(np.prod(c[1][:-1]))
+            else:
+                flat.append(c)
+        assert flat == expect, (flat, expect)
+        assert len(drv.pn_log) == 3 and drv.train_step_in_iter == T
+        results.append((mu.L.params.clone(), d.obs_rms.sums.clone(), list(drv.pn_log), np.random.randint(0, 1 << 30, 4)))
+    # row-by-row and packed launches: same arithmetic, same adaptions, same generator position afterwards
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    assert results[0][2] == results[1][2] and np.array_equal(results[0][3], results[1][3])
+    # the last adaption against the oracle: distance between the actor and the perturbed actor on its batch
+    # (sam_agent.py:727-740; param_noise.py adapt_std)
+    assert all(np.isfinite(x) for pair in results[0][2] for x in pair)
+    stds = [s for _, s in results[0][2]]
+    for (dist, new), old in zip(results[0][2], [0.2] + stds[:-1]):
+        assert new == pytest.approx(old / 1.01 if dist > 0.2 else old * 1.01, rel=1e-12)
 
 
 def test_schedule_packed_launch_equals_single_rows():
