@@ -678,6 +678,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const WDesc a1 = w_nn(a.actor.W1, ob), a2 = w_nn(a.actor.W2, H), a3 = w_nt(a.actor.W2, H, 0, H);
     const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
     const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
+    if (cw) WTRACE(wg, 1, 0);
     if (cw) {
         load_rows(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 4), in_c);
         for (int t = tid; t < R * PP; t += NC) L.PRE[t] = 0.f;
@@ -768,9 +769,9 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
                 a.DZ1a[(row0 + r) * H + c] = v * ((m1a >> bi) & 1u ? 1.f : 0.2f);
             });
     }
+    if (cw) WTRACE(wg, 1, 1);
 }
 
-constexpr int kRowBatch = 13;   // discriminator rows: loads go out in batches of 13 columns per thread
 template <bool CW>
 __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
@@ -787,6 +788,8 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc d1 = w_nn(n.W1, in), d2 = w_nn(n.W2, H), d3 = w_nt(n.W2, H, 0, H);
+    const int tsec = sect == 2 ? 0 : (sect == 0 ? 2 : 4);
+    if (cw) WTRACE(wg % tiles_b, 2, tsec);
     // statistics the rows are normalised with, staged in LDS (over T1, unused until the first product).
     // d.obs_rms.update folded into the step: the batch's float64 column sums were computed ahead, every
     // workgroup derives the mean/std that INCLUDE this batch from sums + addvec — the same arithmetic as the
@@ -811,51 +814,60 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         }
         bar();
     }
-    if (cw) {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134);
-        // loads in batches (see load_rows)
-        const int r = tid >> 4, c0 = tid & 15;
+    if (cw) {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134):
+        // every row load goes out first (rows_issue), then the rows are normalised and written (branch-free,
+        // the HBM copy last — see rows_commit)
+        const int r = tid >> 4;
         const int64_t g = row0 + r;
         const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g);
         const int64_t eg = (a.e_start ? a.e_start[0] : 0) + g;
-        const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
-        for (int cb = c0; cb < k32; cb += 16 * kRowBatch) {
-            float pv[kRowBatch], ev[kRowBatch], ee[kRowBatch], m[kRowBatch], sd[kRowBatch];
+        const float* mp = norm ? ms : nullptr;
+        RowRegs xp, xe;
+        if (sect != 1) rows_issue(xp, k32, a.p_obs, a.p_acs, ob, ac, ac, pg);
+        if (sect != 0) rows_issue(xe, k32, a.e_obs, a.e_acs, ob, ac, ac, eg);
+        if (sect == 0) rows_commit(L, xp, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
+        else if (sect == 1) rows_commit(L, xe, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
+        else {
+            // interpolates of the NORMALISED rows; X receives V later, nothing goes to HBM here
+            const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
+            const int t = opaque_tid();
+            const int c0 = t & 15;
+            float* xr = L.X + (t >> 4) * L.px + c0;
+            constexpr int HB = kRowRegs / 2;
 #pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) {
-                const int c = cb + 16 * u;
-                pv[u] = 0.f; ev[u] = 0.f; ee[u] = 0.f; m[u] = 0.f; sd[u] = 1.f;
-                if (c < ob) {
-                    if (sect != 1) pv[u] = a.p_obs[pg * ob + c];
-                    if (sect != 0) ev[u] = a.e_obs[eg * ob + c];
-                    if (norm) { m[u] = ms[c]; sd[u] = ms[kMaxIn + c]; }
-                    if (sect == 2 && a.eps_ob) ee[u] = a.eps_ob[g * ob + c];
-                } else if (c < in) {
-                    if (sect != 1) pv[u] = a.p_acs[pg * ac + (c - ob)];
-                    if (sect != 0) ev[u] = a.e_acs[eg * ac + (c - ob)];
-                    if (sect == 2 && a.eps_ob) ee[u] = a.eps_ac[g * ac + (c - ob)];
-                }
-            }
+            for (int h = 0; h < 2; ++h) {
+                float m[HB], sd[HB], ee[HB];
 #pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) {
-                const int c = cb + 16 * u;
-                if (c >= k32) continue;
-                float v = 0.f;
-                if (c < in) {
-                    float p = pv[u], e = ev[u], eps = ee[u];
-                    if (c < ob) {
-                        if (norm) {
-                            p = fminf(fmaxf((p - m[u]) / sd[u], -5.f), 5.f);
-                            e = fminf(fmaxf((e - m[u]) / sd[u], -5.f), 5.f);
-                        }
-                        if (sect == 2 && !a.eps_ob)
-                            eps = philox_uniform(a.rng_seed, step, RNG_EPS_OB, (uint64_t)(g * ob + c));
-                    } else if (sect == 2 && !a.eps_ob) {
-                        eps = philox_uniform(a.rng_seed, step, RNG_EPS_AC, (uint64_t)(g * ac + (c - ob)));
+                for (int i = 0; i < HB; ++i) {
+                    const int c = c0 + 16 * (h * HB + i);
+                    const int ci = min(c, ob - 1);
+                    m[i] = 0.f; sd[i] = 1.f; ee[i] = 0.f;
+                    if (norm) { m[i] = ms[ci]; sd[i] = ms[kMaxIn + ci]; }   // uniform branch
+                    if (a.eps_ob) {                                       // injected randoms (uniform branch)
+                        const bool isob = c < ob;
+                        const int ca = min(max(c - ob, 0), ac - 1);
+                        ee[i] = isob ? a.eps_ob[g * ob + ci] : a.eps_ac[g * ac + ca];
                     }
-                    v = sect == 0 ? p : (sect == 1 ? e : eps * p + (1.f - eps) * e);
-                    if (sect != 2) a.X[(hrow0 + r) * in + c] = v;   // interpolate rows: X receives V below
                 }
-                L.X[r * L.px + c] = v;
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    const int u = h * HB + i, c = c0 + 16 * u;
+                    float pv = xp.v[u], ev = xe.v[u];
+                    if (norm) {
+                        const float pn = fminf(fmaxf((pv - m[i]) / sd[i], -5.f), 5.f);
+                        const float en = fminf(fmaxf((ev - m[i]) / sd[i], -5.f), 5.f);
+                        pv = c < ob ? pn : pv;
+                        ev = c < ob ? en : ev;
+                    }
+                    float eps = ee[i];
+                    if (!a.eps_ob) {   // drawn here: stream and element as samx_disc_randoms numbers them
+                        const bool isob = c < ob;
+                        eps = philox_uniform(a.rng_seed, step, isob ? RNG_EPS_OB : RNG_EPS_AC,
+                                             isob ? (uint64_t)(g * ob + c) : (uint64_t)(g * ac + (c - ob)));
+                    }
+                    const float v = eps * pv + (1.f - eps) * ev;
+                    xr[16 * u] = c < in ? v : 0.f;
+                }
             }
         }
     }
@@ -904,6 +916,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             for_acc(acc, [&](int r, int c, float v, int) {
                 a.DZ1[(hrow0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
             });
+        if (cw) WTRACE(wg % tiles_b, 2, tsec + 1);
         return;
     }
     // ---- interpolate rows: g = d score / d input, sum g^2, V = g / (B dim), tangent forward along V.
@@ -1012,6 +1025,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         }
         if (tid == 0) slot[H] = 0.f;
     }
+    if (cw) WTRACE(wg % tiles_b, 2, 1);
 }
 
 // Placement: blocks b and b + 8 share an XCD (and its 4 MiB L2), so the 8 residue classes of blockIdx.x are

@@ -31,6 +31,11 @@ for it in range(20):
 t = acc[5:, :32]
 rel = (t - t[:, :1]) / 100.0
 print('target+critic', ' '.join('%d:%.2f' % (i, x) for i, x in enumerate(np.median(rel, axis=0)) if t[0, i] > 0))
+base = t[:, :1]
+ra, rd = acc[5:, 32:34], acc[5:, 64:70]
+f = lambda x: ' '.join('%.2f' % v for v in np.median((x - base) / 100.0, axis=0))
+print('actor role workgroup 0 (start end):', f(ra))
+print('D role first tiles (interpolate start end | policy start end | expert start end):', f(rd))
 st = acc[5:, 128:]
 n = int((st[0] > 0).sum())
 d = np.median(np.diff(st[:, :n], axis=1), axis=0) / 100.0
