@@ -34,6 +34,18 @@ struct AgentArgs {
     // actor role
     float *Xa, *A1a, *A2a, *DZ1a, *DZ2a;   // [B][ob+ac] (obz0 | mu(obz0)), [B][256] x 4
     float *dPre, *row_q;                   // [B][ac] ; [B] Q(obz0, mu(obz0))
+    // Return normalisation / PopArt / n-step returns (sam_agent.py:161-201,483-498,651-672): the statistics and
+    // the critic heads change between the target pass and the loss pass, so the targets then come from their
+    // own launch (launch_targets) and the roles read them back:
+    //   ret_mean / ret_std: device scalars or null;  ext_tq / ext_tqn: targets computed ahead (null = the
+    //   target+critic role computes the 1-step targets itself);  tdn_scale: weight of the n-step TD loss;
+    //   n_idx / n_rews / n_dones / n_len: the n-step lookahead of the sampled rows (launch_targets only);
+    //   targ_qn: [B] out of launch_targets;  row_hubn: [B] huber(n-step TD) * iw
+    const float *ret_mean, *ret_std, *ext_tq, *ext_tqn;
+    float tdn_scale;
+    const int64_t* n_idx;
+    const float *n_rews, *n_dones, *n_len;
+    float *targ_qn, *row_hubn;
     // weight decay (network_util.py:43-56): wd_blocks extra workgroups leave float64 partial sums of squares of
     // the critic's two hidden kernels in wd_part[wd_blocks] (0 = off)
     double* wd_part;
@@ -65,6 +77,9 @@ struct DiscArgs {
 bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B);
 // roles: bit 0 actor, bit 1 target+critic, bit 2 discriminator
 int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t st);
+// TD targets only: the 1-step targets of the sampled rows into a->targ_q and, with a->n_idx, the n-step targets
+// into a->targ_qn (de-normalised with the CURRENT return statistics, sam_agent.py:196-205)
+int launch_targets(const AgentArgs* a, hipStream_t st);
 
 }  // namespace wide
 }  // namespace samx

@@ -560,6 +560,54 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// TD targets only (return normalisation + PopArt / n-step).  pass 0: the 1-step target of the sampled rows;
+// pass 1: the n-step target (rows n_idx, dense n_rews / n_dones / n_len).
+template <bool CW>
+__device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) {
+    const int tid = threadIdx.x;
+    constexpr bool cw = CW;
+    const int64_t row0 = (int64_t)wg * R;
+    const int ob = a.ob, ac = a.ac, in_c = ob + ac;
+    Lds L = carve(lds, in_c);
+    const int k32c = ((in_c + 31) / 32) * 32;
+    const int64_t* idx = pass ? a.n_idx : a.idx;
+    const int64_t pr = cw ? ring_row(idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
+    WPipe pipe;
+    wpipe_init(pipe);
+    const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
+    const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
+    if (cw && tid < R) {
+        if (pass) {
+            L.rw[tid] = a.n_rews[row0 + tid]; L.dn[tid] = a.n_dones[row0 + tid]; L.tl[tid] = a.n_len[row0 + tid];
+        } else {
+            const int64_t prs = ring_row(idx, a.ring_start, a.ring_len, row0 + tid);
+            L.rw[tid] = a.rews[prs];
+            L.dn[tid] = a.dones1[prs];
+            L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
+        }
+    }
+    if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
+    bar();
+    hidden_fwd<CW>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
+    HeadStage hs;
+    stage_head_issue(hs, a.targ_actor.W3, ac);
+    hidden_fwd<CW>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
+    hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
+    HeadRegs hd;
+    if (cw) head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
+    hidden_fwd<CW>(pipe, tc2, tc2, false, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
+    if (cw) head1(L.T2, hd, L.s_);
+    bar();
+    if (cw && tid < R) {
+        const bool lens = pass || a.td_len;
+        const float gam = lens ? powf(a.gamma, L.tl[tid]) : a.gamma;
+        float qp = L.s_[tid];
+        if (a.ret_mean) qp = qp * a.ret_std[0] + a.ret_mean[0];              // sam_agent.py:199-201
+        (pass ? a.targ_qn : a.targ_q)[row0 + tid] = L.rw[tid] + gam * ((1.f - L.dn[tid]) * qp);
+    }
+}
+
 template <bool CW>
 __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
@@ -574,13 +622,24 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
     const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
     const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    const bool ext = a.ext_tq != nullptr;   // the targets were computed ahead (launch_targets)
     if (cw && tid < R) {
-        const int64_t prs = ring_row(a.idx, a.ring_start, a.ring_len, row0 + tid);
-        L.rw[tid] = a.rews[prs];
-        L.dn[tid] = a.dones1[prs];
         L.iw[tid] = a.iws ? a.iws[row0 + tid] : 1.f;
-        L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
+        if (ext) {
+            L.tq[tid] = a.ext_tq[row0 + tid];
+            L.tl[tid] = a.ext_tqn ? a.ext_tqn[row0 + tid] : 0.f;   // (the n-step target sits in the tl strip)
+        } else {
+            const int64_t prs = ring_row(a.idx, a.ring_start, a.ring_len, row0 + tid);
+            L.rw[tid] = a.rews[prs];
+            L.dn[tid] = a.dones1[prs];
+            L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
+        }
     }
+    RowRegs x0;
+    HeadRegs hd;
+    if (ext) {
+        if (cw) rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
+    } else {
     // ---- TD target with the target nets on obs1
     WTRACE(wg, 0, 0);
 #ifdef SAMX_TRACE
@@ -599,8 +658,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     WTRACE(wg, 0, 4);
     hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
     WTRACE(wg, 0, 5);
-    RowRegs x0;   // the online critic's input rows travel while the target critic's second layer runs
-    HeadRegs hd;
+    // the online critic's input rows travel while the target critic's second layer runs
     if (cw) {
         rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
         head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
@@ -616,6 +674,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         a.targ_q[row0 + tid] = t;
         L.tq[tid] = t;
     }
+    }   // !ext
     // ---- online critic on (obz0, acs): forward, loss, backward
     WTRACE(wg, 0, 14);
     if (cw) rows_commit(L, x0, k32c, a.mean, a.stdv, ob, ac, a.Xc, row0 + (tid >> 4), in_c);
@@ -630,15 +689,29 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     if (cw) head1(L.T2, hd, L.s_);
     bar();
     if (cw && tid < R) {
-        const float td = L.s_[tid] - L.tq[tid];
+        // with return normalisation: de-normalised prediction minus normalised target (sam_agent.py:161-182)
+        const float rmean = a.ret_mean ? a.ret_mean[0] : 0.f, rstd = a.ret_std ? a.ret_std[0] : 1.f;
+        const float pred = a.ret_mean ? L.s_[tid] * rstd + rmean : L.s_[tid];
+        auto hub = [](float td, float& dh) {                              // math_util.py:22-29
+            const float ad = fabsf(td);
+            dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
+            return ad < 1.f ? 0.5f * td * td : ad - 0.5f;
+        };
+        const float td = pred - (a.ret_mean ? (L.tq[tid] - rmean) / rstd : L.tq[tid]);
         const float iw = L.iw[tid];
-        const float ad = fabsf(td);
-        const float hub = ad < 1.f ? 0.5f * td * td : ad - 0.5f;         // math_util.py:22-29
-        const float dh = ad < 1.f ? td : (td > 0.f ? 1.f : -1.f);
-        const float dq = (a.td_scale / (float)a.B) * dh * iw;
+        float dh, dhn = 0.f, hn = 0.f;
+        const float h1 = hub(td, dh);
+        float dq = (a.td_scale / (float)a.B) * dh;
+        if (a.ext_tqn) {                                                  // sam_agent.py:483-498
+            const float tdn = pred - (a.ret_mean ? (L.tl[tid] - rmean) / rstd : L.tl[tid]);
+            hn = hub(tdn, dhn);
+            dq += (a.tdn_scale / (float)a.B) * dhn;
+        }
+        dq = a.ret_mean ? dq * iw * rstd : dq * iw;
         L.dq[tid] = dq;
         a.row_dq[row0 + tid] = dq;
-        a.row_hub[row0 + tid] = hub * iw;
+        a.row_hub[row0 + tid] = h1 * iw;
+        if (a.row_hubn) a.row_hubn[row0 + tid] = hn * iw;
         if (a.td_out) a.td_out[row0 + tid] = td;
     }
     bar();
@@ -696,7 +769,8 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
     if (cw) {
         head1(L.T2, hd, L.s_);
-        if (tid < R) L.dq[tid] = -a.q_scale / (float)a.B;
+        // (d(de-normalised Q)/d(critic output) = ret_std, sam_agent.py:184-187)
+        if (tid < R) L.dq[tid] = a.ret_std ? -a.q_scale / (float)a.B * a.ret_std[0] : -a.q_scale / (float)a.B;
     }
     bar();
     if (cw) {
@@ -1080,6 +1154,12 @@ __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     }
 }
 
+__global__ __launch_bounds__(NT, 1) void targets_kernel(AgentArgs a, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int pass = blockIdx.x / tiles, wg = blockIdx.x % tiles;
+    if (is_compute()) role_t<true>(a, wg, lds, pass); else role_t<false>(a, wg, lds, pass);
+}
+
 bool net_ok(const samx_mlp* d) { return d && !d->layernorm && d->h1 == kH && d->h2 == kH; }
 
 }  // namespace
@@ -1131,6 +1211,19 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
     static LdsGrant grant;
     if (int rc = grant.ensure((const void*)roles_kernel, lds)) return rc;
     roles_kernel<<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_targets(const AgentArgs* a, hipStream_t st) {
+    SAMX_REQUIRE(a && a->targ_q && (!a->n_idx || (a->n_rews && a->n_dones && a->n_len && a->targ_qn)),
+                 "wide::launch_targets: missing buffers");
+    const int tiles = (int)(a->B / kRows);
+    const size_t lds = lds_floats(a->ob + a->ac) * sizeof(float);
+    SAMX_REQUIRE(lds <= 160 * 1024, "wide target kernel needs %zu bytes of LDS", lds);
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)targets_kernel, lds)) return rc;
+    targets_kernel<<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

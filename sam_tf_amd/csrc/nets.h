@@ -28,6 +28,16 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
 // the chains of layer products of every role, ONE grouped launch for the weight-gradient products, ONE
 // reduction.  ws_tc / ws_a: one samx_nets_ws_bytes workspace per agent role, ws_d: samx_disc_ws_bytes.
 bool wide_step_supported(const samx_learner* L, int64_t B);
+// Return normalisation / PopArt / n-step returns: the TD targets come from their own launch (the statistics and the
+// critic heads change between the target pass and the loss pass, sam_agent.py:651-672).  targets_only: launch
+// only wide::launch_targets (1-step targets into out.targ_q; with n_idx the n-step targets into tqn) and return;
+// use_ext: the roles read out.targ_q / tqn instead of computing the targets.
+struct WideExt {
+    bool targets_only = false, use_ext = false;
+    const int64_t* n_idx = nullptr;
+    const float *n_rews = nullptr, *n_dones = nullptr, *n_len = nullptr;
+    float* tqn = nullptr;
+};
 size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B);
 // Fills learner.grads, the per-segment sums of squares (sumsq, fused::kMaxSegBlocks per optimiser) and the
 // losses, and ticks the step counters of the roles it ran.  part bit 0: the role launch and the grouped
@@ -36,6 +46,6 @@ size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B);
 // path) and the counter tick.  Four launches per step with samx_step_apply, all on the caller's stream.
 int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
                     size_t nets_bytes, void* ws_d, size_t disc_bytes, void* ws_red, size_t red_bytes, float* sumsq,
-                    bool do_a, bool do_d, int part, hipStream_t st);
+                    bool do_a, bool do_d, int part, hipStream_t st, const WideExt* ext);
 
 }  // namespace samx

@@ -1291,6 +1291,9 @@ struct WFinishSeg {
 struct WLossArgs {
     int64_t B;
     const float* row_hub;             // critic (null = no agent roles)
+    const float* row_hubn;            // n-step TD loss rows, or null
+    float tdn_scale;
+    const float *ret_mean, *ret_std;  // return normalisation (device scalars) or null
     const double* wd_part;
     int wd_blocks;
     float td_scale, wd_scale;
@@ -1338,17 +1341,21 @@ __device__ void wide_losses(const WLossArgs& t, int which, double* sh) {
     if (which == 0) {
         if (!t.row_hub) return;
         const double l = sum_f32_x4(t.row_hub, B, sh) / (double)B * t.td_scale;
+        const double ln_ = t.row_hubn ? sum_f32_x4(t.row_hubn, B, sh) / (double)B * t.tdn_scale : 0.0;
         double wd = 0.0;
         if (t.wd_scale > 0.f) wd = 0.5 * t.wd_scale * block_sum_d(i < t.wd_blocks ? t.wd_part[i] : 0.0, sh);
         if (i == 0) {
             t.critic_losses[0] = (float)l;
             t.critic_losses[1] = (float)wd;
-            t.critic_losses[2] = (float)(l + wd);
-            t.critic_losses[3] = 0.f;
+            t.critic_losses[2] = (float)(l + wd + ln_);
+            t.critic_losses[3] = (float)ln_;
         }
     } else if (which == 1) {
         if (!t.row_q) return;
-        const double q = -sum_f32_x4(t.row_q, B, sh) / (double)B * t.q_scale;
+        // with return normalisation the actor loss is on the DE-normalised prediction (sam_agent.py:184-194):
+        // mean(s * std + mean) = mean(s) * std + mean
+        const double rm = t.ret_mean ? (double)t.ret_mean[0] : 0.0, rs = t.ret_std ? (double)t.ret_std[0] : 1.0;
+        const double q = -(sum_f32_x4(t.row_q, B, sh) / (double)B * rs + rm) * t.q_scale;
         if (i == 0) {
             t.actor_losses[0] = (float)q;
             t.actor_losses[1] = 0.f;
@@ -1506,14 +1513,14 @@ size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B) {
 }
 
 bool wide_step_supported(const samx_learner* L, int64_t B) {
-    return wide::supported(&L->actor, &L->critic, &L->reward, L->ob_dim, L->ac_dim, B) && !L->ret_mean &&
-           L->n_step == 0 && L->d_actor_loss_scale == 0.f && B / wide::kRows <= kGpBlocks;
+    return wide::supported(&L->actor, &L->critic, &L->reward, L->ob_dim, L->ac_dim, B) &&
+           L->d_actor_loss_scale == 0.f && B / wide::kRows <= kGpBlocks;
 }
 
 int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws_tc, void* ws_a,
                     size_t nets_bytes, void* ws_d, size_t disc_bytes, void* ws_red, size_t red_bytes, float* sumsq,
-                    bool do_a, bool do_d, int part, hipStream_t st) {
-    const bool run = (part & 1) != 0;
+                    bool do_a, bool do_d, int part, hipStream_t st, const WideExt* ext) {
+    const bool run = (part & 1) != 0 && !(ext && ext->targets_only);
     static_assert(kWdBlocks <= 256 && kGpBlocks <= 256, "one 256-thread workgroup adds the partial sums");
     const int64_t B = b->B;
     const samx_mlp *da = &L->actor, *dc = &L->critic, *dd = &L->reward;
@@ -1583,6 +1590,18 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.row_hub = w1.row0; a.row_dq = w1.row1; a.w3c_part = wr.w3c;
         a.Xa = w2.XC; a.A1a = w2.ha.A1; a.A2a = w2.ha.A2; a.DZ1a = w2.ka.DZ1; a.DZ2a = w2.ka.DZ2;
         a.dPre = w2.dPre; a.row_q = w2.row0;
+        a.ret_mean = L->ret_mean; a.ret_std = L->ret_std; a.tdn_scale = L->td_loss_n_scale;
+        a.ext_tq = a.ext_tqn = nullptr; a.n_idx = nullptr; a.n_rews = a.n_dones = a.n_len = nullptr;
+        a.targ_qn = nullptr; a.row_hubn = nullptr;
+        if (ext) {
+            a.n_idx = ext->n_idx; a.n_rews = ext->n_rews; a.n_dones = ext->n_dones; a.n_len = ext->n_len;
+            a.targ_qn = ext->tqn;
+            if (ext->targets_only) return wide::launch_targets(&a, st);
+            if (ext->use_ext) {
+                a.ext_tq = o->targ_q; a.ext_tqn = ext->tqn;
+                if (ext->tqn) a.row_hubn = w1.row2;
+            }
+        }
         // weight-gradient products: critic W2, W1 ; actor W3, W2, W1
         prob(0, w1.hc.A1, H, H, w1.kc.DZ2, H, H, B, B);
         prob(1, w1.XC, in, in, w1.kc.DZ1, H, H, B, B);
@@ -1654,6 +1673,8 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         WLossArgs& t = f.loss;
         t.B = B;
         t.row_hub = do_a ? w1.row0 : nullptr;
+        t.row_hubn = (do_a && ext && ext->use_ext && ext->tqn) ? w1.row2 : nullptr;
+        t.tdn_scale = L->td_loss_n_scale; t.ret_mean = L->ret_mean; t.ret_std = L->ret_std;
         t.wd_part = w1.wd_part; t.wd_blocks = kWdBlocks;
         t.td_scale = L->td_loss_scale; t.wd_scale = L->wd_scale; t.critic_losses = o->critic_losses;
         t.row_q = do_a ? w2.row0 : nullptr; t.q_scale = L->q_actor_loss_scale; t.actor_losses = o->actor_losses;

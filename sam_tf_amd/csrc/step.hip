@@ -737,8 +737,48 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     }
     if (wide && !t_only && !t_done) {
         // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions, all on the caller's stream
-        return samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes,
-                                     w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, part & 3, st);
+        samx::WideExt we;
+        auto roles = [&](const samx::WideExt* e) {
+            return samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes,
+                                         w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, part & 3, st, e);
+        };
+        if (do_a && (L->ret_mean || L->n_step > 0)) {
+            // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
+            // ret_rms.update + PopArt -> losses with the new ones
+            we.tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;
+            if ((part & 1) && L->n_step > 0) {
+                SAMX_REQUIRE(b->a_idx && b->num_entries > 0,
+                             "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
+                if (b->n_end) {   // done ahead by the caller (samx_nstep_lookahead_many)
+                    we.n_idx = b->n_end; we.n_rews = b->n_rews; we.n_dones = b->n_dones; we.n_len = b->n_len;
+                } else {
+                    rc = samx_nstep_lookahead(b->rews, b->dones1, b->ring_len, b->ring_start, b->num_entries, b->a_idx,
+                                              B, L->n_step, (double)L->gamma, w.n_end, w.n_rews, nullptr, w.n_dones,
+                                              w.n_len, stream);
+                    if (rc != SAMX_OK) return rc;
+                    we.n_idx = w.n_end; we.n_rews = w.n_rews; we.n_dones = w.n_dones; we.n_len = w.n_len;
+                }
+            }
+            if (part & 1) {
+                we.targets_only = true;
+                rc = roles(&we);
+                if (rc != SAMX_OK) return rc;
+                we.targets_only = false;
+                if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
+                    rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, stream);
+                    if (rc != SAMX_OK) return rc;
+                    if (we.tqn) {
+                        rc = samx_rms_batch_sums(we.tqn, B, nullptr, 0, 1, w.ret_add2, stream);
+                        if (rc != SAMX_OK) return rc;
+                    }
+                    rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, we.tqn ? w.ret_add2 : nullptr, L->ret_mean,
+                                                L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, stream);
+                    if (rc != SAMX_OK) return rc;
+                }
+            }
+            we.use_ext = true;
+        }
+        return roles(&we);
     }
     if (!use_fused(L, B)) {
         // layer-wise path, role by role (same order as the reference: D first).  It works on dense

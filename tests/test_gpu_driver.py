@@ -213,7 +213,8 @@ def _assert_weights(mu, d, ref, K, tag, nets=('actor', 'critic', 'targ_actor', '
 @pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
                                       'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper', 'ragged-launcher',
-                                      'raggedper-ret', 'C4'])
+                                      'raggedper-ret', 'C4', 'C4-retn', 'wsmall-ret', 'wsmall-retn',
+                                      'wsmall-nstep', 'wsmallper-ret'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
@@ -230,7 +231,11 @@ def test_k_steps_match_oracle(cfg_name, graph):
              'bigBper': dict(ob=17, ac=6, h=(64, 64), B=512, per=True, name='big-batch-per'),
              # nothing a multiple of a tile, on the layer-wise path with the launcher's options
              'ragged': dict(ob=5, ac=2, h=(33, 70), B=37, per=False, name='ragged'),
-             'raggedper': dict(ob=5, ac=2, h=(33, 70), B=37, per=True, name='ragged-per')}
+             'raggedper': dict(ob=5, ac=2, h=(33, 70), B=37, per=True, name='ragged-per'),
+             # 256x256 nets on the role-fused path with the argparse-default options: targets from their own
+             # launch, PopArt between the target pass and the loss pass, n-step TD loss
+             'wsmall': dict(ob=20, ac=3, h=(256, 256), B=48, per=False, name='wide-small'),
+             'wsmallper': dict(ob=20, ac=3, h=(256, 256), B=48, per=True, name='wide-small-per')}
     # ret / retn / nstep: the argparse-default options (rmsify_rets + PopArt, n-step returns) WITHOUT
     # LayerNorm: whole-network path with the targets in their own launch
     cfg = dict(extra.get(base) or bench.CONFIGS[base], mem=2048, ln=opt in ('ln', 'launcher'),
@@ -238,10 +243,11 @@ def test_k_steps_match_oracle(cfg_name, graph):
                p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
     if base in extra:
-        assert drv.fused == (base not in ('widein', 'ragged', 'raggedper'))
+        assert drv.fused == (base not in ('widein', 'ragged', 'raggedper', 'wsmall', 'wsmallper'))
+        assert drv.wide == base.startswith('wsmall')
         assert drv.sums_small == (not base.startswith('bigB'))
     if opt and base not in extra:
-        assert drv.fused   # LayerNorm included: whole-network kernels of fused_ln.hip
+        assert drv.fused or (base == 'C4' and drv.wide)   # LayerNorm included: whole-network kernels of fused_ln.hip
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'])
     # C4: the Humanoid-shaped configuration at its full batch (1024 rows, 256x256 nets) through the real driver
