@@ -73,7 +73,8 @@ int samx_tree_find_prefixsum(const double* sum_tree, int64_t cap, const double* 
  * u: the B unit uniforms the reference draws with random.random() (host generates them with the
  * same generator and copies them in).  idxs_out int64[B]; iws_out float64[B] (and, if not NULL,
  * iws_f32_out float32[B] — what the critic loss is fed).  Requires num_entries >= 2.
- * Indices and all tree sums are bit-exact; iws use the device pow and agree to ~1e-15 relative. */
+ * Indices, tree sums AND the importance weights are bit-exact: the two pows of memory.py:301,308 go through
+ * the device routine that follows the host pow bit for bit (samx_pow_device below). */
 int samx_per_sample(const double* sum_tree, const double* min_tree, int64_t cap,
                     int64_t num_entries, const double* u, int64_t B, double beta,
                     int64_t* idxs_out, double* iws_out, float* iws_f32_out, void* stream);
@@ -93,6 +94,31 @@ int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host
 int samx_per_leaves_from_td_host(const float* td_host, const int64_t* idxs_host, int64_t n,
                                  int64_t num_entries, double alpha, int64_t num_demos, double demos_eps,
                                  double* leaf_out_host, double* max_priority_host);
+
+/* The same refresh ON THE DEVICE (no host round trip between two prioritized update steps): td float32[n]
+ * and idxs int64[n] in HBM -> leaf_out float64[n]; entries whose index lies outside [0, cap) mean "nothing
+ * pending" and are skipped.  per_state: 16 bytes in HBM, {double max_priority; uint64 error bits}: the running
+ * max(priority) (memory.py:379) and the reference's two asserts (bit 0: a priority that is not positive,
+ * memory.py:371; bit 1: index >= num_entries, memory.py:372) which the host reads when it next needs them.
+ * leaf = priority ** alpha with the host pow's bits (samx_pow_device). */
+int samx_per_leaves_from_td(const float* td, const int64_t* idxs, int64_t n, int64_t cap, int64_t num_entries,
+                            double alpha, int64_t num_demos, double demos_eps, double* leaf_out,
+                            void* per_state, void* stream);
+
+/* pow(x[i], y) with the bits of the HOST C library's pow (glibc's table-driven routine, FMA build; constants
+ * taken from the image's libm by tools/extract_pow_tables.py), computed on the device: what lets
+ * `priority ** alpha` (memory.py:341-342,376-377) and the importance weights (memory.py:301,308) stay in HBM.
+ * Bit-for-bit domain: x positive and normal, 2^-65 <= |y| < 2^63, |y log x| < 512; outside it the platform pow
+ * answers.  tests/test_gpu_pow.py compares >= 2^26 float32-born bases per exponent against libm.
+ * samx_pow_device_f32_range / samx_pow_host_f32_range: the same for the n float32 values whose bit patterns
+ * start at first_bits, widened to double, + bonus (device result in HBM / libm result in host memory).
+ * samx_pow_selfcheck(n): HOST — the number of n pseudo-random cases in which the host build of the routine
+ * differs from this machine's libm pow (0 expected; non-zero = another libm code path, keep the host refresh). */
+int samx_pow_device(const double* x, double y, int64_t n, double* out, void* stream);
+int samx_pow_device_f32_range(uint32_t first_bits, int64_t n, double bonus, double y, double* out, void* stream);
+int samx_pow_host_f32_range(uint32_t first_bits, int64_t n, double bonus, double y, double* out_host);
+int samx_pow_host(const double* x_host, double y, int64_t n, double* out_host);   /* libm pow, HOST pointers */
+int64_t samx_pow_selfcheck(int64_t n);
 
 /* ---- replay storage ------------------------------------------------------------------------ */
 /* RingBuffer.get_batch for the five atoms at once (memory.py:33-34,74-84): row = (start+idx)%maxlen.
@@ -438,6 +464,18 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
                           int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
                           float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
                           int64_t copy_skip_lo, int64_t copy_skip_n, void* stream);
+
+/* samx_per_row_prologue with the pending update given as TD ERRORS (upd_td float32[n_upd], HBM): workgroup 0
+ * first runs the refresh of samx_per_leaves_from_td on them (leaves kept in LDS, per_state updated), then
+ * goes on as above.  No upload words: every input already lives in HBM, so consecutive prioritized rows can
+ * sit in one captured graph (sam_agent.py:693-703 of row k feeding memory.py:266-309 of row k + 1). */
+int samx_per_row_prologue_td(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                             const int64_t* upd_idx, const float* upd_td, int64_t n_upd, double alpha,
+                             int64_t num_demos, double demos_eps, void* per_state,
+                             const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
+                             const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
+                             int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
+                             float* iws_f32_out, void* stream);
 
 /* a[n] (float) and b[n] (int64) to PINNED HOST memory (device-accessible) in one launch: the refreshed TD
  * errors and the sampled indices a prioritized-replay row hands back to the host (sam_agent.py:693-703). */

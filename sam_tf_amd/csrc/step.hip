@@ -271,6 +271,16 @@ __global__ __launch_bounds__(1024) void d_input_stats_kernel(
                        addvec, commit, sums, mean_out, std_out, idx_stride, addvec_stride);
 }
 
+// The pending update given as TD errors instead of leaf values: the refresh itself (|td| + 1e-6 ->
+// priority ** alpha with the host pow's bits, max_priority, the reference's asserts) runs at the head of
+// workgroup 0, the leaves stay in LDS.
+struct PerRefresh {
+    const float* td;          // null: upd_leaf holds the leaf values
+    double alpha, demos_eps;
+    int64_t num_demos, num_entries;
+    samx::PerState* state;
+};
+
 // PER row prologue: the pending priority update of the trees (workgroup 0) and the D-input sums of the
 // row (workgroup 1) do not depend on each other — one launch instead of two dependent ones.
 __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
     const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
     int64_t n_ent, const double* __restrict__ u, double beta, int64_t* __restrict__ idxs_out,
     double* __restrict__ iws_out, float* __restrict__ iws32_out, const int64_t* __restrict__ copy_src,
-    int64_t* copy_dst, int64_t copy_n, int64_t skip_lo, int64_t skip_n) {
+    int64_t* copy_dst, int64_t copy_n, int64_t skip_lo, int64_t skip_n, PerRefresh rf) {
     if (copy_src) {
         // the row's host-drawn words (pinned host memory) -> their device home, by BOTH workgroups (same
         // values to the same addresses; each then reads what it wrote itself): no separate upload node.
@@ -292,7 +302,14 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
         __syncthreads();
     }
     if (blockIdx.x == 0) {
-        samx::tree_set_body(ts, tm, stamp, cap, upd_idx, upd_leaf, n_upd, levels);
+        extern __shared__ double leaf_sh[];   // this workgroup's use of the launch's dynamic LDS (n_upd < 1024)
+        const double* leaf = upd_leaf;
+        if (rf.td) {
+            samx::leaves_from_td_body(rf.td, upd_idx, n_upd, cap, rf.num_entries, rf.alpha, rf.num_demos,
+                                      rf.demos_eps, leaf_sh, rf.state);
+            leaf = leaf_sh;
+        }
+        samx::tree_set_body(ts, tm, stamp, cap, upd_idx, leaf, n_upd, levels);
         if (u) {   // ... and, on the updated trees, this row's stratified sample (memory.py:266-309)
             __syncthreads();
             samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, 0, B);
@@ -518,14 +535,16 @@ int samx_d_input_stats_static(const float* replay_obs0, int64_t ring_start, int6
                               kStaticScratchBytes, (hipStream_t)stream);
 }
 
-int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
-                          const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
+static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                          const int64_t* upd_idx, const double* upd_leaf, const PerRefresh& rf, int64_t n_upd,
                           const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
                           int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
                           float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
                           int64_t copy_skip_lo, int64_t copy_skip_n, void* stream) {
-    SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && upd_leaf, "samx_per_row_prologue: null tree argument");
+    SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && (upd_leaf || rf.td), "samx_per_row_prologue: null tree argument");
+    SAMX_REQUIRE(!rf.td || (rf.state && rf.num_entries >= 0 && rf.num_entries <= cap && samx_pow::in_domain(1.0, rf.alpha)),
+                 "samx_per_row_prologue_td: needs the state words, num_entries in [0, cap] and alpha inside the pow domain");
     SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_row_prologue: cap %lld is not a power of two",
                  (long long)cap);
     SAMX_REQUIRE(n_upd > 0 && n_upd < 1024, "samx_per_row_prologue: 1..1023 priority updates (got %lld)",
@@ -550,9 +569,37 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
     per_row_prologue_kernel<<<2, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
         sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, (int)n_upd, levels, replay_obs0, ring_start, ring_len,
         p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, num_entries, u, beta, idxs_out, iws_out, iws_f32_out,
-        copy_src, copy_dst, copy_n, copy_skip_lo, copy_skip_n);
+        copy_src, copy_dst, copy_n, copy_skip_lo, copy_skip_n, rf);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
+}
+
+int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                          const int64_t* upd_idx, const double* upd_leaf, int64_t n_upd,
+                          const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
+                          const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
+                          int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
+                          float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
+                          int64_t copy_skip_lo, int64_t copy_skip_n, void* stream) {
+    PerRefresh rf{};
+    return per_row_prologue_impl(sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, rf, n_upd, replay_obs0, ring_start,
+                                 ring_len, p_idx, pool_obs0, e_start, B, ob_dim, addvec, num_entries, u, beta,
+                                 idxs_out, iws_out, iws_f32_out, copy_src, copy_dst, copy_n, copy_skip_lo,
+                                 copy_skip_n, stream);
+}
+
+int samx_per_row_prologue_td(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                             const int64_t* upd_idx, const float* upd_td, int64_t n_upd, double alpha,
+                             int64_t num_demos, double demos_eps, void* per_state,
+                             const float* replay_obs0, int64_t ring_start, int64_t ring_len, const int64_t* p_idx,
+                             const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
+                             int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
+                             float* iws_f32_out, void* stream) {
+    SAMX_REQUIRE(upd_td && per_state, "samx_per_row_prologue_td: null pointer");
+    PerRefresh rf{upd_td, alpha, demos_eps, num_demos, num_entries, (samx::PerState*)per_state};
+    return per_row_prologue_impl(sum_tree, min_tree, stamp, cap, upd_idx, nullptr, rf, n_upd, replay_obs0, ring_start,
+                                 ring_len, p_idx, pool_obs0, e_start, B, ob_dim, addvec, num_entries, u, beta,
+                                 idxs_out, iws_out, iws_f32_out, nullptr, nullptr, 0, 0, 0, stream);
 }
 
 int samx_to_host_pair(const float* a, float* a_host, const int64_t* b, int64_t* b_host, int64_t n, void* stream) {

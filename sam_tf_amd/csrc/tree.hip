@@ -5,6 +5,7 @@
 #include "tree_dev.h"
 #include "../../include/samx.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -132,6 +133,28 @@ __global__ __launch_bounds__(256) void per_sample_kernel(
                           blockIdx.x * (int64_t)256, 256);   // tree_dev.h
 }
 
+// the priority refresh on the device (memory.py:370-379 for the entries of one update)
+__global__ __launch_bounds__(kTreeThreads) void per_leaves_from_td_kernel(
+    const float* __restrict__ td, const int64_t* __restrict__ idxs, int n, int64_t cap, int64_t num_entries,
+    double alpha, int64_t num_demos, double demos_eps, double* __restrict__ leaf_out, samx::PerState* state) {
+    samx::leaves_from_td_body(td, idxs, n, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, state);
+}
+
+__global__ void pow_bits_kernel(const double* __restrict__ x, double y, int64_t n, double* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = samx_pow::pow_bits(x[i], y);
+}
+
+// every float32 base from bits lo on, widened (+ bonus): count of results that differ from `expect` is
+// not formed here - the device writes its results, the host compares (tests/test_gpu_pow.py)
+__global__ void pow_bits_f32_range_kernel(uint32_t lo, int64_t n, double bonus, double y, double* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float f = __uint_as_float(lo + (uint32_t)i);
+        out[i] = samx_pow::pow_bits(__dadd_rn((double)f, bonus), y);
+    }
+}
+
 int levels_of(int64_t cap) {
     int l = 0;
     while ((int64_t(1) << l) < cap) ++l;
@@ -239,6 +262,70 @@ int samx_per_leaf_values_host(const int64_t* idxs_host, const double* prios_host
     }
     *max_priority_host = mp;
     return SAMX_OK;
+}
+
+int samx_per_leaves_from_td(const float* td, const int64_t* idxs, int64_t n, int64_t cap, int64_t num_entries,
+                            double alpha, int64_t num_demos, double demos_eps, double* leaf_out,
+                            void* per_state, void* stream) {
+    SAMX_REQUIRE(td && idxs && leaf_out && per_state, "samx_per_leaves_from_td: null pointer");
+    SAMX_REQUIRE(n > 0 && n <= (1 << 24), "samx_per_leaves_from_td: batch %lld out of range", (long long)n);
+    SAMX_REQUIRE(cap > 0 && num_entries >= 0 && num_entries <= cap, "samx_per_leaves_from_td: bad cap / num_entries");
+    SAMX_REQUIRE(samx_pow::in_domain(1.0, alpha), "samx_per_leaves_from_td: alpha %g outside the pow domain", alpha);
+    per_leaves_from_td_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(
+        td, idxs, (int)n, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, (samx::PerState*)per_state);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_pow_device(const double* x, double y, int64_t n, double* out, void* stream) {
+    SAMX_REQUIRE(x && out && n > 0, "samx_pow_device: bad arguments");
+    pow_bits_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_pow_device_f32_range(uint32_t first_bits, int64_t n, double bonus, double y, double* out, void* stream) {
+    SAMX_REQUIRE(out && n > 0 && n <= (int64_t(1) << 31), "samx_pow_device_f32_range: bad arguments");
+    pow_bits_f32_range_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(first_bits, n, bonus, y, out);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_pow_host_f32_range(uint32_t first_bits, int64_t n, double bonus, double y, double* out_host) {
+    SAMX_REQUIRE(out_host && n > 0, "samx_pow_host_f32_range: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t u = first_bits + (uint32_t)i;
+        float f;
+        memcpy(&f, &u, 4);
+        out_host[i] = pow((double)f + bonus, y);   // the platform libm: what the reference's Python calls
+    }
+    return SAMX_OK;
+}
+
+int samx_pow_host(const double* x_host, double y, int64_t n, double* out_host) {
+    SAMX_REQUIRE(x_host && out_host && n > 0, "samx_pow_host: bad arguments");
+    for (int64_t i = 0; i < n; ++i) out_host[i] = pow(x_host[i], y);
+    return SAMX_OK;
+}
+
+int64_t samx_pow_selfcheck(int64_t n) {
+    // the HOST build of pow_bits against this machine's libm pow on n pseudo-random bases and the two usual
+    // exponent signs; a machine whose libm takes another code path (no FMA/AVX2, another glibc) shows up
+    // here as a non-zero count and the callers keep the host round trip
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    int64_t bad = 0;
+    const double ys[4] = {0.3, 0.6, -0.4, -1.0};
+    for (int64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const uint64_t ex = 1023 - 30 + (s >> 52) % 61;
+        const uint64_t u = (ex << 52) | ((s * 0x2545F4914F6CDD1Dull) & ((1ull << 52) - 1));
+        double x;
+        memcpy(&x, &u, 8);
+        const double y = ys[i & 3];
+        const double a = samx_pow::pow_bits(x, y), b = pow(x, y);
+        if (memcmp(&a, &b, 8) != 0) ++bad;
+    }
+    return bad;
 }
 
 int samx_per_leaves_from_td_host(const float* td_host, const int64_t* idxs_host, int64_t n,

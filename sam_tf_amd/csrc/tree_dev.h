@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include "pow_bits.h"
 
 namespace samx {
 
@@ -18,6 +19,65 @@ __device__ __forceinline__ double tree_op(int kind, double a, double b) {
 }
 
 
+// State words of a prioritized buffer kept on the device when the priority refresh runs there:
+// [0] max_priority (memory.py:379), [1] error bits as a double-sized word (bit 0: a priority that is not
+// positive, memory.py:371; bit 1: an index without an element behind it, memory.py:372).
+struct PerState {
+    double max_priority;
+    unsigned long long err;
+};
+
+// One entry of the priority refresh (sam_agent.py:702 -> memory.py:370-379): priority = |td| + 1e-6 in
+// float32, widened; the demonstration bonus; leaf = priority ** alpha with the bits of the host pow
+// (pow_bits.h).  Same arithmetic as samx_per_leaves_from_td_host.
+__device__ __forceinline__ double leaf_from_td(float td, int64_t idx, int64_t num_demos, double demos_eps,
+                                               double alpha, double* prio) {
+    const float p32 = __fadd_rn(fabsf(td), 1e-6f);
+    double p = (double)p32;
+    if (num_demos > 0 && idx < num_demos) p = __dadd_rn(p, demos_eps);
+    *prio = p;
+    return samx_pow::pow_bits(p, alpha);
+}
+
+// The refresh of n entries by one workgroup (every thread calls this; barrier inside): leaves -> leaf_out
+// (LDS or global), max_priority and the reference's two asserts -> state.  Entries whose index is outside
+// [0, cap) are the "nothing pending" marker and are skipped.
+__device__ __forceinline__ void leaves_from_td_body(const float* __restrict__ td, const int64_t* __restrict__ idxs,
+                                                    int n, int64_t cap, int64_t num_entries, double alpha,
+                                                    int64_t num_demos, double demos_eps, double* leaf_out,
+                                                    PerState* state) {
+    __shared__ double wmax[kTreeThreads / 64];
+    __shared__ unsigned werr[kTreeThreads / 64];
+    const int tid = threadIdx.x;
+    double mx = 0.0;
+    unsigned err = 0;
+    for (int i = tid; i < n; i += kTreeThreads) {
+        const int64_t idx = idxs[i];
+        if (idx < 0 || idx >= cap) { leaf_out[i] = 0.0; continue; }
+        double p;
+        leaf_out[i] = leaf_from_td(td[i], idx, num_demos, demos_eps, alpha, &p);
+        if (!(p > 0.0)) err |= 1u;
+        if (idx >= num_entries) err |= 2u;
+        if (p > mx) mx = p;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(mx, o, 64);
+        if (other > mx) mx = other;
+        err |= (unsigned)__shfl_xor((int)err, o, 64);
+    }
+    if ((tid & 63) == 0) { wmax[tid >> 6] = mx; werr[tid >> 6] = err; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kTreeThreads / 64; ++w) {
+            if (wmax[w] > mx) mx = wmax[w];
+            err |= werr[w];
+        }
+        if (mx > state->max_priority) state->max_priority = mx;
+        if (err) state->err |= err;
+    }
+    __syncthreads();
+}
+
 // One workgroup of kTreeThreads. Phase 1 elects, per distinct leaf, the LAST position in the batch (the
 // reference loop is sequential, so the last write survives); phase 2 writes the elected leaves; then every
 // level is recomputed bottom-up as value[2i] + value[2i+1] (or min), one barrier per level.
@@ -26,7 +86,7 @@ __device__ __forceinline__ double tree_op(int kind, double a, double b) {
 __device__ __forceinline__ void tree_set_body(double* __restrict__ s, double* __restrict__ m,
                                               int32_t* __restrict__ stamp, int64_t cap,
                                               const int64_t* __restrict__ idxs,
-                                              const double* __restrict__ leaf, int n, int levels) {
+                                              const double* leaf, int n, int levels) {
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += kTreeThreads) {
         int64_t idx = idxs[i];
@@ -196,13 +256,13 @@ __device__ __forceinline__ void per_sample_body(const double* __restrict__ sumv,
     const double piece = p_total / (double)B;
     const double n = (double)n_ent;
     const double lowest = lowest_p / total;
-    const double max_w = pow(__dmul_rn(n, lowest), -beta);
+    const double max_w = samx_pow::pow_bits(__dmul_rn(n, lowest), -beta);
     for (int64_t i = first + tid; i < B && i < first + span; i += 256) {
         const double s = __dadd_rn(__dmul_rn(u[i], piece), __dmul_rn((double)i, piece));
         const int64_t idx = prefix_descent(sumv, cap, s, top, top_n);
         idxs[i] = idx;
         const double prob = sumv[cap + idx] / total;
-        const double w = pow(__dmul_rn(n, prob), -beta) / max_w;
+        const double w = samx_pow::pow_bits(__dmul_rn(n, prob), -beta) / max_w;
         iws[i] = w;
         if (iws32) iws32[i] = (float)w;
     }

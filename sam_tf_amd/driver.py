@@ -75,7 +75,7 @@ class UpdateStepDriver(object):
     D, A = 1, 2   # role bits of a row
 
     def __init__(self, mu, d, expert_pool, use_graph=True, n_slots=4, steps_per_launch=16, d_steps=1, g_steps=1,
-                 window=None, pn_adapt_frequency=None):
+                 window=None, pn_adapt_frequency=None, per_host_pow=False):
         self.mu, self.d, self.pool = mu, d, expert_pool
         assert d_steps >= 1 and g_steps >= 1
         self.window = None if window is None else int(window)
@@ -101,6 +101,13 @@ class UpdateStepDriver(object):
         self.dev = dev
         self.per = bool(mu.hps.prioritized_replay)
         self.use_graph = bool(use_graph)
+        # PER, one process: the priority refresh (|td| + 1e-6 -> priority ** alpha, max_priority, the asserts;
+        # sam_agent.py:693-703 -> memory.py:370-379) stays ON THE DEVICE — its pow carries the host libm's bits
+        # (csrc/pow_bits.h), checked against this machine's libm when the driver is built.  Rows then need no
+        # host between them and are packed K per graph like uniform replay.  per_host_pow=True (or
+        # SAMX_PER_HOST_POW=1, or a libm the routine does not reproduce) keeps the host refresh of round 1.
+        self.per_dev = bool(self.per and self.comm.Get_size() == 1 and not per_host_pow and
+                            os.environ.get('SAMX_PER_HOST_POW', '0') != '1' and ops.pow_matches_host())
         # Several consecutive steps per graph launch: possible when nothing between two steps needs
         # the host — one process (no collective) and uniform replay (PER's priority refresh computes
         # p ** alpha with the host libm).  The host RNG draws of those steps are made up front, in the
@@ -114,7 +121,8 @@ class UpdateStepDriver(object):
         m = 1
         while 2 * m * self.S <= int(steps_per_launch):
             m *= 2
-        self.K = m * self.S if (self.use_graph and not self.per) else 1   # rows per launch: whole training steps
+        # rows per launch: whole training steps
+        self.K = m * self.S if (self.use_graph and (not self.per or self.per_dev)) else 1
         if self.world > 1 and not self.fused:
             self.K = 1   # layer-wise path under N > 1: the three-segment plan, one step per launch
         # N > 1 with a communicator whose all-reduce runs on the caller's stream (sam_tf_amd.rccl): the
@@ -144,6 +152,12 @@ class UpdateStepDriver(object):
         self.prev_idx = self.words[0, 3 * B + 1:4 * B + 1]
         self.prev_leaf = self.words[0, 4 * B + 1:].view(torch.float64)
         self._pending = None
+        if self.per_dev:   # the pending update in HBM: the indices and POST-update TD errors of the last agent row
+            self.pend_idx = torch.full((B,), -1, dtype=torch.int64, device=dev)   # -1: nothing pending
+            self.pend_td = torch.zeros(B, dtype=torch.float32, device=dev)
+            self.leaf_buf = torch.zeros(B, dtype=torch.float64, device=dev)
+            self.per_state = ops.make_per_state(rb.max_priority, dev)
+            self._dev_pending = False
         self.iws = torch.zeros(B, dtype=torch.float64, device=dev)
         self.iws32 = torch.zeros(B, **f32)
         hp = d.hps
@@ -161,7 +175,7 @@ class UpdateStepDriver(object):
         # PER, one process: the row's H2D upload and the D2H of the refreshed TD errors are nodes of the
         # captured graph (fixed pinned buffers; the host waits for every row anyway), which leaves ONE
         # host call — the graph launch — between two rows' host arithmetic
-        self.per_graph_io = bool(self.per and self.use_graph and self.world == 1)
+        self.per_graph_io = bool(self.per and self.use_graph and self.world == 1 and not self.per_dev)
         self._launch_words = torch.zeros(1, self.W, dtype=torch.int64).pin_memory()
         self._launch_np = self._launch_words.numpy()
         # the captured graph reads _launch_words asynchronously: this event, recorded behind every launch,
@@ -253,18 +267,33 @@ class UpdateStepDriver(object):
         return ((0 if role & self.D else 4) | (0 if role & self.A else 8),
                 (0 if role & self.D else 8) | (0 if role & self.A else 16))
 
-    def _seg_trees(self, role=3):
+    def _row_views(self, k):
+        """(idx_a, u) of row k inside the launch's words."""
+        B, w = self.B, self.words[k]
+        return w[B:2 * B], w[2 * B + 1:3 * B + 1].view(torch.float64)
+
+    def _per_td(self):
+        rb = self.mu.replay_buffer
+        return (self.pend_td, rb.alpha, rb.num_demos, rb.demos_eps, self.per_state)
+
+    def _seg_trees(self, role=3, k=0):
         """PER: the pending priority update, then memory.py:248-309 on the device trees."""
         mu = self.mu
         if self.per and role & self.A:
-            mu.replay_buffer.trees.set(self.prev_idx, self.prev_leaf)
-            mu.replay_buffer.trees.per_sample(mu.replay_buffer.num_entries, self.u, mu.hps.beta,
-                                              idxs_out=self.idx_a, iws_out=self.iws,
-                                              iws32_out=self.iws32)
+            rb = mu.replay_buffer
+            idx_a, u = self._row_views(k)
+            if self.per_dev:
+                ops.per_leaves_from_td(self.pend_td, self.pend_idx, rb.st_cap, rb.num_entries, rb.alpha, rb.num_demos,
+                                       rb.demos_eps, self.leaf_buf, self.per_state)
+                rb.trees.set(self.pend_idx, self.leaf_buf)
+            else:
+                rb.trees.set(self.prev_idx, self.prev_leaf)
+            rb.trees.per_sample(rb.num_entries, u, mu.hps.beta, idxs_out=idx_a, iws_out=self.iws,
+                                iws32_out=self.iws32)
 
     def _seg_targets(self, k=0, role=3):
         """N > 1 with PopArt: [PER sampling,] the target pass and the local return sums -> ret_addvec."""
-        self._seg_trees(role)
+        self._seg_trees(role, k)
         ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 16 | self._masks(role)[0])
 
     def _seg_grads(self, k=0, role=3, trees_done=False):
@@ -274,26 +303,29 @@ class UpdateStepDriver(object):
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
         split = self.popart_split and role & self.A   # _seg_targets + all-reduce(ret_addvec) came before
         if not trees_done and not split:
-            self._seg_trees(role)
+            self._seg_trees(role, k)
         ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0))
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
         ops.step_apply(self.L, self.B, (3 if self.world == 1 else 1) | mode, 1.0)
         if self.world == 1:
-            self._seg_refresh(role)
+            self._seg_refresh(role, k)
 
     def _seg_apply(self, role=3):
         ops.step_apply(self.L, self.B, 6 | self._masks(role)[1], 1.0 / self.world)
         self._seg_refresh(role)
 
-    def _seg_refresh(self, role=3):
+    def _seg_refresh(self, role=3, k=0):
         if self.per and role & self.A:  # TD errors with the POST-update critic (sam_agent.py:693-701), rows read in place
             mu = self.mu
             mean, std = mu._mean_std()
             st = mu.replay_buffer.store
             # (one process: the TD errors and the sampled indices also land in pinned host memory, for the
             # host's leaf arithmetic of the next priority update)
+            # (device refresh: they land in the pending-update buffers the next agent row's tree update reads)
             io = dict(td_host=self._td_host, idx_host=self._idx_host) if self.per_graph_io else {}
-            ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self.idx_a, self._batch_start,
+            if self.per_dev:
+                io = dict(td_host=self.pend_td, idx_host=self.pend_idx)
+            ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self._row_views(k)[0], self._batch_start,
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret, **io)
 
     def _grads_of(self, role):
@@ -358,6 +390,23 @@ class UpdateStepDriver(object):
                                          # (all but idx_a, which the sampling writes): no upload node
                                          upload=(self._launch_words.view(-1), self.words[0], self.B, self.B))
                     self._seg_grads(0, roles[0], trees_done=True)
+                elif self.per_dev:
+                    # rows chained on the device: row k's post-update TD errors are row k + 1's pending update
+                    pro = (self.inline_stats and self.B < 1024 and self.sums_small and
+                           all(r == self.D | self.A for r in roles if r & self.D))
+                    if any_d and not pro:
+                        self._seg_sums(K)
+                    for k in range(K):
+                        if pro and roles[k] == self.D | self.A:
+                            idx_a, u = self._row_views(k)
+                            ops.per_row_prologue(rb.trees, self.pend_idx, None, rb.store['obs0'], self._batch_start,
+                                                 self.words[k], self.B, self.pool.obs0, self.addvecs[k],
+                                                 sample=(rb.num_entries, u, self.mu.hps.beta, idx_a, self.iws,
+                                                         self.iws32), td=self._per_td())
+                            self._seg_grads(k, roles[k], trees_done=True)
+                        else:
+                            self._seg_inputs(k, roles[k])
+                            self._seg_grads(k, roles[k])
                 else:
                     if any_d:
                         self._seg_sums(K)
@@ -422,7 +471,7 @@ class UpdateStepDriver(object):
         self._fill_pending(slot, phase)
 
     def _fill_pending(self, slot, phase):
-        if self.per and self.sched[phase] & self.A:
+        if self.per and not self.per_dev and self.sched[phase] & self.A:
             if self._pending is None:
                 self._pending = self._noop_update()
             slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._pending
@@ -547,6 +596,21 @@ class UpdateStepDriver(object):
     def flush(self):
         """Apply the priority update still waiting for the next launch (call before reading the trees
         or sampling from the replay buffer outside the driver)."""
+        if self.per_dev:
+            if self._dev_pending:
+                rb = self.mu.replay_buffer
+                ops.per_leaves_from_td(self.pend_td, self.pend_idx, rb.st_cap, rb.num_entries, rb.alpha, rb.num_demos,
+                                       rb.demos_eps, self.leaf_buf, self.per_state)
+                rb.trees.set(self.pend_idx, self.leaf_buf)
+                self.pend_idx.fill_(-1)
+                self._dev_pending = False
+                # the reference's asserts and its max_priority, as the device tracked them (memory.py:371-379)
+                mp, err = self.per_state.cpu().numpy().view(np.uint64)
+                err = int(err)
+                assert not err & 1, "priorities must be positive"
+                assert not err & 2, "no element in buffer associated w/ index"
+                rb.max_priority = max(rb.max_priority, float(np.uint64(mp).view(np.float64)))
+            return
         if self._pending is not None:
             idxs, leaf = self._pending
             rb = self.mu.replay_buffer
@@ -581,6 +645,11 @@ class UpdateStepDriver(object):
             keep += [d.obs_rms.sums, d.obs_rms.mean, d.obs_rms.std]
         if mu.hps.rmsify_rets:
             keep += [mu.ret_rms.sums, mu.ret_rms.mean, mu.ret_rms.std]
+        if self.per_dev:
+            self.flush()   # the warm-up's first row then carries "nothing pending"
+            keep += [self.per_state]
+            if K > 1:      # ... its later rows apply the warm-up's own TD errors: the trees are put back
+                keep += [mu.replay_buffer.trees.sum, mu.replay_buffer.trees.min]
         saved = [t.clone() for t in keep]
         rng_np, rng_py = np.random.get_state(), _random.getstate()
         ptr0 = self.pool.pointer
@@ -591,9 +660,11 @@ class UpdateStepDriver(object):
         slot.np_idx[:K] = np.random.randint(low=0, high=mu.replay_buffer.num_entries, size=(K, 2, self.B))
         slot.np_e[:K] = 0
         if self.per:
-            slot.np_u[0] = mu.replay_buffer.draw_uniforms(self.B)
-            self.flush()
-            slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
+            for k in range(K):
+                slot.np_u[k] = mu.replay_buffer.draw_uniforms(self.B)
+            if not self.per_dev:
+                self.flush()
+                slot.np_prev_idx[0], slot.np_prev_leaf[0] = self._noop_update()
         self._upload(slot, K)
         torch.cuda.synchronize()   # nothing in flight reads _launch_words any more
         self._launch_busy = False
@@ -602,6 +673,8 @@ class UpdateStepDriver(object):
         torch.cuda.synchronize()
         for t, sv in zip(keep, saved):
             t.copy_(sv)
+        if self.per_dev:
+            self.pend_idx.fill_(-1)   # the warm-up rows' TD errors are not an update of anything
         np.random.set_state(rng_np)
         _random.setstate(rng_py)
         self.pool.pointer = ptr0
@@ -643,7 +716,10 @@ class UpdateStepDriver(object):
         if self.per_graph_io:
             self._launch_event.record()
             self._launch_busy = True
-        if self.per:
+        if self.per_dev:
+            if any(r & self.A for r in self._roles(K, phase)):
+                self._dev_pending = True
+        elif self.per:
             refresh = bool(role & self.A)
             if refresh and not self.per_graph_io:
                 self._td_host.copy_(self.td_post, non_blocking=True)

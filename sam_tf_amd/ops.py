@@ -115,6 +115,41 @@ def per_leaves_from_td_host(td, idxs, num_entries, alpha, num_demos, demos_eps, 
     return mp.value
 
 
+_POW_OK = None
+
+
+def pow_matches_host(n=200000):
+    """True when the library's pow routine reproduces THIS machine's libm pow bit for bit on n host-side
+    cases (samx_pow_selfcheck) — the condition for keeping the priority refresh on the device."""
+    global _POW_OK
+    if _POW_OK is None:
+        _POW_OK = int(_L().samx_pow_selfcheck(int(n))) == 0
+    return _POW_OK
+
+
+def pow_device(x, y):
+    """x float64 device tensor -> x ** y with the host pow's bits (samx_pow_device)."""
+    _chk(x, F64, (x.numel(),), 'x')
+    out = torch.empty_like(x)
+    check(_L().samx_pow_device(ptr(x), float(y), x.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+def make_per_state(max_priority, device='cuda'):
+    """The 16 state bytes of samx_per_leaves_from_td: [max_priority, error bits] as two float64 words."""
+    st = torch.zeros(2, dtype=F64, device=device)
+    st[0] = float(max_priority)
+    return st
+
+
+def per_leaves_from_td(td, idxs, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, state):
+    n = td.numel()
+    _chk(td, F32, (n,), 'td'); _chk(idxs, I64, (n,), 'idxs'); _chk(leaf_out, F64, (n,), 'leaf_out')
+    _chk(state, F64, (2,), 'state')
+    check(_L().samx_per_leaves_from_td(ptr(td), ptr(idxs), n, int(cap), int(num_entries), float(alpha),
+                                       int(num_demos), float(demos_eps), ptr(leaf_out), ptr(state), stream_ptr()))
+
+
 # ------------------------------------------------------------------ replay rows
 
 def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None):
@@ -335,7 +370,9 @@ def td_errors_rows(dc, pc, obs0_store, acs_store, idx, ring_start, tc1s, mean, s
     """TD errors of the batch rows addressed in place in the replay storages (idx int64[B]).  td_host /
     idx_host: pinned host tensors that receive copies of the TD errors and of idx from the same launch."""
     if td_host is not None:
-        assert idx_host is not None and td_host.is_pinned() and idx_host.is_pinned()
+        # pinned host memory (the host refresh) or device memory (the device refresh): the kernel just stores
+        assert idx_host is not None and (td_host.is_pinned() or td_host.is_cuda) and \
+            (idx_host.is_pinned() or idx_host.is_cuda)
         assert td_host.dtype == F32 and idx_host.dtype == I64 and td_host.numel() == idx.numel() == idx_host.numel()
     B = idx.numel()
     ring_len, ob = obs0_store.shape
@@ -610,14 +647,33 @@ def d_input_sums_many(replay_obs0, ring_start, words, B, pool_obs0, addvecs):
 
 
 def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_row, B, pool_obs0, addvec,
-                     sample=None, upload=None):
+                     sample=None, upload=None, td=None):
     """Pending priority update (trees.set) + the row's D-input sums in one launch (samx_per_row_prologue).
     words_row: int64 [W] with idx_p at [:B] and e_start at [2B]; addvec: float64 [2*ob+1].
     sample = (num_entries, u f64[B], beta, idxs_out i64[B], iws_out f64[B], iws32_out f32[B] or None): the
     row's stratified sample on the updated trees in the same launch.  upload = (pinned int64 host tensor,
     device int64 tensor of the same size, skip_lo, skip_n): copied host -> device by the kernel before it reads
     anything, except words [skip_lo, skip_lo + skip_n) (where idxs_out may live); the other arguments may be
-    views of the device tensor."""
+    views of the device tensor.
+    td = (upd_td f32[n], alpha, num_demos, demos_eps, state f64[2]) instead of upd_leaf: the pending update as TD
+    errors, refreshed on the device (samx_per_row_prologue_td; no upload)."""
+    if td is not None:
+        assert upload is None and upd_leaf is None
+        upd_td, alpha, num_demos, demos_eps, state = td
+        ring_len, ob = replay_obs0.shape
+        n = upd_idx.numel()
+        _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_td, F32, (n,), 'upd_td'); _chk(state, F64, (2,), 'state')
+        _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+        n_ent, u, beta, idxs_out, iws_out, iws32_out = sample
+        _chk(u, F64, (B,), 'u'); _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out')
+        _opt(iws32_out, F32, (B,), 'iws32_out')
+        check(_L().samx_per_row_prologue_td(
+            ptr(trees.sum), ptr(trees.min), ptr(trees.stamp), trees.cap, ptr(upd_idx), ptr(upd_td), n, float(alpha),
+            int(num_demos), float(demos_eps), ptr(state), ptr(replay_obs0), int(ring_start), int(ring_len),
+            C.c_void_p(words_row.data_ptr()), ptr(pool_obs0), C.c_void_p(words_row.data_ptr() + 8 * 2 * B), int(B),
+            int(ob), ptr(addvec), int(n_ent), ptr(u), float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out),
+            stream_ptr()))
+        return
     src = dst = None
     n_copy = skip_lo = skip_n = 0
     if upload is not None:

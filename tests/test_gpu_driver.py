@@ -416,7 +416,7 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
     for mode in ('single', 'packed'):
         mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
-        assert drv.K == (1 if cfg['per'] else 4)   # PER: one step per launch, host draws made ahead
+        assert drv.K == 4   # PER too: the priority refresh stays on the device, rows chain inside the graph
         drv.prepare(1); drv.prepare(drv.K)
         np.random.seed(77); random.seed(77)
         # the expert pool wraps (host reshuffle, np.random) after 6 of the 11 steps
@@ -637,8 +637,10 @@ def test_schedule_packed_launch_equals_single_rows():
         assert torch.equal(a.cpu(), b.cpu())
 
 
-def test_per_d_only_rows_run_equals_step():
-    """Prioritized replay with d_steps = 2, g_steps = 1: the D-only row does not end in a host wait, so
+@pytest.mark.parametrize('host_pow', [True, False])
+def test_per_d_only_rows_run_equals_step(host_pow):
+    """(host_pow False: the priority refresh on the device, rows packed K per graph; True: round 1's host
+    refresh, one row per launch.)  Prioritized replay with d_steps = 2, g_steps = 1: the D-only row does not end in a host wait, so
     the next launch must not overwrite the pinned launch words while the previous graph may still read
     them.  run(n) — launches back to back — must leave the learner and the trees bit-identical
     to n x step(), which synchronises after every row."""
@@ -649,8 +651,9 @@ def test_per_d_only_rows_run_equals_step():
     states = []
     for mode in ('single', 'run'):
         mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
-        drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=2, g_steps=1)
-        assert drv.sched == [1, 3] and drv.K == 1 and drv.per_graph_io
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=2, g_steps=1, per_host_pow=host_pow)
+        assert drv.sched == [1, 3]
+        assert (drv.K == 1 and drv.per_graph_io) if host_pow else (drv.K == 16 and drv.per_dev)
         drv.prepare_all()
         np.random.seed(81); random.seed(81)
         pool.pointer = 0
@@ -669,6 +672,37 @@ def test_per_d_only_rows_run_equals_step():
     assert int(states[0][4][0].item()) == 7 and int(states[0][4][2].item()) == 14
     for a, b in zip(*states):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize('cfg_name,g_steps', [('C3', 1), ('C3', 3), ('bigBper', 1), ('raggedper', 2)])
+def test_device_priority_refresh_equals_host_refresh(cfg_name, g_steps):
+    """The same n rows with the priority refresh on the device (rows packed K per captured graph, pow with the
+    host libm's bits) and with round 1's host refresh (one row per launch, libm pow on the host): learner,
+    optimiser state, both trees, max_priority and the host generators bit for bit."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    extra = {'bigBper': dict(ob=17, ac=6, h=(64, 64), B=512, per=True, name='big-batch-per'),
+             'raggedper': dict(ob=5, ac=2, h=(33, 70), B=37, per=True, name='ragged-per')}
+    cfg = dict(extra.get(cfg_name) or bench.CONFIGS[cfg_name], mem=4096)
+    states = []
+    for host_pow in (True, False):
+        mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, d_steps=1, g_steps=g_steps, per_host_pow=host_pow)
+        assert drv.per_dev == (not host_pow) and (drv.K == 1) == host_pow
+        drv.prepare_all()
+        np.random.seed(82); random.seed(82)
+        pool.pointer = 0
+        drv.run(5 * drv.S + drv.S * 16)   # one full-size launch, smaller ones and a flush in between
+        drv.run(2 * drv.S)
+        torch.cuda.synchronize()
+        rb = mu.replay_buffer
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps, d.obs_rms.sums,
+                                           rb.trees.sum, rb.trees.min]] +
+                      [torch.tensor([rb.max_priority], dtype=torch.float64),
+                       torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([random.random()])])
+    for i, (a, b) in enumerate(zip(*states)):
+        assert torch.equal(a.cpu(), b.cpu()), i
 
 
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-retn'])

@@ -1,6 +1,7 @@
 """HIP replay / segment-tree kernels vs the golden vectors recorded from the reference and vs the
-C oracle at full capacity.  Bit-exact for indices, tree nodes and sums (tolerance: none); IS
-weights use the device pow and are held to 1e-13 relative (include/samx.h, samx_per_sample)."""
+C oracle at full capacity.  Bit-exact for indices, tree nodes, sums AND the importance
+weights (tolerance: none): their pows go through the device routine that carries the host pow's bits
+(csrc/pow_bits.h, tests/test_gpu_pow.py)."""
 import os
 import random
 
@@ -61,7 +62,7 @@ def test_per_golden(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, name + '.npz'))
     rb = RC.run_per_fixture(
         fx, lambda limit, ob, ac, alpha, beta: PrioritizedRB(limit, (ob,), (ac,), alpha, beta),
-        iws_exact=False)
+        iws_exact=True)
     assert np.array_equal(rb.store['obs0'].cpu().numpy(), fx['final_obs0'])
     assert np.array_equal(rb.store['rews'].cpu().numpy().ravel(), fx['final_rews'].ravel())
     assert rb.start == int(fx['final_start']) and rb.length == int(fx['final_length'])
@@ -94,7 +95,7 @@ def test_per_full_capacity_vs_c_oracle(cap_log2, B):
         ic, wc = ct.per_sample(n, u, 1.0)
         idd, wd = dt.per_sample(n, torch.as_tensor(u).cuda(), 1.0)
         assert np.array_equal(ic, idd.cpu().numpy()), 'round %d idxs' % r
-        np.testing.assert_allclose(wd.cpu().numpy(), wc, rtol=1e-13)
+        assert np.array_equal(wd.cpu().numpy(), wc), 'round %d importance weights' % r
         # heavy-tailed priorities make later rounds revisit the same leaves -> duplicates
         pr = np.abs(rs.standard_cauchy(B)) + 1e-6
         if B > 1:
@@ -243,7 +244,7 @@ def test_random_op_sequences_vs_oracle(limit, n_demos, seed):
     """Random sequences of append / sample / sample_uniform / update_priorities (duplicate indices, demo
     rows, priorities over several orders of magnitude, ring wrap-around, non-power-of-two limits) on the HIP
     PrioritizedRB and on the oracle (pinned on the reference's vectors) side by side: indices, both trees,
-    range sums / minima and max_priority bit for bit after every operation; IS weights to 1e-13."""
+    range sums / minima, max_priority and the importance weights bit for bit after every operation."""
     from oracle.replay_oracle import PrioritizedReplayOracle
     from sam_tf_amd.memory import PrioritizedRB
     ob, ac = 3, 2
@@ -282,7 +283,7 @@ def test_random_op_sequences_vs_oracle(limit, n_demos, seed):
             random.seed(1000 * seed + step); a = hip.sample(B)
             random.seed(1000 * seed + step); b = ref.sample(B)
             assert np.array_equal(np.asarray(a['idxs'], dtype=np.int64), np.asarray(b['idxs'], dtype=np.int64)), step
-            np.testing.assert_allclose(np.asarray(a['iws'], dtype=np.float64).ravel(), b['iws'].ravel(), rtol=1e-13)
+            assert np.array_equal(np.asarray(a['iws'], dtype=np.float64).ravel(), b['iws'].ravel()), step
             assert np.array_equal(np.asarray(a['obs0']), b['obs0']) and np.array_equal(np.asarray(a['rews']), b['rews'])
             # priorities over many orders of magnitude, with duplicate indices
             idxs = np.asarray(b['idxs'], dtype=np.int64)

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['SAMX_PER_HOST_POW'] = '1'   # this tool times the HOST refresh (the device refresh has no host part)
 import bench  # noqa: E402
 from sam_tf_amd.comm import TorchComm  # noqa: E402
 
