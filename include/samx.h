@@ -468,7 +468,11 @@ int samx_per_row_prologue(double* sum_tree, double* min_tree, int32_t* stamp, in
 /* samx_per_row_prologue with the pending update given as TD ERRORS (upd_td float32[n_upd], HBM): workgroup 0
  * first runs the refresh of samx_per_leaves_from_td on them (leaves kept in LDS, per_state updated), then
  * goes on as above.  No upload words: every input already lives in HBM, so consecutive prioritized rows can
- * sit in one captured graph (sam_agent.py:693-703 of row k feeding memory.py:266-309 of row k + 1). */
+ * sit in one captured graph (sam_agent.py:693-703 of row k feeding memory.py:266-309 of row k + 1).
+ * With u != NULL and cap <= 2^30 the work is spread over more of the chip in two launches: 16 subtree
+ * workgroups refresh + rebuild the levels below the top 12 (one more adds the D-input sums), then B/32
+ * workgroups each rebuild the top 12 levels in LDS and draw their share of the row's samples.
+ * replay_obs0 == NULL: no D-input sums here (the caller computed them at the head of its launch). */
 int samx_per_row_prologue_td(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
                              const int64_t* upd_idx, const float* upd_td, int64_t n_upd, double alpha,
                              int64_t num_demos, double demos_eps, void* per_state,

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
     const int64_t* __restrict__ e_start, int64_t B, int dim, int dimpad, double* __restrict__ addvec,
     int64_t n_ent, const double* __restrict__ u, double beta, int64_t* __restrict__ idxs_out,
     double* __restrict__ iws_out, float* __restrict__ iws32_out, const int64_t* __restrict__ copy_src,
-    int64_t* copy_dst, int64_t copy_n, int64_t skip_lo, int64_t skip_n, PerRefresh rf) {
+    int64_t* copy_dst, int64_t copy_n, int64_t skip_lo, int64_t skip_n, PerRefresh rf, int fast) {
     if (copy_src) {
         // the row's host-drawn words (pinned host memory) -> their device home, by BOTH workgroups (same
         // values to the same addresses; each then reads what it wrote itself): no separate upload node.
@@ -302,22 +302,64 @@ __global__ __launch_bounds__(1024) void per_row_prologue_kernel(
         __syncthreads();
     }
     if (blockIdx.x == 0) {
-        extern __shared__ double leaf_sh[];   // this workgroup's use of the launch's dynamic LDS (n_upd < 1024)
+        // this workgroup's use of the launch's dynamic LDS (n_upd < 1024): the leaves, and with `fast` the
+        // whole working set of the tree update (tree_dev.h: FastLds)
+        extern __shared__ double leaf_sh[];
+        samx::FastLds& F = *reinterpret_cast<samx::FastLds*>(leaf_sh);
+        double* leaf_lds = fast ? F.cs : leaf_sh;
         const double* leaf = upd_leaf;
         if (rf.td) {
             samx::leaves_from_td_body(rf.td, upd_idx, n_upd, cap, rf.num_entries, rf.alpha, rf.num_demos,
-                                      rf.demos_eps, leaf_sh, rf.state);
-            leaf = leaf_sh;
+                                      rf.demos_eps, leaf_lds, rf.state);
+            leaf = leaf_lds;
         }
-        samx::tree_set_body(ts, tm, stamp, cap, upd_idx, leaf, n_upd, levels);
+        if (fast) samx::tree_set_fast_body(ts, tm, cap, upd_idx, leaf, n_upd, levels, F);
+        else samx::tree_set_body(ts, tm, stamp, cap, upd_idx, leaf, n_upd, levels);
         if (u) {   // ... and, on the updated trees, this row's stratified sample (memory.py:266-309)
             __syncthreads();
-            samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, 0, B);
+            if (fast)
+                samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, 0, B, F.top_s,
+                                      2 * cap < samx::kFastTop ? 2 * cap : samx::kFastTop);
+            else
+                samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, 0, B);
         }
     } else {
         d_input_stats_body(0, replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, dim, dimpad, addvec,
                            0, nullptr, nullptr, nullptr, 0, 0);
     }
+}
+
+// The same head of a prioritized row in TWO launches that fill more of the chip (tree_dev.h: "spread over
+// several workgroups").  Launch 1: G subtree workgroups refresh + walk the lower levels, one more workgroup
+// adds the row's D-input sums.  Launch 2: S workgroups each rebuild the top in LDS (workgroup 0 stores it)
+// and draw B / S of the row's samples.
+__global__ __launch_bounds__(1024) void per_refresh_walk_kernel(
+    double* __restrict__ ts, double* __restrict__ tm, int64_t cap, const int64_t* __restrict__ upd_idx, int n_upd,
+    int levels, PerRefresh rf, int G, const float* __restrict__ replay_obs0, int64_t ring_start, int64_t ring_len,
+    const int64_t* __restrict__ p_idx, const float* __restrict__ pool_obs0, const int64_t* __restrict__ e_start,
+    int64_t B, int dim, int dimpad, double* __restrict__ addvec) {
+    extern __shared__ double walk_lds[];
+    if ((int)blockIdx.x < G) {
+        const int64_t sub = cap / G, lo = (int64_t)blockIdx.x * sub;
+        samx::tree_walk_sub_body(ts, tm, cap, upd_idx, rf.td, n_upd, levels, lo, lo + sub, rf.num_entries, rf.alpha,
+                                 rf.num_demos, rf.demos_eps, rf.state, *reinterpret_cast<samx::WalkLds*>(walk_lds));
+    } else {
+        d_input_stats_body(0, replay_obs0, ring_start, ring_len, p_idx, pool_obs0, e_start, B, dim, dimpad, addvec,
+                           0, nullptr, nullptr, nullptr, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(1024) void per_top_sample_kernel(
+    double* __restrict__ ts, double* __restrict__ tm, int64_t cap, int levels, int64_t n_ent,
+    const double* __restrict__ u, int64_t B, double beta, int64_t* __restrict__ idxs_out,
+    double* __restrict__ iws_out, float* __restrict__ iws32_out, int64_t per) {
+    extern __shared__ double top_lds[];   // [2][kFastTop]
+    double* top_s = top_lds;
+    double* top_m = top_lds + samx::kFastTop;
+    samx::tree_top_body(ts, tm, cap, levels, top_s, top_m, blockIdx.x == 0);
+    const int64_t topn = 2 * (cap >> samx::fast_lb(levels));
+    samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, blockIdx.x * per, per, top_s,
+                          topn, top_m);
 }
 
 // two device arrays -> pinned host memory in one launch (the TD errors and sampled indices a PER row
@@ -549,8 +591,10 @@ static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* st
                  (long long)cap);
     SAMX_REQUIRE(n_upd > 0 && n_upd < 1024, "samx_per_row_prologue: 1..1023 priority updates (got %lld)",
                  (long long)n_upd);
-    SAMX_REQUIRE(replay_obs0 && pool_obs0 && addvec && B > 0 && ob_dim > 0, "samx_per_row_prologue: bad arguments");
-    SAMX_REQUIRE(2 * B * (int64_t)ob_dim <= 16384, "samx_per_row_prologue: batch too large (2*B*ob = %lld)",
+    const bool sums = replay_obs0 != nullptr;   // (the TD form may leave the D-input sums to the launch head)
+    SAMX_REQUIRE(B > 0 && (sums ? (pool_obs0 && addvec && ob_dim > 0) : (rf.td != nullptr && u != nullptr)),
+                 "samx_per_row_prologue: bad arguments");
+    SAMX_REQUIRE(!sums || 2 * B * (int64_t)ob_dim <= 16384, "samx_per_row_prologue: batch too large (2*B*ob = %lld)",
                  (long long)(2 * B * ob_dim));
     SAMX_REQUIRE(!p_idx || (ring_len > 0 && ring_start >= 0 && ring_start < ring_len),
                  "samx_per_row_prologue: bad ring geometry");
@@ -566,10 +610,33 @@ static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* st
     while ((int64_t(1) << levels) < cap) ++levels;
     int dimpad = 1;
     while (dimpad < ob_dim) dimpad *= 2;
-    per_row_prologue_kernel<<<2, 1024, 2 * 1024 * sizeof(double), (hipStream_t)stream>>>(
+    if (rf.td && u && cap <= (int64_t(1) << 30)) {
+        int G = 16;
+        while (G > 1 && (cap / G) < (int64_t(1) << samx::fast_lb(levels))) G /= 2;
+        while (G > cap) G /= 2;
+        per_refresh_walk_kernel<<<G + (sums ? 1 : 0), 1024, sizeof(samx::WalkLds), (hipStream_t)stream>>>(
+            sum_tree, min_tree, cap, upd_idx, (int)n_upd, levels, rf, G, replay_obs0, ring_start, ring_len, p_idx,
+            pool_obs0, e_start, B, ob_dim, dimpad, addvec);
+        SAMX_LAUNCH_CHECK();
+        int S = (int)((B + 31) / 32);
+        if (S > 16) S = 16;
+        const int64_t per = (B + S - 1) / S;
+        const size_t lds2 = 2 * samx::kFastTop * sizeof(double);
+        static LdsGrant grant2;
+        if (int rc = grant2.ensure((const void*)per_top_sample_kernel, lds2)) return rc;
+        per_top_sample_kernel<<<S, 1024, lds2, (hipStream_t)stream>>>(sum_tree, min_tree, cap, levels, num_entries, u,
+                                                                     B, beta, idxs_out, iws_out, iws_f32_out, per);
+        SAMX_LAUNCH_CHECK();
+        return SAMX_OK;
+    }
+    const int fast = cap <= (int64_t(1) << 30) ? 1 : 0;   // n_upd < 1024 was required above (tree_set_fast_ok)
+    const size_t lds = fast ? sizeof(samx::FastLds) : 2 * 1024 * sizeof(double);
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)per_row_prologue_kernel, lds, 64 * 1024)) return rc;
+    per_row_prologue_kernel<<<2, 1024, lds, (hipStream_t)stream>>>(
         sum_tree, min_tree, stamp, cap, upd_idx, upd_leaf, (int)n_upd, levels, replay_obs0, ring_start, ring_len,
         p_idx, pool_obs0, e_start, B, ob_dim, dimpad, addvec, num_entries, u, beta, idxs_out, iws_out, iws_f32_out,
-        copy_src, copy_dst, copy_n, copy_skip_lo, copy_skip_n, rf);
+        copy_src, copy_dst, copy_n, copy_skip_lo, copy_skip_n, rf, fast);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

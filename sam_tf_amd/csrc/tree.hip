@@ -34,6 +34,15 @@ __global__ __launch_bounds__(kTreeThreads) void tree_set_kernel(double* __restri
     samx::tree_set_body(s, m, stamp, cap, idxs, leaf, n, levels);   // tree_dev.h
 }
 
+// n < 1024: the update whose dependent chain runs in LDS (tree_dev.h: tree_set_fast_body)
+__global__ __launch_bounds__(kTreeThreads) void tree_set_fast_kernel(double* __restrict__ s, double* __restrict__ m,
+                                                                     int64_t cap, const int64_t* __restrict__ idxs,
+                                                                     const double* __restrict__ leaf, int n,
+                                                                     int levels) {
+    extern __shared__ double fast_lds[];
+    samx::tree_set_fast_body(s, m, cap, idxs, leaf, n, levels, *reinterpret_cast<samx::FastLds*>(fast_lds));
+}
+
 // Large batches (C5: 8192 updates into a 2^22 tree): one workgroup is bound by the number of random
 // 8-byte accesses a single CU can keep in flight (8192 x 4 loads per level, 22 levels: ~460 us measured).
 // Split by SUBTREE instead: workgroup g owns the leaves [g * cap/G, (g+1) * cap/G) and every internal
@@ -193,6 +202,14 @@ int samx_tree_set(double* sum_tree, double* min_tree, int32_t* stamp, int64_t ca
         SAMX_LAUNCH_CHECK();
         tree_set_top_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(sum_tree, min_tree, cap, levels - top,
                                                                         levels);
+        SAMX_LAUNCH_CHECK();
+        return SAMX_OK;
+    }
+    if (n < kTreeThreads && cap <= (int64_t(1) << 30)) {
+        static samx::LdsGrant grant;
+        if (int rc = grant.ensure((const void*)tree_set_fast_kernel, sizeof(samx::FastLds), 64 * 1024)) return rc;
+        tree_set_fast_kernel<<<1, kTreeThreads, sizeof(samx::FastLds), (hipStream_t)stream>>>(
+            sum_tree, min_tree, cap, idxs, leaf, (int)n, levels);
         SAMX_LAUNCH_CHECK();
         return SAMX_OK;
     }

@@ -392,17 +392,19 @@ class UpdateStepDriver(object):
                     self._seg_grads(0, roles[0], trees_done=True)
                 elif self.per_dev:
                     # rows chained on the device: row k's post-update TD errors are row k + 1's pending update
-                    pro = (self.inline_stats and self.B < 1024 and self.sums_small and
-                           all(r == self.D | self.A for r in roles if r & self.D))
-                    if any_d and not pro:
+                    # (the D-input sums of all K rows come from one launch at the head, as with uniform replay:
+                    # they depend on host-drawn indices only)
+                    if any_d:
                         self._seg_sums(K)
                     for k in range(K):
-                        if pro and roles[k] == self.D | self.A:
+                        if self.B < 1024 and roles[k] & self.A:
+                            # refresh + tree update + this row's stratified sample (samx_per_row_prologue_td)
                             idx_a, u = self._row_views(k)
-                            ops.per_row_prologue(rb.trees, self.pend_idx, None, rb.store['obs0'], self._batch_start,
-                                                 self.words[k], self.B, self.pool.obs0, self.addvecs[k],
+                            ops.per_row_prologue(rb.trees, self.pend_idx, None, None, self._batch_start,
+                                                 self.words[k], self.B, None, None,
                                                  sample=(rb.num_entries, u, self.mu.hps.beta, idx_a, self.iws,
                                                          self.iws32), td=self._per_td())
+                            self._seg_inputs(k, roles[k])
                             self._seg_grads(k, roles[k], trees_done=True)
                         else:
                             self._seg_inputs(k, roles[k])

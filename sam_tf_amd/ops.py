@@ -660,17 +660,22 @@ def per_row_prologue(trees, upd_idx, upd_leaf, replay_obs0, ring_start, words_ro
     if td is not None:
         assert upload is None and upd_leaf is None
         upd_td, alpha, num_demos, demos_eps, state = td
-        ring_len, ob = replay_obs0.shape
         n = upd_idx.numel()
         _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_td, F32, (n,), 'upd_td'); _chk(state, F64, (2,), 'state')
-        _chk(addvec, F64, (2 * ob + 1,), 'addvec')
+        if replay_obs0 is None:   # no D-input sums in this launch
+            ring_len = ob = 0
+            pool_obs0 = addvec = None
+        else:
+            ring_len, ob = replay_obs0.shape
+            _chk(addvec, F64, (2 * ob + 1,), 'addvec')
         n_ent, u, beta, idxs_out, iws_out, iws32_out = sample
         _chk(u, F64, (B,), 'u'); _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out')
         _opt(iws32_out, F32, (B,), 'iws32_out')
         check(_L().samx_per_row_prologue_td(
             ptr(trees.sum), ptr(trees.min), ptr(trees.stamp), trees.cap, ptr(upd_idx), ptr(upd_td), n, float(alpha),
             int(num_demos), float(demos_eps), ptr(state), ptr(replay_obs0), int(ring_start), int(ring_len),
-            C.c_void_p(words_row.data_ptr()), ptr(pool_obs0), C.c_void_p(words_row.data_ptr() + 8 * 2 * B), int(B),
+            C.c_void_p(words_row.data_ptr()) if ob else None, ptr(pool_obs0),
+            C.c_void_p(words_row.data_ptr() + 8 * 2 * B) if ob else None, int(B),
             int(ob), ptr(addvec), int(n_ent), ptr(u), float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out),
             stream_ptr()))
         return
