@@ -700,10 +700,14 @@ class UpdateStepDriver(object):
         phase = self.step_no % self.S
         role = self.sched[phase]
         rb = self.mu.replay_buffer
-        if rb.start != self._batch_start or rb.num_entries != self._batch_entries:
+        if rb.start != self._batch_start or (rb.num_entries != self._batch_entries and
+                                             (self.per or self.mu.hps.n_step_returns)):
             # transitions were appended since the plans were captured (the ring start and the entry
             # count are baked into them): re-read the geometry and capture again
             self.refresh()
+        # (uniform replay without n-step returns: the entry count only bounds the HOST's index draws, which read
+        # it live — the captured graphs survive appends until the ring wraps and its start moves)
+        self._batch_entries = rb.num_entries
         self.prepare(K, phase)
         slot = self.slots[self.launch_no % len(self.slots)]
         self._draw(slot, K, phase)
