@@ -301,3 +301,70 @@ def test_random_op_sequences_vs_oracle(limit, n_demos, seed):
             lo = int(rs.randint(0, n)); hi = int(rs.randint(lo + 1, n + 1))   # [lo, hi): never empty
             assert hip.tree_sum(lo, hi) == ref.tree_sum(lo, hi) and hip.tree_min(lo, hi) == ref.tree_min(lo, hi)
         same_trees((step, op))
+
+
+@pytest.mark.parametrize('pattern', ['spread', 'one_subtree', 'siblings', 'dups', 'single', 'edges'])
+@pytest.mark.parametrize('cap_log2', [4, 6, 11, 12, 13, 17, 20])
+def test_row_head_from_td_errors_vs_c_oracle(cap_log2, pattern):
+    """samx_per_row_prologue_td (the prioritized row head of the device refresh: subtree workgroups walk the
+    lower levels in LDS, the sampling workgroups rebuild the top) and samx_tree_set's one-workgroup form of the
+    same walk, against oracle/per_tree.c: every node of both trees, the sampled indices, the importance weights,
+    max_priority — bit for bit.  Capacities on both sides of the 12 LDS levels; batches that land in ONE subtree
+    (one workgroup carries everything, several waves stay alive), on sibling leaves (both children touched at
+    every level), on the first/last leaves, with heavy duplication (last position wins), and of one entry."""
+    from oracle.per_tree_c import PerTreesC
+    from sam_tf_amd import ops
+    cap = 1 << cap_log2
+    n_ent = cap - 3
+    rs = np.random.RandomState(100 * cap_log2 + len(pattern))
+    ct = PerTreesC(cap)
+    dt = ops.DeviceTrees(cap)
+    # a populated tree: priorities over several orders of magnitude (host leaves on both sides)
+    max_c = max_d = 1.0
+    for lo in range(0, n_ent, 800):
+        ii = np.arange(lo, min(lo + 800, n_ent), dtype=np.int64)
+        pr = np.abs(rs.randn(ii.size)) * 10.0 ** rs.uniform(-3, 2, ii.size) + 1e-6
+        max_c = ct.per_update(ii, pr, 0.6, max_priority=max_c)
+        leaf, max_d = ops.per_leaf_values_host(ii, pr, 0.6, 0, 0.1, max_d)
+        dt.set(torch.as_tensor(ii).cuda(), torch.as_tensor(leaf).cuda())   # < 1024 entries: the one-workgroup walk
+    assert np.array_equal(dt.sum.cpu().numpy(), ct.sumv) and np.array_equal(dt.min.cpu().numpy(), ct.minv)
+    state = ops.make_per_state(max_d)
+    B = 64
+    idx_out = torch.empty(B, dtype=torch.int64, device='cuda')
+    iws = torch.empty(B, dtype=torch.float64, device='cuda')
+    iws32 = torch.empty(B, dtype=torch.float32, device='cuda')
+    dummy = torch.zeros(4, dtype=torch.int64, device='cuda')
+    for r in range(4):
+        n = {'single': 1, 'dups': 300}.get(pattern, [5, 64, 257, 1000][r])
+        n = min(n, 1023)
+        if pattern == 'spread':
+            idx = rs.randint(0, n_ent, n)
+        elif pattern == 'one_subtree':
+            w = max(2, cap // 16)
+            base = (r % 16) * w
+            idx = base + rs.randint(0, min(w, max(1, n_ent - base)), n)
+        elif pattern == 'siblings':
+            first = rs.randint(0, max(1, n_ent - n - 1))
+            idx = (first + np.arange(n)) % n_ent
+        elif pattern == 'dups':
+            idx = rs.randint(0, n_ent, 7)[rs.randint(0, 7, n)]
+        elif pattern == 'single':
+            idx = rs.randint(0, n_ent, 1)
+        else:
+            idx = np.concatenate([np.arange(min(3, n_ent)), n_ent - 1 - np.arange(min(3, n_ent))])[:max(1, min(n, 6))]
+        idx = idx.astype(np.int64)
+        td = (rs.standard_cauchy(idx.size) * 10.0 ** rs.uniform(-5, 2, idx.size)).astype(np.float32)
+        pr = (np.abs(td) + np.float32(1e-6)).astype(np.float64)      # sam_agent.py:702 in float32, then widened
+        max_c = ct.per_update(idx, pr, 0.6, max_priority=max_c)
+        u = rs.rand(B)
+        ic, wc = ct.per_sample(n_ent, u, 0.7)
+        ops.per_row_prologue(dt, torch.as_tensor(idx).cuda(), None, None, 0, dummy, B, None, None,
+                             sample=(n_ent, torch.as_tensor(u).cuda(), 0.7, idx_out, iws, iws32),
+                             td=(torch.as_tensor(td).cuda(), 0.6, 0, 0.0, state))
+        what = '%s cap 2^%d round %d' % (pattern, cap_log2, r)
+        assert np.array_equal(dt.sum.cpu().numpy(), ct.sumv), what
+        assert np.array_equal(dt.min.cpu().numpy(), ct.minv), what
+        assert np.array_equal(idx_out.cpu().numpy(), ic), what
+        assert np.array_equal(iws.cpu().numpy(), wc), what
+        st = state.cpu().numpy()
+        assert st[0] == max_c and st.view(np.uint64)[1] == 0, what
