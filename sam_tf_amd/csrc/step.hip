@@ -614,6 +614,8 @@ static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* st
         int G = 16;
         while (G > 1 && (cap / G) < (int64_t(1) << samx::fast_lb(levels))) G /= 2;
         while (G > cap) G /= 2;
+        static LdsGrant grant1;
+        if (int rc = grant1.ensure((const void*)per_refresh_walk_kernel, sizeof(samx::WalkLds))) return rc;
         per_refresh_walk_kernel<<<G + (sums ? 1 : 0), 1024, sizeof(samx::WalkLds), (hipStream_t)stream>>>(
             sum_tree, min_tree, cap, upd_idx, (int)n_upd, levels, rf, G, replay_obs0, ring_start, ring_len, p_idx,
             pool_obs0, e_start, B, ob_dim, dimpad, addvec);

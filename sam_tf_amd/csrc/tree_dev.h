@@ -311,10 +311,10 @@ __device__ __forceinline__ void tree_set_fast_body(double* __restrict__ s, doubl
 // that fits the top (tree_walk_sub_body); the workgroups of the NEXT launch each load that level (coalesced),
 // recompute the top densely in LDS (tree_top_body; workgroup 0 stores it) and sample on it.
 struct WalkLds {
-    double cs[kTreeThreads];
-    double cm[kTreeThreads];
+    double hs[2][kFastHash];   // the carried node's sum / min, stored IN the hash slot: a sibling lookup reads key and
+    double hm[2][kFastHash];   // values of the home slot in one round of LDS reads
     int hkey[2][kFastHash];
-    int hown[2][kFastHash];
+    int hown[2][kFastHash];    // (duplicates' table and the compaction list only)
 };
 
 __host__ __device__ __forceinline__ int fast_lb(int levels) {
@@ -409,33 +409,40 @@ __device__ __forceinline__ void tree_walk_sub_body(double* __restrict__ s, doubl
         // reader: with one or two waves left a sweep over all slots would cost more than the level itself)
         const int b = (l - 1) & 1;
         int myslot = -1;
+        if (l == 2) { SAMX_TREE_STAMP(19) }
         if (active) {
-            L.cs[tid] = vs;
-            L.cm[tid] = vm;
             slot = fast_hash(node);
             while (atomicCAS(&L.hkey[b][slot], -1, node) != -1) slot = (slot + 1) & (kFastHash - 1);
-            L.hown[b][slot] = tid;
+            L.hs[b][slot] = vs;
+            L.hm[b][slot] = vm;
             myslot = slot;
         }
+        if (l == 2) { SAMX_TREE_STAMP(15) }
         lds_bar();
+        if (l == 2) { SAMX_TREE_STAMP(16) }
         if (l == 1 && dslot >= 0) {   // the duplicates' table: every reader passed the barrier above
             L.hkey[1][dslot] = -1;
             L.hown[1][dslot] = -1;
         }
         if (active) {
             const int sn = node ^ 1;
-            int sl = fast_hash(sn), o = -1;
+            int sl = fast_hash(sn);
+            int k = L.hkey[b][sl];
+            double fs = L.hs[b][sl], fm = L.hm[b][sl];   // read with the key: the home slot is almost always the one
+            bool found = false;
             while (true) {
-                const int k = L.hkey[b][sl];
-                if (k == sn) { o = L.hown[b][sl]; break; }
+                if (k == sn) { found = true; break; }
                 if (k == -1) break;
                 sl = (sl + 1) & (kFastHash - 1);
+                k = L.hkey[b][sl];
+                fs = L.hs[b][sl];
+                fm = L.hm[b][sl];
             }
             const bool odd = node & 1;
-            if (o >= 0 && odd) {
+            if (found && odd) {
                 active = false;
             } else {
-                const double ss = o >= 0 ? L.cs[o] : old_s, sm = o >= 0 ? L.cm[o] : old_m;
+                const double ss = found ? fs : old_s, sm = found ? fm : old_m;
                 const double ls = odd ? ss : vs, rs = odd ? vs : ss, lm = odd ? sm : vm, rm = odd ? vm : sm;
                 vs = __dadd_rn(ls, rs);
                 vm = (rm < lm) ? rm : lm;
@@ -444,11 +451,10 @@ __device__ __forceinline__ void tree_walk_sub_body(double* __restrict__ s, doubl
                 m[node] = vm;
             }
         }
+        if (l == 2) { SAMX_TREE_STAMP(17) }
         lds_bar();
-        if (myslot >= 0) {
-            L.hkey[b][myslot] = -1;
-            L.hown[b][myslot] = -1;
-        }
+        if (l == 2) { SAMX_TREE_STAMP(18) }
+        if (myslot >= 0) L.hkey[b][myslot] = -1;
     };
 #define SAMX_TREE_LEVEL(LV) if (lb >= LV) level(LV, sib_s[LV - 1], sib_m[LV - 1]);
     SAMX_TREE_LEVEL(1) SAMX_TREE_LEVEL(2) SAMX_TREE_LEVEL(3) SAMX_TREE_LEVEL(4) SAMX_TREE_LEVEL(5)
@@ -596,8 +602,12 @@ constexpr int kTopNodes = 1 << kTopLevels;   // nodes 1 .. kTopNodes-1
 
 // find_prefixsum_idx (segment_tree.py:82-97): the top levels from LDS (`top`, valid when top_n > 0),
 // the rest from memory
+// leaf_val (optional): receives the value of the leaf found when the last memory round reached the leaves (its
+// odd siblings are loaded in that round too), *have_leaf says whether it did.
 __device__ __forceinline__ int64_t prefix_descent(const double* __restrict__ v, int64_t cap,
-                                                  double s, const double* top = nullptr, int64_t top_n = 0) {
+                                                  double s, const double* top = nullptr, int64_t top_n = 0,
+                                                  double* leaf_val = nullptr, bool* have_leaf = nullptr) {
+    if (have_leaf) *have_leaf = false;
     int64_t node = 1;
     while (2 * node < top_n) {
         const double left = top[2 * node];
@@ -619,6 +629,13 @@ __device__ __forceinline__ int64_t prefix_descent(const double* __restrict__ v, 
         double b[2] = {0.0, 0.0}, c[4] = {0.0, 0.0, 0.0, 0.0};
         if (l2) { b[0] = v[n4]; b[1] = v[n4 + 2]; }
         if (l3) { c[0] = v[n8]; c[1] = v[n8 + 2]; c[2] = v[n8 + 4]; c[3] = v[n8 + 6]; }
+        const bool last = leaf_val && (l3 ? n8 : l2 ? n4 : n2) >= cap;   // this round ends on the leaves
+        double o[4] = {0.0, 0.0, 0.0, 0.0};                               // ... then their odd members too
+        if (last) {
+            if (l3) { o[0] = v[n8 + 1]; o[1] = v[n8 + 3]; o[2] = v[n8 + 5]; o[3] = v[n8 + 7]; }
+            else if (l2) { o[0] = v[n4 + 1]; o[1] = v[n4 + 3]; }
+            else o[0] = v[n2 + 1];
+        }
         if (a > s) { node = n2; } else { s = __dadd_rn(s, -a); node = n2 + 1; }
         if (l2) {
             const double left = (node & 1) ? b[1] : b[0];
@@ -628,6 +645,17 @@ __device__ __forceinline__ int64_t prefix_descent(const double* __restrict__ v, 
             const int k = (int)(node & 3);
             const double left = k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3];
             if (left > s) { node = 2 * node; } else { s = __dadd_rn(s, -left); node = 2 * node + 1; }
+        }
+        if (last) {
+            const bool odd = node & 1;
+            const int k = (int)((node >> 1) & 3);
+            double val;
+            if (l3) val = odd ? (k == 0 ? o[0] : k == 1 ? o[1] : k == 2 ? o[2] : o[3])
+                              : (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]);
+            else if (l2) val = odd ? ((k & 1) ? o[1] : o[0]) : ((k & 1) ? b[1] : b[0]);
+            else val = odd ? o[0] : a;
+            *leaf_val = val;
+            *have_leaf = true;
         }
     }
     return node - cap;
@@ -676,9 +704,11 @@ __device__ __forceinline__ void per_sample_body(const double* __restrict__ sumv,
     const double max_w = samx_pow::pow_bits(__dmul_rn(n, lowest), -beta);
     for (int64_t i = first + tid; i < B && i < first + span; i += 256) {
         const double s = __dadd_rn(__dmul_rn(u[i], piece), __dmul_rn((double)i, piece));
-        const int64_t idx = prefix_descent(sumv, cap, s, top, top_n);
+        double lv = 0.0;
+        bool have = false;
+        const int64_t idx = prefix_descent(sumv, cap, s, top, top_n, &lv, &have);
         idxs[i] = idx;
-        const double prob = sumv[cap + idx] / total;
+        const double prob = (have ? lv : sumv[cap + idx]) / total;
         const double w = samx_pow::pow_bits(__dmul_rn(n, prob), -beta) / max_w;
         iws[i] = w;
         if (iws32) iws32[i] = (float)w;

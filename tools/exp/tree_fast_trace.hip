@@ -53,7 +53,8 @@ int main() {
         hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stamp), sizeof(t));
         printf("run %d: walk %.1f us top %.1f us; walk cycles:", r, ms1 * 1e3, ms2 * 1e3);
         for (int i = 8; i <= 14; ++i) printf(" [%d] %lld", i, t[i] - t[i - 1]);
-        printf(" ; top %lld\n", t[21] - t[20]);
+        printf(" ; top %lld ; level 2: insert %lld barA %lld lookup %lld barB %lld\n", t[21] - t[20], t[15] - t[19], t[16] - t[15],
+               t[17] - t[16], t[18] - t[17]);
     }
     return 0;
 }
