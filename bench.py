@@ -101,7 +101,8 @@ def build_learner(cfg, comm, device, seed, use_graph):
             rb.update_priorities(idx, np.abs(rs.randn(cfg['B'])) + 1e-6)
     drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph, d_steps=int(cfg.get('d_steps', 1)),
                            g_steps=int(cfg.get('g_steps', 1)), window=cfg.get('window'),
-                           pn_adapt_frequency=cfg.get('pn_adapt_frequency'))
+                           pn_adapt_frequency=cfg.get('pn_adapt_frequency'),
+                           steps_per_launch=int(os.environ.get('SAMX_STEPS_PER_LAUNCH', '32')))
     return mu, d, pool, drv
 
 
