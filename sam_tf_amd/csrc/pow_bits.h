@@ -10,7 +10,7 @@
 // resolver picks on every CPU with both, read from the disassembly of this image's libm).  Here every fma
 // is explicit and nothing else may contract.
 //
-// Proof is by test, not by reading: tools/exp/pow_check.c (CPU build of this header against libm's pow) and
+// Proof is by test, not by reading: tools/exp/pow_check.cpp (CPU build of this header against libm's pow) and
 // tests/test_gpu_pow.py (device against libm) compare >= 2^26 bases per exponent bit for bit.
 // Domain of the bit-for-bit claim: x positive and normal, 2^-65 <= |y| < 2^63, no overflow/underflow
 // (|y log x| < 512).  Outside it the routine defers to the platform pow (and the claim does not apply).
