@@ -102,7 +102,10 @@ def build_learner(cfg, comm, device, seed, use_graph):
     drv = UpdateStepDriver(mu, d, pool, use_graph=use_graph, d_steps=int(cfg.get('d_steps', 1)),
                            g_steps=int(cfg.get('g_steps', 1)), window=cfg.get('window'),
                            pn_adapt_frequency=cfg.get('pn_adapt_frequency'),
-                           steps_per_launch=int(os.environ.get('SAMX_STEPS_PER_LAUNCH', '32')))
+                           steps_per_launch=int(os.environ.get('SAMX_STEPS_PER_LAUNCH', 0)) or
+                           # about 100 kernel nodes per captured graph is the sweet spot measured on MI355X: 32 rows of the
+                           # 3-launch plain step, 16 rows of everything with more launches per row (C3: 6)
+                           (32 if not (cfg['per'] or cfg.get('ret') or cfg.get('nstep') or cfg.get('ln')) else 16))
     return mu, d, pool, drv
 
 

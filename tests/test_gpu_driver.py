@@ -786,7 +786,7 @@ def test_two_rank_plan_matches_oracle(cfg_name):
     mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
     fusable = base != 'ragged'   # LayerNorm (launcher options) included
     assert drv.world == 2 and drv.inline_stats == fusable and drv.popart_split == bool(opt)
-    assert drv.K == (32 if base == 'C1' and fusable else 1)   # uniform replay on the fused path packs K steps
+    assert drv.K == ((16 if opt else 32) if base == 'C1' and fusable else 1)   # uniform replay on the fused path packs K steps
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
     K = 4
