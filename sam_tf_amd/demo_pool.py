@@ -16,6 +16,15 @@ class DevicePairPool(object):
         self.num_entries = self.obs0.shape[0]
         assert self.acs.shape[0] == self.num_entries
         self.randomize = randomize
+        # the permutation travels through pinned staging (two buffers in turn, an event each) and is applied by
+        # stream-ordered device work: a reshuffle never makes the host wait for the launches already queued
+        self._stage = self._events = None
+        if self.device.type == 'cuda':
+            self._stage = [torch.empty(self.num_entries, dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._events = [torch.cuda.Event() for _ in range(2)]
+            self._idx_dev = torch.empty(self.num_entries, dtype=torch.int64, device=self.device)
+            self._tmp_obs, self._tmp_acs = torch.empty_like(self.obs0), torch.empty_like(self.acs)
+        self._turn = 0
         self.init_pointer()
 
     def init_pointer(self):
@@ -23,10 +32,23 @@ class DevicePairPool(object):
         if self.randomize:
             indices = np.arange(self.num_entries)
             np.random.shuffle(indices)  # same generator as the reference
-            idx = torch.as_tensor(indices).to(self.device)
             # permute in place: the storage address stays fixed (captured HIP graphs read it)
-            self.obs0.copy_(self.obs0.index_select(0, idx))
-            self.acs.copy_(self.acs.index_select(0, idx))
+            if self._stage is None:
+                idx = torch.as_tensor(indices).to(self.device)
+                self.obs0.copy_(self.obs0.index_select(0, idx))
+                self.acs.copy_(self.acs.index_select(0, idx))
+                return
+            t = self._turn % 2
+            if self._turn >= 2:
+                self._events[t].synchronize()   # the copy that read this staging buffer two reshuffles ago
+            self._stage[t].numpy()[:] = indices
+            self._idx_dev.copy_(self._stage[t], non_blocking=True)
+            self._events[t].record()
+            self._turn += 1
+            torch.index_select(self.obs0, 0, self._idx_dev, out=self._tmp_obs)
+            torch.index_select(self.acs, 0, self._idx_dev, out=self._tmp_acs)
+            self.obs0.copy_(self._tmp_obs)
+            self.acs.copy_(self._tmp_acs)
 
     def get_next_pair_batch_device(self, batch_size):
         if self.pointer + batch_size >= self.num_entries:

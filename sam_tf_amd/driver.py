@@ -691,6 +691,23 @@ class UpdateStepDriver(object):
             K //= 2
         for phase in range(self.S):
             self.prepare(1, phase)
+        for K in self._recurring_sizes():
+            self.prepare(K)
+
+    def _recurring_sizes(self):
+        """Launch sizes below K that run() meets again and again: the training steps left of an expert-pool epoch
+        after its full-size launches (an epoch starts with the training step that reshuffles), and of a
+        parameter-noise adaption period."""
+        S, Kt = self.S, self.K // self.S
+        out = set()
+        if Kt > 1:
+            per_step = self.nD * self.B
+            fit = (self.pool.num_entries - 1 - per_step) // per_step   # training steps after the reshuffling one
+            if fit % Kt:
+                out.add((fit % Kt) * S)
+            if self.pn_freq and self.pn_freq % Kt:
+                out.add((self.pn_freq % Kt) * S)
+        return sorted(k for k in out if k > 1 and (k, 0) not in self.plans)
 
     @property
     def plan(self):
@@ -767,10 +784,23 @@ class UpdateStepDriver(object):
             # the largest launch (K, K/2, ... whole training steps) that fits the rows left and ends before
             # the next reshuffle of the expert pool (host work between two rows, kept out of a launch)
             K = self.K if self.step_no % S == 0 else 1
-            while K > 1 and (K > n or K % S or
-                             pool.pointer + (K // S) * self.nD * B >= pool.num_entries or
-                             any(self._pn_due(t) for t in range(1, K // S))):   # a due adaption heads its launch
-                K = K // 2 if (K // 2) % S == 0 else 1
+            if K > 1:
+                # whole training steps that fit: the rows left, the expert pool before its next reshuffle, the
+                # training steps before the next due parameter-noise adaption (which heads its own launch)
+                T = min(K // S, n // S, max(0, (pool.num_entries - 1 - pool.pointer) // (self.nD * B)))
+                t_pn = next((t for t in range(1, T) if self._pn_due(t)), T)
+                T = min(T, t_pn)
+                exact = T * S
+                # the sizes that recur — what is left of an expert-pool epoch, of a parameter-noise period — have
+                # captured plans of their own (prepare_all): 32, 32, 32, 27 instead of 32, 32, 32, 16, 8, 2, 1.
+                # Sizes without a plan fall back to K/2, K/4, ...
+                if exact >= 1 and (exact == self.K or (exact, 0) in self.plans):
+                    K = exact
+                else:
+                    while K > 1 and (K > n or K % S or
+                                     pool.pointer + (K // S) * self.nD * B >= pool.num_entries or
+                                     any(self._pn_due(t) for t in range(1, K // S))):
+                        K = K // 2 if (K // 2) % S == 0 else 1
             self._launch(K, more=n > K)
             n -= K
         self.flush()
