@@ -287,6 +287,12 @@ def main():
     def timed():
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks."""
         drv.prepare_all()
+        # the sizes the two runs below end on get plans of their own, so that e.g. 20 timed steps are ONE launch of
+        # 20 rows and not 16 + 4 (capturing is not part of a step; run() only uses sizes that have a plan)
+        if os.environ.get('SAMX_BENCH_TAIL_PLANS', '1') != '0':
+            for k in sorted({args.steps % drv.K, args.warmup % drv.K}):
+                if k > 1 and k % drv.S == 0:
+                    drv.prepare(k)
         drv.run(args.warmup)
         torch.cuda.synchronize(); comm.Barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
