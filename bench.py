@@ -186,7 +186,7 @@ def cpu_baseline(cfg, budget_s=12.0, n_thread=True):
     return out
 
 
-OTHER_RUNS = (('C3', 600, 100), ('C4', 300, 50), ('C5', 40, 8))   # (config, steps, warm-up)
+OTHER_RUNS = (('C3', 2000, 200), ('C4', 600, 100), ('C5', 40, 8))   # (config, steps, warm-up)
 
 
 def other_configs(comm, device, args):
