@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 }
 
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
-__global__ __launch_bounds__(256 * KS) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void gemm_kernel(GemmArgs g) {
     gemm_tile<A_RC, B_RC, KS, A_W, B_W>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
