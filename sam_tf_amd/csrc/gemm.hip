@@ -582,7 +582,13 @@ int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const S
 
 int pick_nsplit(int Mo, int N, int R) {
     int tiles = cdiv(Mo, BM) * cdiv(N, BN);
-    int want = 512 / tiles;  // two workgroups per CU (1024 and 768 measured the same at C4 and C5)
+    // Workgroups to aim for: three 4-wave workgroups per CU now fit (launch bounds, 168 VGPRs).  Measured inside the
+    // C5 step (three role streams running side by side, one box, alternating): 512 -> 623 steps/s, 768 -> 636,
+    // 1024 -> 622, 256 (one round of the 16-wave kernel; best for a product running ALONE, 46.6 -> 41.3 us at
+    // 376x400x8192) -> 619.
+    static int slots = -1;   // SAMX_GEMM_SPLIT_SLOTS: A/B experiments
+    if (slots < 0) { const char* e = getenv("SAMX_GEMM_SPLIT_SLOTS"); slots = e ? atoi(e) : 768; if (slots < 1) slots = 768; }
+    int want = slots / tiles;
     int most = R / 128;      // keep at least 4 stages per split
     int s = want < most ? want : most;
     if (s < 1) s = 1;

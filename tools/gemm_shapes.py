@@ -12,8 +12,8 @@ from sam_tf_amd import ops  # noqa: E402
 from sam_tf_amd import _lib  # noqa: E402,F401
 
 SHAPES = [(8192, 400, 376, 'NN', 1), (8192, 300, 400, 'NN', 1), (8192, 376, 400, 'NT', 1), (8192, 400, 300, 'NT', 1),
-          (376, 400, 8192, 'TN', 12), (400, 300, 8192, 'TN', 16), (8192, 8192, 2048, 'NN', 1),
-          (8192, 256, 393, 'NN', 1), (393, 256, 8192, 'TN', 8)]
+          (376, 400, 8192, 'TN', 12), (376, 400, 8192, 'TN', 18), (376, 400, 8192, 'TN', 6), (400, 300, 8192, 'TN', 16), (400, 300, 8192, 'TN', 21), (400, 300, 8192, 'TN', 7), (8192, 8192, 2048, 'NN', 1),
+          (8192, 256, 393, 'NN', 1), (393, 256, 8192, 'TN', 8), (393, 256, 8192, 'TN', 27), (393, 256, 8192, 'TN', 16)]
 
 
 def main():
