@@ -1054,3 +1054,43 @@ def test_discriminator_feed_path_matches_oracle(cfg_name, world):
     _assert_weights(None, d, ref, 3, 'd_feed/%s-w%d' % (cfg_name, world), nets=('reward',))
     assert relerr(d.obs_rms.sums.cpu().numpy(), ref.rms_d) < 1e-12
     assert_per_var(d.optimizer.m.cpu().numpy(), ref.opt['d'][0], ref.dc, 1e-5, 'd_feed/%s-w%d/adam_m' % (cfg_name, world))
+
+
+@pytest.mark.parametrize('cfg_name,g_steps', [('C1', 1), ('C2', 3), ('C3', 1)])
+def test_pool_epoch_remainder_launches_equal_single_steps(cfg_name, g_steps):
+    """run() ends every expert-pool epoch with ONE launch of the rows that are left (a size prepare_all captured
+    because it recurs) instead of K/2, K/4, ...; the pool's reshuffle uploads its permutation without a host
+    sync.  Across several reshuffles: same host RNG consumption, same pool order, bit-identical learner (and
+    trees) as single steps."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    from sam_tf_amd.driver import UpdateStepDriver
+    cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
+    states = []
+    for mode in ('single', 'packed'):
+        mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
+        drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=8 * g_steps, g_steps=g_steps)
+        sizes = drv._recurring_sizes()
+        assert sizes and all(1 < k < drv.K and k % drv.S == 0 for k in sizes), sizes
+        drv.prepare_all()
+        assert all((k, 0) in drv.plans for k in sizes)
+        np.random.seed(91); random.seed(91)
+        per_epoch = (pool.num_entries - 1) // drv.B            # training steps of one pool epoch (nD = 1)
+        pool.pointer = pool.num_entries - 20 * drv.B           # the first reshuffle comes soon
+        n = (20 + 2 * per_epoch + 5) * drv.S if cfg['B'] >= 256 else (20 + per_epoch // 2) * drv.S
+        used = []
+        launch = drv._launch
+        drv._launch = lambda K, more=False: (used.append(K), launch(K, more))[1]
+        if mode == 'single':
+            for _ in range(n):
+                drv.step()
+        else:
+            drv.run(n)
+            assert any(k in sizes for k in used) or cfg['B'] < 256, (sizes, sorted(set(used)))
+        torch.cuda.synchronize()
+        extra = [mu.replay_buffer.trees.sum, mu.replay_buffer.trees.min] if cfg['per'] else []
+        states.append([t.clone() for t in [mu.L.params, mu.L.targets, mu.L.m, mu.L.v, mu.L.steps, d.obs_rms.sums] +
+                       extra] + [torch.tensor(np.random.randint(0, 1 << 30, 4)), torch.tensor([pool.pointer]),
+                                 pool.obs0.clone(), pool.acs.clone()])
+    for i, (a, b) in enumerate(zip(*states)):
+        assert torch.equal(a.cpu(), b.cpu()), i
