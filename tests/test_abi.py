@@ -71,3 +71,27 @@ def test_shipped_library_is_not_a_profiling_build():
     from sam_tf_amd import _lib
     L = ctypes.CDLL(_lib.SO_PATH)
     assert not hasattr(L, 'samx_debug_trace')
+
+
+def test_pow_routine_matches_this_machines_libm_on_the_host():
+    """The host build of csrc/pow_bits.h against the machine's libm pow (samx_pow_selfcheck; no GPU involved):
+    what the driver asks before it keeps the priority refresh on the device."""
+    from sam_tf_amd import _lib
+    assert int(_lib.lib().samx_pow_selfcheck(500000)) == 0
+
+
+def test_committed_pow_tables_are_those_of_this_images_libm(tmp_path):
+    """pow_tables.h is generated from the image's libm.so.6 (tools/extract_pow_tables.py); a different glibc in the
+    image must show up here, not as a silent fall-back to the host refresh."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libm = '/lib/x86_64-linux-gnu/libm.so.6'
+    if not os.path.exists(libm):
+        import pytest
+        pytest.skip('no libm.so.6 at the usual place')
+    out = tmp_path / 'pow_tables.h'
+    subprocess.check_call([sys.executable, os.path.join(root, 'tools', 'extract_pow_tables.py'), libm, str(out)])
+    strip = lambda s: '\n'.join(l for l in s.splitlines() if not l.startswith('// GENERATED'))
+    assert strip(out.read_text()) == strip(open(os.path.join(root, 'sam_tf_amd', 'csrc', 'pow_tables.h')).read())
