@@ -543,8 +543,12 @@ class UpdateStepDriver(object):
         draws = np.random.randint(low=0, high=N, size=(T, d + g, B))
         if self.S == 1:   # one D + agent row per training step: the draws ARE the rows' index words
             slot.np_idx[:K] = draws
-            for k in range(K):
-                self._expert_rows(slot, k)
+            if self.pool.pointer + K * B < self.pool.num_entries:   # no reshuffle inside (run() guarantees it for K > 1)
+                slot.np_e[:K] = self.pool.pointer + B * np.arange(K, dtype=np.int64)
+                self.pool.pointer += K * B
+            else:
+                for k in range(K):
+                    self._expert_rows(slot, k)
             return
         k = 0
         for t in range(T):
