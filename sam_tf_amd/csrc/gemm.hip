@@ -45,7 +45,8 @@ namespace {
 #define SAMX_GEMM_RING_FEW 6
 #endif
 constexpr int BM = 64, BN = 64, BK = 32;
-template <int KS> constexpr int ring() { return KS == 1 ? SAMX_GEMM_RING : SAMX_GEMM_RING_FEW; }
+// stage slots of the ring: KS = 1 takes NSU one-stage steps (3, or 2 for the four-workgroups-per-CU variant)
+template <int KS, int NSU> constexpr int ring() { return KS == 1 ? NSU : SAMX_GEMM_RING_FEW; }
 constexpr int TILE = BK * 64;            // floats per operand stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -203,7 +204,10 @@ __device__ __forceinline__ void wait_vm() {
 //         Used when a launch has too few workgroups to give every SIMD a wave: the serial chain of
 //         dependent MFMAs per wave is what such a launch waits for, and this cuts it by four.
 // A_W / B_W: the operand is staged with 16-byte DMAs (see the header).
-template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
+// NSU = 3: ring of three steps (one on the matrix cores, two in flight; 48 KB, three workgroups per CU).
+// NSU = 2: ring of two (32 KB, four workgroups per CU, 128 VGPRs): the refill of a slot is issued right after the
+//          barrier that follows its last fragment read, so a stage is still one step in flight before it is needed.
+template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W, int NSU = 3>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz) {
     // A "step" covers SPB consecutive 32-deep stages behind ONE barrier: the 16-wave variant has only
     // four MFMAs per wave and stage, so it takes two stages per barrier (a barrier + wait + issue round
@@ -212,9 +216,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #define SAMX_GEMM_SPB 2
 #endif
     constexpr int SPB = KS == 1 ? 1 : SAMX_GEMM_SPB;   // stages per step
-    constexpr int NSU = 3;                          // steps in the ring: one computing, two in flight
+    static_assert(NSU == 3 || (NSU == 2 && KS == 1), "ring of three, or of two for the 4-wave kernel");
     constexpr int NS = NSU * SPB;                   // stage slots
-    static_assert(NS == ring<KS>(), "launch_inst sizes the LDS from ring<KS>()");
+    static_assert(NS == ring<KS, NSU>(), "launch_inst sizes the LDS from ring<KS, NSU>()");
     constexpr int NW = 4 * KS;                      // waves
     constexpr int DA = ndma<A_W>(), DT = DA + ndma<B_W>();  // DMAs per stage: A's, then B's
     static_assert(DT % NW == 0, "every wave issues the same number of DMAs per stage");
@@ -263,9 +267,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     };
 
     // retire step u (counted wait on this wave's own DMAs, tail / ones-row patches, barrier)
-    auto retire = [&](int u) {
-        // steps issued after u and still allowed in flight: u+1 .. min(u+NSU-2, TU-1)
-        const int ahead = min(NSU - 2, TU - 1 - u);
+    auto retire = [&](int u, const bool head = false) {
+        // steps issued after u and still allowed in flight: u+1 .. min(u+NSU-2, TU-1); the ring of two has step 1
+        // in flight only while step 0 is retired (head)
+        const int ahead = NSU == 2 ? ((head && TU > 1) ? 1 : 0) : min(NSU - 2, TU - 1 - u);
         if (ahead <= 0) wait_vm<0>();
         else wait_vm<SPB * CNT>();
 #pragma unroll
@@ -314,11 +319,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     // One step: the MFMAs of step u run from registers while the fragment reads of step u+1 (into the
     // other register set) and the refill DMAs are in flight.
     auto step = [&](int u, float (&ca)[FPS], float (&cb)[FPS], float (&na)[FPS], float (&nb)[FPS]) {
-        // slots of step u-1: its fragments were consumed before the barrier of step u was passed
-        if (u + NSU - 1 < TU) issue_step(u + NSU - 1);
-        if (u + 1 < TU) {
-            retire(u + 1);
-            frags(u + 1, na, nb);
+        if (NSU == 2) {
+            if (u + 1 < TU) {
+                retire(u + 1);   // behind its barrier every wave has read the fragments of step u: that slot is free
+                if (u + 2 < TU) issue_step(u + 2);
+                frags(u + 1, na, nb);
+            }
+        } else {
+            // slots of step u-1: its fragments were consumed before the barrier of step u was passed
+            if (u + NSU - 1 < TU) issue_step(u + NSU - 1);
+            if (u + 1 < TU) {
+                retire(u + 1);
+                frags(u + 1, na, nb);
+            }
         }
 #pragma unroll
         for (int k = 0; k < FPS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[k], cb[k], acc, 0, 0, 0);
@@ -328,11 +341,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #ifdef SAMX_TRACE
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_gemm_trace[61] = clock64();
 #endif
-    for (int u = 0; u < NSU - 1 && u < TU; ++u) issue_step(u);
+    for (int u = 0; u < 2 && u < TU; ++u) issue_step(u);   // both rings start with two steps in flight
     GTRACE(1);
     float fa0[FPS], fb0[FPS], fa1[FPS], fb1[FPS];
     if (TU > 0) {
-        retire(0);
+        retire(0, true);
         GTRACE(2);
         frags(0, fa0, fb0);
     }
@@ -432,9 +445,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #endif
 }
 
-template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
-__global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void gemm_kernel(GemmArgs g) {
-    gemm_tile<A_RC, B_RC, KS, A_W, B_W>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W, int NSU>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? (NSU == 2 ? 4 : 3) : 1) void gemm_kernel(GemmArgs g) {
+    gemm_tile<A_RC, B_RC, KS, A_W, B_W, NSU>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several weight-gradient products (TN: both operands free-contiguous, 16-byte staging, split over the
@@ -488,12 +501,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo
     g.C[(int64_t)i * g.ldc + j] = apply_epi((int)g.epi, s, i, j, e);
 }
 
-template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W>
+template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W, int NSU = 3>
 int launch_inst(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-    constexpr size_t lds = (size_t)ring<KS>() * 2 * TILE * sizeof(float);
+    constexpr size_t lds = (size_t)ring<KS, NSU>() * 2 * TILE * sizeof(float);
     static LdsGrant grant;  // per instantiation and device; > 64 KB of LDS needs the opt-in
-    if (int rc = grant.ensure((const void*)gemm_kernel<A_RC, B_RC, KS, A_W, B_W>, lds, 64 * 1024)) return rc;
-    gemm_kernel<A_RC, B_RC, KS, A_W, B_W><<<grid, 256 * KS, lds, stream>>>(g);
+    if (int rc = grant.ensure((const void*)gemm_kernel<A_RC, B_RC, KS, A_W, B_W, NSU>, lds, 64 * 1024)) return rc;
+    gemm_kernel<A_RC, B_RC, KS, A_W, B_W, NSU><<<grid, 256 * KS, lds, stream>>>(g);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -510,7 +523,15 @@ int launch_layout(const GemmArgs& g, dim3 grid, bool few, hipStream_t stream) {
         if (aw && bw) return launch_inst<A_RC, B_RC, 4, true, true>(g, grid, stream);
         return launch_inst<A_RC, B_RC, 4, false, false>(g, grid, stream);
     }
-    if (aw && bw) return launch_inst<A_RC, B_RC, 1, true, true>(g, grid, stream);
+    if (aw && bw) {
+        // more than three tiles per CU but at most four: the ring of two runs them in ONE round
+        static int four = -1;  // SAMX_GEMM_FOUR: 0 never, 1 by tile count (default), 2 always (A/B experiments)
+        if (four < 0) { const char* e = getenv("SAMX_GEMM_FOUR"); four = e ? atoi(e) : 1; }
+        const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+        if (four == 2 || (four == 1 && wgs > 768 && wgs <= 1024))
+            return launch_inst<A_RC, B_RC, 1, true, true, 2>(g, grid, stream);
+        return launch_inst<A_RC, B_RC, 1, true, true>(g, grid, stream);
+    }
     if (aw) return launch_inst<A_RC, B_RC, 1, true, false>(g, grid, stream);
     if (bw) return launch_inst<A_RC, B_RC, 1, false, true>(g, grid, stream);
     return launch_inst<A_RC, B_RC, 1, false, false>(g, grid, stream);
@@ -572,7 +593,7 @@ int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const S
     }
     G.sum_first[nsums] = groups;
     blocks += (groups * 16 + 255) / 256;
-    constexpr size_t lds = (size_t)ring<1>() * 2 * TILE * sizeof(float);
+    constexpr size_t lds = (size_t)ring<1, 3>() * 2 * TILE * sizeof(float);
     static LdsGrant grant;
     if (int rc = grant.ensure((const void*)gemm_group_kernel, lds, 64 * 1024)) return rc;
     gemm_group_kernel<<<blocks, 256, lds, stream>>>(G);
