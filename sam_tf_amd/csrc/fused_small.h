@@ -147,8 +147,9 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st);
 // TD targets of B rows (and the n-step targets when a->n_idx) with the target nets: one launch
 int launch_targets(const AgentArgs* a, hipStream_t st);
 // ret_rms.update(tq [, tqn]) + PopArt rescale of the critic heads (sam_agent.py:554-590,662-672), one launch
+// (any hidden widths: also what the 256-wide path runs between its target launch and its role launch)
 int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
-                      int popart, float* critic, float* targ_critic, int critic_in, int critic_ln, int phase,
+                      int popart, float* critic, float* targ_critic, const samx_mlp* dc, int phase,
                       double* addvec, hipStream_t st);   // phase 1: batch sums -> addvec[6] only; 2: commit addvec; 0: both
 constexpr int kLossStride = 8;   // floats per tile in AgentArgs::loss_part
 // TD errors of B rows (rows of the storages through idx when idx != nullptr) with one whole-network launch

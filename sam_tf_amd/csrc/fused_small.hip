@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void ret_popart_kernel(const float* __restrict
                                                          int64_t B, double* __restrict__ sums, float* mean,
                                                          float* stdv, int popart, float* w3a, float* b3a,
                                                          float* w3b, float* b3b, int phase,
-                                                         double* __restrict__ addvec) {
+                                                         double* __restrict__ addvec, int h2) {
     // phase 0: everything (one process).  N processes (mpi_running_mean_std.py:47-59 all-reduces the batch
     // sums): phase 1 = the batch sums only -> addvec[6] = [sum, sumsq, n | the same for the n-step targets];
     // phase 2 = commit the (all-reduced) addvec and rescale.
@@ -748,9 +748,9 @@ __global__ __launch_bounds__(256) void ret_popart_kernel(const float* __restrict
     __syncthreads();
     if (!popart) return;
     const float om = shf[0], os = shf[1], nm = shf[2], ns = shf[3];
-    if (tid < H) {
-        w3a[tid] = __fdiv_rn(__fmul_rn(w3a[tid], os), ns);
-        w3b[tid] = __fdiv_rn(__fmul_rn(w3b[tid], os), ns);
+    for (int c = tid; c < h2; c += 256) {
+        w3a[c] = __fdiv_rn(__fmul_rn(w3a[c], os), ns);
+        w3b[c] = __fdiv_rn(__fmul_rn(w3b[c], os), ns);
     }
     if (tid == 0) {
         b3a[0] = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(b3a[0], os), om), nm), ns);
@@ -1056,13 +1056,16 @@ int launch_step(const AgentArgs* a, const DiscArgs* d, hipStream_t st) {
 }
 
 int launch_ret_popart(const float* tq, const float* tqn, int64_t B, double* sums, float* mean, float* stdv,
-                      int popart, float* critic, float* targ_critic, int critic_in, int critic_ln, int phase,
+                      int popart, float* critic, float* targ_critic, const samx_mlp* dc, int phase,
                       double* addvec, hipStream_t st) {
-    // 64x64 net, 1 output; LayerNorm adds beta/gamma behind each hidden bias
-    const int64_t oW3 = (int64_t)critic_in * H + H + H * H + H + (critic_ln ? 4 * H : 0), ob3 = oW3 + H;
+    // 1 output; LayerNorm adds beta/gamma behind each hidden bias (the flat layout of samx_mlp)
+    const int h1 = dc->h1, h2 = dc->h2;
+    const int64_t oW3 = (int64_t)dc->in_dim * h1 + h1 + (int64_t)h1 * h2 + h2 + (dc->layernorm ? 2 * (h1 + h2) : 0),
+                  ob3 = oW3 + h2;
     SAMX_REQUIRE(phase == 0 || addvec, "launch_ret_popart: phase %d needs addvec", phase);
+    SAMX_REQUIRE(dc->out_dim == 1, "launch_ret_popart: the critic has one output");
     ret_popart_kernel<<<1, 256, 0, st>>>(tq, tqn, B, sums, mean, stdv, popart, critic + oW3, critic + ob3,
-                                         targ_critic + oW3, targ_critic + ob3, phase, addvec);
+                                         targ_critic + oW3, targ_critic + ob3, phase, addvec, h2);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -880,15 +880,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                 rc = roles(&we);
                 if (rc != SAMX_OK) return rc;
                 we.targets_only = false;
-                if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
-                    rc = samx_rms_batch_sums(o->targ_q, B, nullptr, 0, 1, w.ret_add1, stream);
-                    if (rc != SAMX_OK) return rc;
-                    if (we.tqn) {
-                        rc = samx_rms_batch_sums(we.tqn, B, nullptr, 0, 1, w.ret_add2, stream);
-                        if (rc != SAMX_OK) return rc;
-                    }
-                    rc = samx_ret_update_popart(L->ret_sums, w.ret_add1, we.tqn ? w.ret_add2 : nullptr, L->ret_mean,
-                                                L->ret_std, 1, &L->critic, L->params + Pa, L->targets + Pa, stream);
+                if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672: batch sums, commit and rescale in ONE launch
+                    rc = fused::launch_ret_popart(o->targ_q, we.tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
+                                                  L->params + Pa, L->targets + Pa, &L->critic, 0, nullptr, st);
                     if (rc != SAMX_OK) return rc;
                 }
             }
@@ -1085,7 +1079,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         }
         if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672
             rc = fused::launch_ret_popart(o->targ_q, tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
-                                          L->params + Pa, L->targets + Pa, L->critic.in_dim, ln ? 1 : 0,
+                                          L->params + Pa, L->targets + Pa, &L->critic,
                                           t_only ? 1 : (t_done ? 2 : 0), b->ret_addvec, st);
             if (rc != SAMX_OK) return rc;
         }
