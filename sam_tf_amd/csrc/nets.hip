@@ -362,8 +362,11 @@ __global__ __launch_bounds__(256) void ln_tan_kernel(const float* __restrict__ Z
 }
 
 // LayerNorm parameter gradients: dbeta[j] = sum_{r < Mb} DN[r,j], dgamma[j] = sum_{r < Mg} DN[r,j] XH[r,j].
-// Stage 1: block (x = 64 columns, y = row chunk) -> part[y][2][H]; stage 2 adds the chunks in order.
-constexpr int kLnChunksMax = 32;
+// Stage 1: block (x = 64 columns, y = row chunk) -> part[y][2][H]: four row-lanes per column, each adds its rows
+// in increasing order with eight rows' loads in flight (one dependent load pair per row made this the longest
+// small kernel of the LayerNorm configurations: 76 us at 8192 x 400).  Stage 2 adds the chunks: four chunk-lanes
+// per column, each in increasing chunk order, then a fixed tree.
+constexpr int kLnChunksMax = 128;
 __global__ __launch_bounds__(256) void ln_pgrad1_kernel(const float* __restrict__ DN, const float* __restrict__ XH,
                                                         int64_t Mb, int64_t Mg, int H, int64_t chunk,
                                                         float* __restrict__ part) {
@@ -371,12 +374,28 @@ __global__ __launch_bounds__(256) void ln_pgrad1_kernel(const float* __restrict_
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, col = blockIdx.x * 64 + cl;
     const int64_t r0 = blockIdx.y * chunk, r1 = min(r0 + chunk, max(Mb, Mg));
     float b = 0.f, g = 0.f;
-    if (col < H)
-        for (int64_t r = r0 + rl; r < r1; r += 4) {
+    if (col < H) {
+        constexpr int U = 8;
+        int64_t r = r0 + rl;
+        for (; r + 4 * (U - 1) < r1; r += 4 * U) {
+            float dn[U], xh[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                dn[u] = DN[(r + 4 * u) * H + col];
+                xh[u] = XH[(r + 4 * u) * H + col];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + 4 * u < Mb) b += dn[u];
+                if (r + 4 * u < Mg) g = fmaf(dn[u], xh[u], g);
+            }
+        }
+        for (; r < r1; r += 4) {
             const float dn = DN[r * H + col];
             if (r < Mb) b += dn;
             if (r < Mg) g = fmaf(dn, XH[r * H + col], g);
         }
+    }
     sh[0][rl][cl] = b;
     sh[1][rl][cl] = g;
     __syncthreads();
@@ -387,15 +406,35 @@ __global__ __launch_bounds__(256) void ln_pgrad1_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void ln_pgrad2_kernel(const float* __restrict__ part, int S, int H,
                                                         float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= H) return;
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, col = blockIdx.x * 64 + cl;
+    const int per = (S + 3) / 4, s0 = sl * per, s1 = min(S, s0 + per);
     float b = 0.f, g = 0.f;
-    for (int s = 0; s < S; ++s) {
-        b += part[((int64_t)s * 2) * H + col];
-        g += part[((int64_t)s * 2 + 1) * H + col];
+    if (col < H) {
+        constexpr int U = 8;
+        int s = s0;
+        for (; s + U <= s1; s += U) {
+            float pb[U], pg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pb[u] = part[((int64_t)(s + u) * 2) * H + col];
+                pg[u] = part[((int64_t)(s + u) * 2 + 1) * H + col];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { b += pb[u]; g += pg[u]; }
+        }
+        for (; s < s1; ++s) {
+            b += part[((int64_t)s * 2) * H + col];
+            g += part[((int64_t)s * 2 + 1) * H + col];
+        }
     }
-    dbeta[col] = b;
-    dgamma[col] = g;
+    sh[0][sl][cl] = b;
+    sh[1][sl][cl] = g;
+    __syncthreads();
+    if (sl == 0 && col < H) {
+        dbeta[col] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        dgamma[col] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
 }
 
 template <int MODE>
@@ -719,7 +758,7 @@ int ln_pgrad(const float* DN, const float* XH, int64_t Mb, int64_t Mg, int H, fl
     const int64_t chunk = ((M + S - 1) / S + 3) / 4 * 4;
     ln_pgrad1_kernel<<<dim3((H + 63) / 64, S), 256, 0, st>>>(DN, XH, Mb, Mg, H, chunk, part);
     SAMX_LAUNCH_CHECK();
-    ln_pgrad2_kernel<<<(H + 255) / 256, 256, 0, st>>>(part, S, H, dbeta, dgamma);
+    ln_pgrad2_kernel<<<(H + 63) / 64, 256, 0, st>>>(part, S, H, dbeta, dgamma);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -118,6 +118,11 @@ class UpdateStepDriver(object):
         # 256x256 learners (samx_step_path 2): layer-wise in how the driver plans launches and collectives,
         # fused in how the D-input statistics ride inside the step (one process)
         self.wide = self.L.path(B) == 2
+        # PER on the layer-wise path, one process: the D chain beside the PER work + agent roles (see
+        # _seg_grads_two_branches); SAMX_PER_TWO_BRANCHES=0 keeps every row on one chain
+        self.per_two_branches = bool(self.per_dev and not self.fused and not self.wide and self.world == 1 and
+                                     B >= 1024 and os.environ.get('SAMX_PER_TWO_BRANCHES', '1') != '0')
+        self._side_stream = torch.cuda.Stream(device=dev) if self.per_two_branches else None
         m = 1
         while 2 * m * self.S <= int(steps_per_launch):
             m *= 2
@@ -310,6 +315,31 @@ class UpdateStepDriver(object):
         if self.world == 1:
             self._seg_refresh(role, k)
 
+    def _seg_grads_two_branches(self, k, carry_td, last):
+        """One D + agent row of the layer-wise path with prioritized replay, one process, as two branches: the
+        discriminator's chain depends neither on the trees nor on the agent's rows, so it runs on a side stream
+        while the launch stream carries [the previous row's post-update TD errors ->] priority refresh -> tree update
+        -> stratified sample -> the agent roles (which fork inside samx_step_grads_part).  Same kernels on the
+        same inputs as _seg_grads: the results are identical; only [TD pass, tree work, gather] — about 200 us of
+        one-queue work per row at C5 — no longer run with the rest of the chip idle."""
+        role = self.D | self.A
+        cur = torch.cuda.current_stream()
+        side = self._side_stream
+        # (the D chain takes the side stream: the agent call forks its role streams itself, and a fork of a
+        # forked stream made hipStreamEndCapture crash on ROCm 7.0 — every fork starts at the launch stream)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 8)    # network passes, discriminator only
+        if carry_td:
+            self._seg_refresh(role, k - 1)
+        self._seg_trees(role, k)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 4)        # network passes, agent roles only
+        cur.wait_stream(side)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 2)            # the reduction part, every segment
+        ops.step_apply(self.L, self.B, 3, 1.0)
+        if last:
+            self._seg_refresh(role, k)
+
     def _seg_apply(self, role=3):
         ops.step_apply(self.L, self.B, 6 | self._masks(role)[1], 1.0 / self.world)
         self._seg_refresh(role)
@@ -396,8 +426,12 @@ class UpdateStepDriver(object):
                     # they depend on host-drawn indices only)
                     if any_d:
                         self._seg_sums(K)
+                    two = self.per_two_branches and all(r == self.D | self.A for r in roles)
                     for k in range(K):
-                        if self.B < 1024 and roles[k] & self.A:
+                        if two:
+                            self._seg_inputs(k, roles[k])
+                            self._seg_grads_two_branches(k, carry_td=k > 0, last=k == K - 1)
+                        elif self.B < 1024 and roles[k] & self.A:
                             # refresh + tree update + this row's stratified sample (samx_per_row_prologue_td)
                             idx_a, u = self._row_views(k)
                             ops.per_row_prologue(rb.trees, self.pend_idx, None, None, self._batch_start,

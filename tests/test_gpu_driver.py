@@ -213,7 +213,7 @@ def _assert_weights(mu, d, ref, K, tag, nets=('actor', 'critic', 'targ_actor', '
 @pytest.mark.parametrize('graph', [False, True])
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
                                       'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper', 'ragged-launcher',
-                                      'raggedper-ret', 'C4', 'C4-retn', 'wsmall-ret', 'wsmall-retn',
+                                      'raggedper-ret', 'raggedperbig', 'raggedperbig-ret', 'C4', 'C4-retn', 'wsmall-ret', 'wsmall-retn',
                                       'wsmall-nstep', 'wsmallper-ret'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
@@ -232,6 +232,9 @@ def test_k_steps_match_oracle(cfg_name, graph):
              # nothing a multiple of a tile, on the layer-wise path with the launcher's options
              'ragged': dict(ob=5, ac=2, h=(33, 70), B=37, per=False, name='ragged'),
              'raggedper': dict(ob=5, ac=2, h=(33, 70), B=37, per=True, name='ragged-per'),
+             # layer-wise path, prioritized replay, a batch of 1024: the row runs as two branches (the D chain
+             # beside [TD pass -> tree update -> sample -> agent roles], driver._seg_grads_two_branches)
+             'raggedperbig': dict(ob=5, ac=2, h=(33, 70), B=1024, per=True, name='ragged-per-big'),
              # 256x256 nets on the role-fused path with the argparse-default options: targets from their own
              # launch, PopArt between the target pass and the loss pass, n-step TD loss
              'wsmall': dict(ob=20, ac=3, h=(256, 256), B=48, per=False, name='wide-small'),
@@ -243,7 +246,8 @@ def test_k_steps_match_oracle(cfg_name, graph):
                p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, graph)
     if base in extra:
-        assert drv.fused == (base not in ('widein', 'ragged', 'raggedper', 'wsmall', 'wsmallper'))
+        assert drv.fused == (base not in ('widein', 'ragged', 'raggedper', 'raggedperbig', 'wsmall', 'wsmallper'))
+        assert drv.per_two_branches == (base == 'raggedperbig')
         assert drv.wide == base.startswith('wsmall')
         assert drv.sums_small == (not base.startswith('bigB'))
     if opt and base not in extra:
@@ -402,7 +406,7 @@ def test_d_input_stats_and_randoms():
     assert 0.0 < float(fake.min()) and float(fake.max()) <= 0.3
 
 
-@pytest.mark.parametrize('cfg_name', ['C1', 'C2', 'C3'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C2', 'C3', 'raggedperbig'])
 def test_multi_step_launch_equals_single_steps(cfg_name):
     """run(n) packs K steps into one graph launch (uniform replay, one process).  It must sample the
     same indices (same host RNG consumption) and leave bit-identical learner state as n x step()."""
@@ -410,13 +414,17 @@ def test_multi_step_launch_equals_single_steps(cfg_name):
     import bench
     from sam_tf_amd.comm import TorchComm
     from sam_tf_amd.driver import UpdateStepDriver
-    cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
+    if cfg_name == 'raggedperbig':   # layer-wise path + PER + batch >= 1024: two-branch rows, TD pass carried
+        cfg = dict(ob=5, ac=2, h=(33, 70), B=1024, per=True, mem=8192, name='ragged-per-big')
+    else:
+        cfg = dict(bench.CONFIGS[cfg_name], mem=4096)
     n = 11
     states = []
     for mode in ('single', 'packed'):
         mu, d, pool, _ = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 5, True)
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
         assert drv.K == 4   # PER too: the priority refresh stays on the device, rows chain inside the graph
+        assert drv.per_two_branches == (cfg_name == 'raggedperbig')
         drv.prepare(1); drv.prepare(drv.K)
         np.random.seed(77); random.seed(77)
         # the expert pool wraps (host reshuffle, np.random) after 6 of the 11 steps
