@@ -564,9 +564,30 @@ __global__ __launch_bounds__(256) void gp_sumsq_kernel(const float* __restrict__
     const int w = ob + ac;
     const int64_t tot = B * w;
     double so = 0.0, sa = 0.0;
-    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256) {
-        const double g = (double)G[t];
-        if ((int)(t % w) < ob) so += g * g; else sa += g * g;
+    // eight loads in flight per thread, added in the same increasing order of t; the column of an element
+    // advances by (stride mod w) per step (no 64-bit division per element)
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int cstep = (int)(stride % w);
+    int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    int c = (int)(t % w);
+    for (; t + (U - 1) * stride < tot; t += U * stride) {
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) g[u] = G[t + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double d = (double)g[u];
+            if (c < ob) so += d * d; else sa += d * d;
+            c += cstep;
+            c = c >= w ? c - w : c;
+        }
+    }
+    for (; t < tot; t += stride) {
+        const double d = (double)G[t];
+        if (c < ob) so += d * d; else sa += d * d;
+        c += cstep;
+        c = c >= w ? c - w : c;
     }
     so = block_sum_d(so, sh);
     sa = block_sum_d(sa, sh);

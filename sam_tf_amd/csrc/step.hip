@@ -391,26 +391,38 @@ __global__ __launch_bounds__(256) void d_input_partials_kernel(
     {   // blockIdx.y: the chunk of 256 columns
         const int col = blockIdx.y * 256 + threadIdx.x;
         double a = 0.0, q = 0.0;
-        for (int64_t rb = g; rb < 2 * B; rb += (int64_t)G * 8) {
-            float v[8];
-            bool ok[8];
+        // The rows of this group, sixteen per batch: their storage rows are resolved first by the first sixteen
+        // threads (ONE dependent index -> row round trip per batch instead of one per row and thread), then every
+        // thread has its sixteen row loads in flight; added in increasing row order.
+        constexpr int U = 16;
+        __shared__ int64_t srow[U];
+        for (int64_t rb = g; rb < 2 * B; rb += (int64_t)G * U) {
+            __syncthreads();   // the previous batch's rows have been read
+            if (threadIdx.x < U) {
+                const int64_t r = rb + (int64_t)threadIdx.x * G;
+                int64_t sr = -1;
+                if (r < 2 * B) {
+                    if (r < B) {
+                        sr = r;
+                        if (p_idx) { sr = ring_start + p_idx[r]; if (sr >= ring_len) sr -= ring_len; }
+                    } else {
+                        sr = e0 + (r - B);
+                    }
+                }
+                srow[threadIdx.x] = sr;
+            }
+            __syncthreads();
+            float v[U];
+            bool ok[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t r = rb + (int64_t)u * G;
                 ok[u] = r < 2 * B && col < dim;
                 v[u] = 0.f;
-                if (ok[u]) {
-                    if (r < B) {
-                        int64_t pr = r;
-                        if (p_idx) { pr = ring_start + p_idx[r]; if (pr >= ring_len) pr -= ring_len; }
-                        v[u] = replay_obs0[pr * dim + col];
-                    } else {
-                        v[u] = pool_obs0[(e0 + (r - B)) * dim + col];
-                    }
-                }
+                if (ok[u]) v[u] = (r < B ? replay_obs0 : pool_obs0)[srow[u] * dim + col];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < U; ++u)
                 if (ok[u]) {
                     const double x = (double)v[u];
                     a = __dadd_rn(a, x);
