@@ -524,11 +524,14 @@ int launch_layout(const GemmArgs& g, dim3 grid, bool few, hipStream_t stream) {
         return launch_inst<A_RC, B_RC, 4, false, false>(g, grid, stream);
     }
     if (aw && bw) {
-        // more than three tiles per CU but at most four: the ring of two runs them in ONE round
-        static int four = -1;  // SAMX_GEMM_FOUR: 0 never, 1 by tile count (default), 2 always (A/B experiments)
+        // Unsplit launches of more than three tiles per CU take the ring of two (four workgroups per CU): 769..1024
+        // tiles then run in ONE round (8192x400x376: 50.1 -> 53.2 TFLOP/s), longer launches gain from the fourth
+        // resident workgroup (8192^2 x 2048: 100.4 -> 103.7; C5, whose D chain has 1920..2688 tiles per product,
+        // 684 -> 701 steps/s).  Split weight-gradient products lose 3-5 % with it and keep the ring of three.
+        static int four = -1;  // SAMX_GEMM_FOUR: 0 never, 1 as above (default), 2 always (A/B experiments)
         if (four < 0) { const char* e = getenv("SAMX_GEMM_FOUR"); four = e ? atoi(e) : 1; }
         const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
-        if (four == 2 || (four == 1 && wgs > 768 && wgs <= 1024))
+        if (four == 2 || (four == 1 && wgs > 768 && g.nsplit == 1))
             return launch_inst<A_RC, B_RC, 1, true, true, 2>(g, grid, stream);
         return launch_inst<A_RC, B_RC, 1, true, true>(g, grid, stream);
     }

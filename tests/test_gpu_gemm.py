@@ -2,8 +2,8 @@
 float32 operands.  Tolerance 1e-5 relative to the largest output magnitude (fp32 fma chain of length R
 vs fp64).  Shapes cover the 16-byte and the dword staging of either operand (extent % 4), partial tiles,
 reductions that are not a multiple of the 32-deep stage, the 16-wave small-launch variant and the
-4-wave one (>= 512 workgroups), its ring-of-two form (769..1024 workgroups: four per CU; reductions of one, two and
-four stages), every epilogue, the split reduction and the virtual ones row."""
+4-wave one (>= 512 workgroups), its ring-of-two form (unsplit launches of more than 768 workgroups: four per CU; reductions of
+one, two and four stages), every epilogue, the split reduction and the virtual ones row."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(64, 64, 32), (37, 70, 33), (1024, 256, 376), (1024, 256, 393), (1000, 17, 256), (128, 1, 300),
           (2048, 400, 376), (2050, 398, 402), (4096, 300, 400), (8192, 400, 100), (8192, 400, 37),
-          (8192, 400, 20), (3, 5, 7), (256, 256, 4)]
+          (8192, 400, 20), (12288, 400, 50), (3, 5, 7), (256, 256, 4)]
 
 
 def _padded(x):
