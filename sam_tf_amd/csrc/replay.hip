@@ -137,7 +137,7 @@ __global__ void rms_count_kernel(double* sums, const double* addvec, int dim) {
 }  // namespace
 
 namespace {
-// One thread per sampled index (memory.py:125-148).  Rows are read in batches of 8 so that the 8 loads
+// One thread per sampled index (memory.py:125-148).  Rows are read in batches of 32 so that the loads
 // of a batch are in flight together; the discounted sum then runs from the far end in float64 with
 // separate multiply and add (the order and rounding of scipy's lfilter on the reversed rewards).
 __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ rews,
@@ -158,34 +158,86 @@ __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ re
     const int win = (int)(last - idx + 1);
     int64_t phys0 = start + idx;
     if (phys0 >= maxlen) phys0 -= maxlen;
-    // first done inside the window
+    // first done inside the window (NB loads in flight per batch: a window of n = 96 rows is three memory round
+    // trips per pass, not twelve — the kernel is nothing but these round trips)
+    constexpr int NB = 32;
     int hit = -1;
-    for (int k0 = 0; k0 < win && hit < 0; k0 += 8) {
-        float d[8];
+    for (int k0 = 0; k0 < win && hit < 0; k0 += NB) {
+        float d[NB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NB; ++u) {
             int64_t p = phys0 + k0 + u;
             if (p >= maxlen) p -= maxlen;
             d[u] = (k0 + u < win) ? dones1[p] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NB; ++u)
             if (hit < 0 && d[u] == 1.0f) hit = k0 + u;
     }
     const int td_len = hit >= 0 ? hit + 1 : win;
     double acc = 0.0;
-    for (int k0 = td_len - 1; k0 >= 0; k0 -= 8) {
-        float r[8];
+    for (int k0 = td_len - 1; k0 >= 0; k0 -= NB) {
+        float r[NB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NB; ++u) {
             int64_t p = phys0 + (k0 - u);
             if (p >= maxlen) p -= maxlen;
             r[u] = (k0 - u >= 0) ? rews[p] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NB; ++u)
             if (k0 - u >= 0) acc = __dadd_rn((double)r[u], __dmul_rn(gamma, acc));
     }
+    end_idx_out[t] = idx + td_len - 1;
+    rews_out[t] = (float)acc;
+    if (rews64_out) rews64_out[t] = acc;
+    dones_out[t] = (hit >= 0 && hit != win - 1) ? 1.f : 0.f;
+    td_len_out[t] = (float)td_len;
+}
+
+// The same lookahead with SIXTEEN lanes per sampled index (windows of n <= kNstepGroupMax rows): the lanes read the
+// window's dones / rewards side by side (consecutive ring rows: whole cache lines per group instead of one line per
+// lane and load — with one thread per index the kernel was 60 us of uncoalesced gathers on 32 CUs for 16 x 256
+// indices at n = 96), park them in LDS, and lane 0 of the group runs the reference's sequential arithmetic on them —
+// the same operations in the same order as nstep_kernel, so the same bits.
+constexpr int kNstepGroupMax = 256;
+__global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restrict__ rews,
+                                                          const float* __restrict__ dones1, int64_t maxlen,
+                                                          int64_t start, int64_t num_entries,
+                                                          const int64_t* __restrict__ idxs, int64_t idx_stride,
+                                                          int64_t rows_per_batch, int64_t B, int n, double gamma,
+                                                          int64_t* __restrict__ end_idx_out,
+                                                          float* __restrict__ rews_out,
+                                                          double* __restrict__ rews64_out,
+                                                          float* __restrict__ dones_out,
+                                                          float* __restrict__ td_len_out) {
+    __shared__ float sd[16][kNstepGroupMax], sr[16][kNstepGroupMax];
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int64_t t = blockIdx.x * (int64_t)16 + g;
+    const bool valid = t < B;
+    int64_t idx = 0, phys0 = 0;
+    int win = 0;
+    if (valid) {
+        idx = idxs[(t / rows_per_batch) * idx_stride + t % rows_per_batch];
+        const int64_t last = (idx + n < num_entries ? idx + n : num_entries) - 1;  // lookahead_end_idx
+        win = (int)(last - idx + 1);
+        phys0 = start + idx;
+        if (phys0 >= maxlen) phys0 -= maxlen;
+    }
+    for (int k = l; k < win; k += 16) {
+        int64_t p = phys0 + k;
+        if (p >= maxlen) p -= maxlen;
+        sd[g][k] = dones1[p];
+        sr[g][k] = rews[p];
+    }
+    __syncthreads();
+    if (!valid || l != 0) return;
+    int hit = -1;
+    for (int k = 0; k < win && hit < 0; ++k)
+        if (sd[g][k] == 1.0f) hit = k;
+    const int td_len = hit >= 0 ? hit + 1 : win;
+    double acc = 0.0;
+    for (int k = td_len - 1; k >= 0; --k) acc = __dadd_rn((double)sr[g][k], __dmul_rn(gamma, acc));
     end_idx_out[t] = idx + td_len - 1;
     rews_out[t] = (float)acc;
     if (rews64_out) rews64_out[t] = acc;
@@ -259,9 +311,14 @@ int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen,
     SAMX_REQUIRE(B > 0 && n > 1 && n <= 4096, "samx_nstep_lookahead: need B > 0 and 1 < n <= 4096");
     SAMX_REQUIRE(maxlen > 0 && start >= 0 && start < maxlen && num_entries > 0 && num_entries <= maxlen,
                  "samx_nstep_lookahead: bad ring geometry");
-    nstep_kernel<<<(unsigned)((B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
-        rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
-        dones_out, td_len_out);
+    if (n <= kNstepGroupMax)
+        nstep_group_kernel<<<(unsigned)((B + 15) / 16), 256, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
+            dones_out, td_len_out);
+    else
+        nstep_kernel<<<(unsigned)((B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
+            dones_out, td_len_out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -276,9 +333,14 @@ int samx_nstep_lookahead_many(const float* rews, const float* dones1, int64_t ma
                  "samx_nstep_lookahead_many: need B > 0, K > 0, idx_stride >= B and 1 < n <= 4096");
     SAMX_REQUIRE(maxlen > 0 && start >= 0 && start < maxlen && num_entries > 0 && num_entries <= maxlen,
                  "samx_nstep_lookahead_many: bad ring geometry");
-    nstep_kernel<<<(unsigned)((K * B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
-        rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
-        nullptr, dones_out, td_len_out);
+    if (n <= kNstepGroupMax)
+        nstep_group_kernel<<<(unsigned)((K * B + 15) / 16), 256, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
+            nullptr, dones_out, td_len_out);
+    else
+        nstep_kernel<<<(unsigned)((K * B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
+            nullptr, dones_out, td_len_out);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -239,6 +239,35 @@ def test_nstep_lookahead_many_matches_single(name):
             and torch.equal(tl[k], t1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [2, 7, 96, 256, 300])
+def test_nstep_lookahead_window_lengths_vs_oracle(n):
+    """Both lookahead kernels — sixteen lanes per sampled index for windows of up to 256 rows, one thread per index
+    beyond — against the oracle's lookahead (pinned on the reference's vectors by tests/test_oracle_golden.py): a
+    wrapped ring, episode ends every ~40 rows, windows cut by num_entries; end index, n-step reward (float64 and
+    float32), done flag and length bit for bit."""
+    from oracle.replay_oracle import ReplayOracle
+    from sam_tf_amd import memory as XP, ops
+    limit, ob, ac = 700, 3, 2
+    rs = np.random.RandomState(n)
+    rb = XP.RB(limit, (ob,), (ac,))
+    ref = ReplayOracle(limit, (ob,), (ac,))
+    for i in range(limit + 123):   # wraps: start != 0
+        row = (rs.randn(ob).astype(np.float32), rs.uniform(-1, 1, ac).astype(np.float32), float(rs.uniform(0, 5)),
+               rs.randn(ob).astype(np.float32), float(rs.rand() < 0.025))
+        rb.append(*row)
+        ref.append(*row)
+    idxs = np.concatenate([rs.randint(0, limit, size=200), np.arange(limit - 5, limit)]).astype(np.int64)
+    want = ref.lookahead(idxs, n, 0.99)
+    end, rews, dones, tl, r64 = ops.nstep_lookahead(rb.store, rb.start, rb.num_entries, torch.as_tensor(idxs).cuda(),
+                                                    n, 0.99, want64=True)
+    assert np.array_equal(end.cpu().numpy(), np.asarray(want['end_idx']).ravel().astype(np.int64))
+    assert np.array_equal(r64.cpu().numpy(), np.asarray(want['rews'], dtype=np.float64).ravel())
+    assert np.array_equal(rews.cpu().numpy(), np.asarray(want['rews'], dtype=np.float64).ravel().astype(np.float32))
+    assert np.array_equal(dones.cpu().numpy(), np.asarray(want['dones1']).ravel().astype(np.float32))
+    assert np.array_equal(tl.cpu().numpy(), np.asarray(want['td_len']).ravel().astype(np.float32))
+
+
 @pytest.mark.parametrize('limit,n_demos,seed', [(50, 0, 1), (100, 7, 2), (257, 20, 3), (64, 0, 4), (1000, 0, 5)])
 def test_random_op_sequences_vs_oracle(limit, n_demos, seed):
     """Random sequences of append / sample / sample_uniform / update_priorities (duplicate indices, demo
