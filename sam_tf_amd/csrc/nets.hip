@@ -54,6 +54,23 @@ int check_desc(const samx_mlp* d, const char* who) {
 
 // ---------------------------------------------------------------- row-local kernels
 
+// f(row, column) for the elements t = row * w + column < tot of a row-major matrix, grid-stride over t.
+// The split of t is a 32-bit division whenever tot fits (a 64-bit division per element cost these row-local
+// kernels more than their memory traffic).
+template <typename F>
+__device__ __forceinline__ void for_rows_cols(int64_t tot, int w, F f) {
+    if (tot <= 0x7fffffff) {
+        const uint32_t n = (uint32_t)tot, uw = (uint32_t)w, stride = gridDim.x * blockDim.x;
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+            const uint32_t row = t / uw;
+            f((int64_t)row, (int)(t - row * uw));   // (t + stride stays below 2^32: both are below 2^31)
+        }
+    } else {
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x)
+            f(t / w, (int)(t % w));
+    }
+}
+
 // out[row, 0:ob] = clip((obs - mean)/std, -5, 5)  (sam_agent.py:150-156, math_util.py:8-12) ;
 // out[row, ob:ob+ac] = acs[row]  (critic / reward-net input concat, networks.py:238,363)
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ obs,
@@ -63,10 +80,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ obs
                                                    int ac, float* __restrict__ out, int ld) {
     const int w = ob + (acs ? ac : 0);
     const int64_t tot = B * w;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot;
-         t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = t / w;
-        const int c = (int)(t % w);
+    auto body = [&](int64_t row, int c) {
         float v;
         if (c < ob) {
             v = obs[row * ob + c];
@@ -75,7 +89,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ obs
             v = acs[row * ac + (c - ob)];
         }
         out[row * ld + c] = v;
-    }
+    };
+    for_rows_cols(tot, w, body);
 }
 
 // rows [0,B): policy pair, [B,2B): expert pair, [2B,3B): eps*policy + (1-eps)*expert on the
@@ -92,10 +107,7 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(
     const int64_t tot = B * w;
     const uint64_t st = src.draw ? (uint64_t)src.step_dev[0] : 0;
     const int64_t e0 = src.e_start ? src.e_start[0] : 0;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot;
-         t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = t / w;
-        const int c = (int)(t % w);
+    auto body = [&](int64_t row, int c) {
         int64_t pr = row;
         if (src.p_idx) {
             pr = src.ring_start + src.p_idx[row];
@@ -125,7 +137,8 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(
         X[row * w + c] = p;
         X[(B + row) * w + c] = e;
         X[(2 * B + row) * w + c] = eps * p + (1.f - eps) * e;
-    }
+    };
+    for_rows_cols(tot, w, body);
 }
 
 enum HeadMode { HEAD_Q, HEAD_TARG, HEAD_TD, HEAD_CRITIC, HEAD_ACTOR_Q, HEAD_DISC, HEAD_REWARD };
@@ -617,8 +630,7 @@ __global__ __launch_bounds__(256) void gp_scale_kernel(const float* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) gp_out[0] = (float)((N - 1.0) * (N - 1.0));
     const int w = ob + ac;
     const int64_t tot = B * w;
-    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256)
-        V[t] = G[t] * (((int)(t % w) < ob) ? co : ca);
+    for_rows_cols(tot, w, [&](int64_t row, int c) { V[row * w + c] = G[row * w + c] * (c < ob ? co : ca); });
 }
 
 // the 8 discriminator losses in the order of discriminator.py:145-158
