@@ -863,6 +863,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     wpipe_init(pipe);
     const WDesc d1 = w_nn(n.W1, in), d2 = w_nn(n.W2, H), d3 = w_nt(n.W2, H, 0, H);
     const int tsec = sect == 2 ? 0 : (sect == 0 ? 2 : 4);
+    (void)tsec;   // only the SAMX_TRACE build reads it
     if (cw) WTRACE(wg % tiles_b, 2, tsec);
     // statistics the rows are normalised with, staged in LDS (over T1, unused until the first product).
     // d.obs_rms.update folded into the step: the batch's float64 column sums were computed ahead, every

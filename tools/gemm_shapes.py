@@ -1,6 +1,6 @@
-"""GEMM throughput at the layer shapes of C5 (and a large square), both kernels side by side:
-   python tools/gemm_shapes.py            (128x64 tile kernel where gemm() picks it)
-   SAMX_GEMM_BIG=0 python tools/gemm_shapes.py   (the 64x64 kernel everywhere)
+"""GEMM throughput at the layer shapes of C5 (and a large square):
+   python tools/gemm_shapes.py                    (the shipped choice between the ring of three and the ring of two)
+   SAMX_GEMM_FOUR=0 python tools/gemm_shapes.py   (ring of three everywhere; 2: ring of two everywhere)
 Prints TFLOP/s (HIP events around 20 calls) and the max relative error against torch's fp32 matmul."""
 import os
 import sys
@@ -19,7 +19,7 @@ SHAPES = [(8192, 400, 376, 'NN', 1), (8192, 300, 400, 'NN', 1), (8192, 376, 400,
 def main():
     dev = 'cuda'
     g = torch.Generator(device=dev); g.manual_seed(0)
-    print('kernel choice: %s' % ('64x64 only' if os.environ.get('SAMX_GEMM_BIG') == '0' else '128x64 where picked'))
+    print('SAMX_GEMM_FOUR = %s' % os.environ.get('SAMX_GEMM_FOUR', '1 (default)'))
     for M, N, R, layout, nsplit in SHAPES:
         if layout == 'NN':
             A = torch.randn(M, R, generator=g, device=dev); B = torch.randn(R, N, generator=g, device=dev)
