@@ -201,7 +201,13 @@ class UpdateStepDriver(object):
         randoms are drawn inside the kernels."""
         rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
         B = self.B
-        self._batch_start = rb.start
+        # Uniform replay without n-step returns: the index words carry STORAGE rows — the host adds the ring's start to
+        # its draws (memory.py:16-35: data[(start + idx) % maxlen]) — and the kernels see a ring that starts at 0, so
+        # the captured graphs survive every append, also once the ring is full and each append moves its start (the
+        # reference's loop appends between any two training phases; re-capturing there cost more than the phase).
+        # PER and n-step returns work on logical indices on the device (trees, windows) and keep the ring's start.
+        self.storage_rows = bool(not self.per and not self.mu.hps.n_step_returns)
+        self._batch_start = 0 if self.storage_rows else rb.start
         self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
@@ -232,7 +238,7 @@ class UpdateStepDriver(object):
                 B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
                 obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
                 obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=w[:B], a_idx=w[B:2 * B],
-                e_start=w[2 * B:2 * B + 1], ring_start=rb.start, ring_len=rb.limit, rng_seed=self.rng_seed,
+                e_start=w[2 * B:2 * B + 1], ring_start=self._batch_start, ring_len=rb.limit, rng_seed=self.rng_seed,
                 label_smoothing=self.label_mode, num_entries=rb.num_entries,
                 d_rms_sums=r.sums if r else None,
                 d_rms_addvec=self.addvecs[k] if r else None, ret_addvec=self.ret_addvec, **nk))
@@ -504,7 +510,16 @@ class UpdateStepDriver(object):
         if slot.used:
             slot.event.synchronize()
         self._draw_rng(slot, K, phase)
+        self._to_storage_rows(slot, K)
         self._fill_pending(slot, phase)
+
+    def _to_storage_rows(self, slot, K):
+        """Logical replay indices of K rows -> storage rows, in place (see _make_batch: storage_rows)."""
+        start = self.mu.replay_buffer.start
+        if self.storage_rows and start:
+            idx = slot.np_idx[:K]
+            idx += start
+            idx[idx >= self.mu.replay_buffer.limit] -= self.mu.replay_buffer.limit
 
     def _fill_pending(self, slot, phase):
         if self.per and not self.per_dev and self.sched[phase] & self.A:
@@ -755,8 +770,8 @@ class UpdateStepDriver(object):
         phase = self.step_no % self.S
         role = self.sched[phase]
         rb = self.mu.replay_buffer
-        if rb.start != self._batch_start or (rb.num_entries != self._batch_entries and
-                                             (self.per or self.mu.hps.n_step_returns)):
+        if (not self.storage_rows and rb.start != self._batch_start) or (
+                rb.num_entries != self._batch_entries and (self.per or self.mu.hps.n_step_returns)):
             # transitions were appended since the plans were captured (the ring start and the entry
             # count are baked into them): re-read the geometry and capture again
             self.refresh()

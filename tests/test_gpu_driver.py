@@ -214,7 +214,7 @@ def _assert_weights(mu, d, ref, K, tag, nets=('actor', 'critic', 'targ_actor', '
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-ln', 'C1-launcher', 'C3-ret', 'C1-ret', 'C1-retn', 'C2-retn',
                                       'C1-nstep', 'widein', 'edge64', 'bigB', 'bigBper', 'ragged-launcher',
                                       'raggedper-ret', 'raggedperbig', 'raggedperbig-ret', 'C4', 'C4-retn', 'wsmall-ret', 'wsmall-retn',
-                                      'wsmall-nstep', 'wsmallper-ret'])
+                                      'wsmall-nstep', 'wsmallper-ret', 'C1-wrapped', 'ragged-wrapped', 'C3-wrapped'])
 def test_k_steps_match_oracle(cfg_name, graph):
     """C1-launcher: the canonical launcher options (mujoco_sam_imitate.sh): LayerNorm, rmsify_rets +
     PopArt, n-step returns (n = 7 here so that windows are cut by episode ends AND by num_entries)."""
@@ -253,6 +253,18 @@ def test_k_steps_match_oracle(cfg_name, graph):
     if opt and base not in extra:
         assert drv.fused or (base == 'C4' and drv.wide)   # LayerNorm included: whole-network kernels of fused_ln.hip
     drv.prepare()
+    if opt == 'wrapped':
+        # the ring is full: 45 appended transitions move its start.  Uniform replay: the driver's index words carry
+        # storage rows and its captured plans are the ones made BEFORE the appends; PER re-captures.
+        rs = np.random.RandomState(9)
+        assert mu.replay_buffer.num_entries == mu.replay_buffer.limit
+        plans_before = dict(drv.plans)
+        for t in range(45):
+            mu.store_transition(rs.randn(mu.ob_dim).astype(np.float32),
+                                rs.uniform(-1, 1, mu.ac_dim).astype(np.float32), float(rs.rand()),
+                                rs.randn(mu.ob_dim).astype(np.float32), float(t % 13 == 12))
+        assert mu.replay_buffer.start == 45
+        assert drv.storage_rows == (not cfg['per'])
     ref = OracleLearner(mu, d, pool, cfg['per'])
     # C4: the Humanoid-shaped configuration at its full batch (1024 rows, 256x256 nets) through the real driver
     # (captured graph, role-fused 256-wide kernels, two-stage D-input sums of the launch head)
@@ -264,14 +276,19 @@ def test_k_steps_match_oracle(cfg_name, graph):
         drv.step()
         torch.cuda.synchronize()
         h = lambda t: t.cpu().numpy()
+        rb_ = mu.replay_buffer
+        # (uniform replay: the index words hold storage rows; the oracle takes the reference's logical indices)
+        lg = (lambda t: (h(t) - rb_.start) % rb_.limit) if drv.storage_rows else h
+        if opt == 'wrapped' and drv.storage_rows:
+            assert drv.plans[(1, 0)] is plans_before[(1, 0)], 'the captured plan survives the appends'
         e0 = int(drv.e_start.item())
         eps_ob, eps_ac, real, _ = drv.step_randoms(k)   # what the kernels drew for update k
         # The driver samples its own rows, so the row redraw of nets_cases.keep_off_the_kink is not available
         # here; at full size every update meets units within fp32 rounding distance of the lrelu kink.  The
         # oracle is told the device's gradients and accounts for those units one by one (with_kinks).
         ref.gpu_g = {key: h(drv.L.seg(drv.L.grads, seg)) for seg, key in enumerate('acd')}
-        out = ref.step(h(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
-                       h(eps_ac), h(real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
+        out = ref.step(lg(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
+                       h(eps_ac), h(real), idx_a=lg(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
         if cfg['per']:
             assert np.array_equal(out['idx_a'], h(drv.idx_a)), 'PER indices differ at step %d' % k
         # the unclipped gradients of THIS update, every variable against its own max-norm
@@ -715,9 +732,10 @@ def test_device_priority_refresh_equals_host_refresh(cfg_name, g_steps):
 
 @pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'C1-retn'])
 def test_appending_transitions_between_runs(cfg_name):
-    """Rollouts append transitions between training phases (sam.py:305-321): the driver notices that the
-    ring geometry / entry count changed and re-captures.  Same learner state as a driver built AFTER the
-    append (bit for bit, PER trees included)."""
+    """Rollouts append transitions between training phases (sam.py:305-321).  Uniform replay: the index words carry
+    storage rows, the captured plans survive; PER / n-step returns: the driver notices that the ring geometry / entry
+    count changed and re-captures.  Same learner state as a driver built AFTER the append (bit for bit, PER trees
+    included); test_k_steps_match_oracle[*-wrapped] checks the moved ring against the oracle."""
     import bench
     from sam_tf_amd.comm import TorchComm
     from sam_tf_amd.driver import UpdateStepDriver
