@@ -147,6 +147,16 @@ int samx_nstep_lookahead_many(const float* rews, const float* dones1, int64_t ma
                               int64_t B, int n, double gamma, int64_t* end_idx_out, float* rews_out,
                               float* dones_out, float* td_len_out, void* stream);
 
+/* samx_nstep_lookahead_many on STORAGE rows: rows[k * row_stride + i] = (start + idx) % maxlen of the reference's
+ * logical index (memory.py:16-35), geom = int64[2] {start, num_entries} IN DEVICE MEMORY, end_row_out = storage row of
+ * the last kept transition.  The ring's geometry changes with every append (memory.py:36-57); a caller that replays a
+ * captured graph uploads it with the rows instead of re-capturing (UpdateStepDriver under uniform replay).  Same
+ * arithmetic as samx_nstep_lookahead (memory.py:113-160, math_util.py:32-43). */
+int samx_nstep_lookahead_many_rows(const float* rews, const float* dones1, int64_t maxlen, const int64_t* geom,
+                                   const int64_t* rows, int64_t row_stride, int64_t K, int64_t B, int n, double gamma,
+                                   int64_t* end_row_out, float* rews_out, float* dones_out, float* td_len_out,
+                                   void* stream);
+
 /* RingBuffer.append of one staged transition (memory.py:36-57,177-184): `row` is the physical
  * slot the host ring arithmetic chose; packed = [obs0(ob) | acs(ac) | rew | obs1(ob) | done]. */
 int samx_replay_write(float* obs0, float* acs, float* rews, float* dones1, float* obs1,

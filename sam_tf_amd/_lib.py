@@ -119,6 +119,7 @@ SIGNATURES = {
                                        _P, _P]),
     'samx_nstep_lookahead_many': (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, C.c_int, _D, _P, _P,
                                             _P, _P, _P]),
+    'samx_nstep_lookahead_many_rows': (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, C.c_int, _D, _P, _P, _P, _P, _P]),
     'samx_disc_ws_bytes': (_SZ, [_MP, _I64]),
     'samx_disc_grad': (C.c_int, [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int,
                                  _F, _P, _P, _P, _SZ, _P]),

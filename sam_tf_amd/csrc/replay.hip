@@ -149,15 +149,24 @@ __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ re
                                                     float* __restrict__ rews_out,
                                                     double* __restrict__ rews64_out,
                                                     float* __restrict__ dones_out,
-                                                    float* __restrict__ td_len_out) {
+                                                    float* __restrict__ td_len_out,
+                                                    const int64_t* __restrict__ geom) {
     const int64_t t = blockIdx.x * (int64_t)128 + threadIdx.x;
     if (t >= B) return;
     // batch k's indices start at idxs + k*idx_stride (the driver's per-row index words); outputs are dense
-    const int64_t idx = idxs[(t / rows_per_batch) * idx_stride + t % rows_per_batch];
+    int64_t idx = idxs[(t / rows_per_batch) * idx_stride + t % rows_per_batch];
+    int64_t phys0;
+    if (geom) {   // storage rows in, storage rows out; the ring's geometry from device memory (see nstep_group_kernel)
+        start = geom[0]; num_entries = geom[1];
+        phys0 = idx;
+        idx -= start;
+        if (idx < 0) idx += maxlen;
+    } else {
+        phys0 = start + idx;
+        if (phys0 >= maxlen) phys0 -= maxlen;
+    }
     const int64_t last = (idx + n < num_entries ? idx + n : num_entries) - 1;  // lookahead_end_idx
     const int win = (int)(last - idx + 1);
-    int64_t phys0 = start + idx;
-    if (phys0 >= maxlen) phys0 -= maxlen;
     // first done inside the window (NB loads in flight per batch: a window of n = 96 rows is three memory round
     // trips per pass, not twelve — the kernel is nothing but these round trips)
     constexpr int NB = 32;
@@ -188,7 +197,9 @@ __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ re
         for (int u = 0; u < NB; ++u)
             if (k0 - u >= 0) acc = __dadd_rn((double)r[u], __dmul_rn(gamma, acc));
     }
-    end_idx_out[t] = idx + td_len - 1;
+    int64_t end = idx + td_len - 1;
+    if (geom) { end = phys0 + td_len - 1; if (end >= maxlen) end -= maxlen; }
+    end_idx_out[t] = end;
     rews_out[t] = (float)acc;
     if (rews64_out) rews64_out[t] = acc;
     dones_out[t] = (hit >= 0 && hit != win - 1) ? 1.f : 0.f;
@@ -200,6 +211,9 @@ __global__ __launch_bounds__(128) void nstep_kernel(const float* __restrict__ re
 // lane and load — with one thread per index the kernel was 60 us of uncoalesced gathers on 32 CUs for 16 x 256
 // indices at n = 96), park them in LDS, and lane 0 of the group runs the reference's sequential arithmetic on them —
 // the same operations in the same order as nstep_kernel, so the same bits.
+// geom != nullptr (both kernels): the indices are STORAGE rows ((start + idx) % maxlen of the reference's logical
+// index, what the driver's index words carry under uniform replay), {start, num_entries} are read from device memory
+// — they change with every append, and a captured graph must not hold them — and end_idx_out is a storage row too.
 constexpr int kNstepGroupMax = 256;
 __global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restrict__ rews,
                                                           const float* __restrict__ dones1, int64_t maxlen,
@@ -210,7 +224,8 @@ __global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restric
                                                           float* __restrict__ rews_out,
                                                           double* __restrict__ rews64_out,
                                                           float* __restrict__ dones_out,
-                                                          float* __restrict__ td_len_out) {
+                                                          float* __restrict__ td_len_out,
+                                                          const int64_t* __restrict__ geom) {
     __shared__ float sd[16][kNstepGroupMax], sr[16][kNstepGroupMax];
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int64_t t = blockIdx.x * (int64_t)16 + g;
@@ -219,10 +234,17 @@ __global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restric
     int win = 0;
     if (valid) {
         idx = idxs[(t / rows_per_batch) * idx_stride + t % rows_per_batch];
+        if (geom) {
+            start = geom[0]; num_entries = geom[1];
+            phys0 = idx;
+            idx -= start;
+            if (idx < 0) idx += maxlen;
+        } else {
+            phys0 = start + idx;
+            if (phys0 >= maxlen) phys0 -= maxlen;
+        }
         const int64_t last = (idx + n < num_entries ? idx + n : num_entries) - 1;  // lookahead_end_idx
         win = (int)(last - idx + 1);
-        phys0 = start + idx;
-        if (phys0 >= maxlen) phys0 -= maxlen;
     }
     for (int k = l; k < win; k += 16) {
         int64_t p = phys0 + k;
@@ -238,7 +260,9 @@ __global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restric
     const int td_len = hit >= 0 ? hit + 1 : win;
     double acc = 0.0;
     for (int k = td_len - 1; k >= 0; --k) acc = __dadd_rn((double)sr[g][k], __dmul_rn(gamma, acc));
-    end_idx_out[t] = idx + td_len - 1;
+    int64_t end = idx + td_len - 1;
+    if (geom) { end = phys0 + td_len - 1; if (end >= maxlen) end -= maxlen; }
+    end_idx_out[t] = end;
     rews_out[t] = (float)acc;
     if (rews64_out) rews64_out[t] = acc;
     dones_out[t] = (hit >= 0 && hit != win - 1) ? 1.f : 0.f;
@@ -314,11 +338,11 @@ int samx_nstep_lookahead(const float* rews, const float* dones1, int64_t maxlen,
     if (n <= kNstepGroupMax)
         nstep_group_kernel<<<(unsigned)((B + 15) / 16), 256, 0, (hipStream_t)stream>>>(
             rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
-            dones_out, td_len_out);
+            dones_out, td_len_out, nullptr);
     else
         nstep_kernel<<<(unsigned)((B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
             rews, dones1, maxlen, start, num_entries, idxs, B, B, B, n, gamma, end_idx_out, rews_out, rews64_out,
-            dones_out, td_len_out);
+            dones_out, td_len_out, nullptr);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -336,11 +360,31 @@ int samx_nstep_lookahead_many(const float* rews, const float* dones1, int64_t ma
     if (n <= kNstepGroupMax)
         nstep_group_kernel<<<(unsigned)((K * B + 15) / 16), 256, 0, (hipStream_t)stream>>>(
             rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
-            nullptr, dones_out, td_len_out);
+            nullptr, dones_out, td_len_out, nullptr);
     else
         nstep_kernel<<<(unsigned)((K * B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
             rews, dones1, maxlen, start, num_entries, idxs, idx_stride, B, K * B, n, gamma, end_idx_out, rews_out,
-            nullptr, dones_out, td_len_out);
+            nullptr, dones_out, td_len_out, nullptr);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_nstep_lookahead_many_rows(const float* rews, const float* dones1, int64_t maxlen, const int64_t* geom,
+                                   const int64_t* rows, int64_t row_stride, int64_t K, int64_t B, int n, double gamma,
+                                   int64_t* end_row_out, float* rews_out, float* dones_out, float* td_len_out,
+                                   void* stream) {
+    SAMX_REQUIRE(rews && dones1 && geom && rows && end_row_out && rews_out && dones_out && td_len_out,
+                 "samx_nstep_lookahead_many_rows: null pointer");
+    SAMX_REQUIRE(B > 0 && K > 0 && row_stride >= B && n > 1 && n <= 4096 && maxlen > 0,
+                 "samx_nstep_lookahead_many_rows: need B > 0, K > 0, row_stride >= B, 1 < n <= 4096, maxlen > 0");
+    if (n <= kNstepGroupMax)
+        nstep_group_kernel<<<(unsigned)((K * B + 15) / 16), 256, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, 0, 0, rows, row_stride, B, K * B, n, gamma, end_row_out, rews_out, nullptr, dones_out,
+            td_len_out, geom);
+    else
+        nstep_kernel<<<(unsigned)((K * B + 127) / 128), 128, 0, (hipStream_t)stream>>>(
+            rews, dones1, maxlen, 0, 0, rows, row_stride, B, K * B, n, gamma, end_row_out, rews_out, nullptr, dones_out,
+            td_len_out, geom);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

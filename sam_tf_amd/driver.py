@@ -151,6 +151,7 @@ class UpdateStepDriver(object):
         self.idx_a = self.words[0, B:2 * B]
         self.e_start = self.words[0, 2 * B:2 * B + 1]
         self.u = self.words[0, 2 * B + 1:3 * B + 1].view(torch.float64)
+        self.geom = self.words[0, 2 * B + 1:2 * B + 3]   # uniform replay: {start, num_entries} (see _write_geom)
         # PER: the previous step's priority update rides in this launch's upload and is applied by the
         # first kernel of the launch (the host libm pow that produces it is the only host work between
         # two PER steps, memory.py:376-377)
@@ -201,12 +202,14 @@ class UpdateStepDriver(object):
         randoms are drawn inside the kernels."""
         rb, st = self.mu.replay_buffer, self.mu.replay_buffer.store
         B = self.B
-        # Uniform replay without n-step returns: the index words carry STORAGE rows — the host adds the ring's start to
-        # its draws (memory.py:16-35: data[(start + idx) % maxlen]) — and the kernels see a ring that starts at 0, so
-        # the captured graphs survive every append, also once the ring is full and each append moves its start (the
+        # Uniform replay: the index words carry STORAGE rows — the host adds the ring's start to its draws
+        # (memory.py:16-35: data[(start + idx) % maxlen]) — and the kernels see a ring that starts at 0, so the
+        # captured graphs survive every append, also once the ring is full and each append moves its start (the
         # reference's loop appends between any two training phases; re-capturing there cost more than the phase).
-        # PER and n-step returns work on logical indices on the device (trees, windows) and keep the ring's start.
-        self.storage_rows = bool(not self.per and not self.mu.hps.n_step_returns)
+        # The n-step lookahead needs the ring's geometry (window ends at num_entries): {start, num_entries} ride in
+        # two spare words of row 0 of the same upload and the kernel reads them there
+        # (samx_nstep_lookahead_many_rows).  PER works on logical indices on the device (trees) and keeps the start.
+        self.storage_rows = bool(not self.per and os.environ.get('SAMX_STORAGE_ROWS', '1') != '0')
         self._batch_start = 0 if self.storage_rows else rb.start
         self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
@@ -269,9 +272,13 @@ class UpdateStepDriver(object):
         words 0 and their results are not used)."""
         if self.nstep_ahead:
             rb, hp = self.mu.replay_buffer, self.mu.hps
-            ops.nstep_lookahead_many(rb.store, self._batch_start, self._batch_entries, self.words[:K], self.B,
-                                     self.B, hp.n, hp.gamma, self.n_end[:K], self.n_rews[:K], self.n_dones[:K],
-                                     self.n_len[:K])
+            if self.storage_rows:
+                ops.nstep_lookahead_many_rows(rb.store, self.geom, self.words[:K], self.B, self.B, hp.n, hp.gamma,
+                                              self.n_end[:K], self.n_rews[:K], self.n_dones[:K], self.n_len[:K])
+            else:
+                ops.nstep_lookahead_many(rb.store, self._batch_start, self._batch_entries, self.words[:K], self.B,
+                                         self.B, hp.n, hp.gamma, self.n_end[:K], self.n_rews[:K], self.n_dones[:K],
+                                         self.n_len[:K])
 
     def _masks(self, role):
         """(part bits, apply-mode bits) that leave out the roles a row does not carry (samx.h)."""
@@ -515,11 +522,20 @@ class UpdateStepDriver(object):
 
     def _to_storage_rows(self, slot, K):
         """Logical replay indices of K rows -> storage rows, in place (see _make_batch: storage_rows)."""
-        start = self.mu.replay_buffer.start
-        if self.storage_rows and start:
-            idx = slot.np_idx[:K]
-            idx += start
-            idx[idx >= self.mu.replay_buffer.limit] -= self.mu.replay_buffer.limit
+        rb = self.mu.replay_buffer
+        if self.storage_rows:
+            if rb.start:
+                idx = slot.np_idx[:K]
+                idx += rb.start
+                idx[idx >= rb.limit] -= rb.limit
+            self._write_geom(slot)
+
+    def _write_geom(self, slot):
+        """{start, num_entries} of the ring as this launch finds it, in the two words behind row 0's e_start (the PER
+        uniforms' place, unused under uniform replay): device view self.geom."""
+        rb = self.mu.replay_buffer
+        slot.np_words[0, 2 * self.B + 1] = rb.start
+        slot.np_words[0, 2 * self.B + 2] = rb.num_entries
 
     def _fill_pending(self, slot, phase):
         if self.per and not self.per_dev and self.sched[phase] & self.A:
@@ -714,6 +730,8 @@ class UpdateStepDriver(object):
             slot.event.synchronize()
         slot.np_idx[:K] = np.random.randint(low=0, high=mu.replay_buffer.num_entries, size=(K, 2, self.B))
         slot.np_e[:K] = 0
+        if self.storage_rows:
+            self._write_geom(slot)
         if self.per:
             for k in range(K):
                 slot.np_u[k] = mu.replay_buffer.draw_uniforms(self.B)
@@ -770,8 +788,7 @@ class UpdateStepDriver(object):
         phase = self.step_no % self.S
         role = self.sched[phase]
         rb = self.mu.replay_buffer
-        if (not self.storage_rows and rb.start != self._batch_start) or (
-                rb.num_entries != self._batch_entries and (self.per or self.mu.hps.n_step_returns)):
+        if not self.storage_rows and (rb.start != self._batch_start or rb.num_entries != self._batch_entries):
             # transitions were appended since the plans were captured (the ring start and the entry
             # count are baked into them): re-read the geometry and capture again
             self.refresh()

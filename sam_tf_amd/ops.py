@@ -454,6 +454,23 @@ def nstep_lookahead_many(store, start, num_entries, words, a_off, B, n, gamma, e
                                          float(gamma), ptr(end), ptr(rews), ptr(dones), ptr(tl), stream_ptr()))
 
 
+def nstep_lookahead_many_rows(store, geom, words, a_off, B, n, gamma, end, rews, dones, tl):
+    """nstep_lookahead_many on storage rows: words[k, a_off:a_off+B] hold (start + idx) % maxlen, geom is int64[2]
+    {start, num_entries} in device memory, `end` receives storage rows (include/samx.h)."""
+    K, W = words.shape
+    _chk(words, I64, (K, W), 'words')
+    _chk(geom, I64, (2,), 'geom')
+    assert 0 <= a_off and a_off + B <= W
+    maxlen = store['rews'].shape[0]
+    _chk(store['rews'], F32, (maxlen, 1), 'rews'); _chk(store['dones1'], F32, (maxlen, 1), 'dones1')
+    _chk(end, I64, (K, B), 'end')
+    for t, nm in ((rews, 'rews'), (dones, 'dones'), (tl, 'tl')):
+        _chk(t, F32, (K, B), nm)
+    check(_L().samx_nstep_lookahead_many_rows(ptr(store['rews']), ptr(store['dones1']), maxlen, geom.data_ptr(),
+                                              words.data_ptr() + 8 * a_off, W, K, B, int(n), float(gamma), ptr(end),
+                                              ptr(rews), ptr(dones), ptr(tl), stream_ptr()))
+
+
 def disc_grad(dd, pd, p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, real, fake, mean, std, ent_scale, ws,
               losses=None, grad=None):
     B, ob = p_obs.shape

@@ -240,6 +240,37 @@ def test_nstep_lookahead_many_matches_single(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n', [7, 96, 300])
+@pytest.mark.parametrize('filled', [300, 823])
+def test_nstep_lookahead_on_storage_rows(n, filled):
+    """samx_nstep_lookahead_many_rows (storage rows in and out, the ring's geometry from device memory) against
+    samx_nstep_lookahead on the logical indices: a ring that is not full yet (start 0, windows cut by num_entries)
+    and one that wrapped (start 123)."""
+    from sam_tf_amd import memory as XP, ops
+    limit, ob, ac = 700, 3, 2
+    rs = np.random.RandomState(n + filled)
+    rb = XP.RB(limit, (ob,), (ac,))
+    for i in range(filled):
+        rb.append(rs.randn(ob).astype(np.float32), rs.uniform(-1, 1, ac).astype(np.float32), float(rs.uniform(0, 5)),
+                  rs.randn(ob).astype(np.float32), float(rs.rand() < 0.025))
+    assert rb.start == max(0, filled - limit)
+    K, B, off = 3, 50, 4
+    W = off + B + 2
+    idx = rs.randint(0, rb.num_entries, size=(K, W)).astype(np.int64)
+    idx[0, off:off + 5] = np.arange(rb.num_entries - 5, rb.num_entries)   # windows that run into num_entries
+    rows = (idx + rb.start) % limit
+    geom = torch.as_tensor(np.array([rb.start, rb.num_entries], dtype=np.int64)).cuda()
+    end = torch.zeros(K, B, dtype=torch.int64, device='cuda')
+    rews, dones, tl = (torch.zeros(K, B, dtype=torch.float32, device='cuda') for _ in range(3))
+    ops.nstep_lookahead_many_rows(rb.store, geom, torch.as_tensor(rows).cuda(), off, B, n, 0.99, end, rews, dones, tl)
+    for k in range(K):
+        e1, r1, d1, t1 = ops.nstep_lookahead(rb.store, rb.start, rb.num_entries,
+                                             torch.as_tensor(idx[k, off:off + B].copy()).cuda(), n, 0.99)
+        assert torch.equal(end[k], (e1 + rb.start) % limit)
+        assert torch.equal(rews[k], r1) and torch.equal(dones[k], d1) and torch.equal(tl[k], t1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n', [2, 7, 96, 256, 300])
 def test_nstep_lookahead_window_lengths_vs_oracle(n):
     """Both lookahead kernels — sixteen lanes per sampled index for windows of up to 256 rows, one thread per index

@@ -13,6 +13,8 @@ import bench  # noqa: E402
 from sam_tf_amd.comm import TorchComm  # noqa: E402
 
 cfg = dict(bench.CONFIGS['C2'], mem=65536, d_steps=1, g_steps=3)
+if len(sys.argv) > 1 and sys.argv[1] == 'launcher':   # LayerNorm, return normalisation + PopArt, n-step returns n = 96
+    cfg.update(ln=True, ret=True, nstep=96)
 mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 0, True)
 assert mu.replay_buffer.num_entries == mu.replay_buffer.limit
 drv.prepare_all()
