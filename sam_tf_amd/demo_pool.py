@@ -28,10 +28,24 @@ class DevicePairPool(object):
         self.init_pointer()
 
     def init_pointer(self):
+        self.apply_permutation(self.shuffle_host())
+
+    def shuffle_host(self):
+        """The host half of demo_dataset.py:33-40's reshuffle: pointer back to 0 and the np.random.shuffle draw at
+        its place in the generator's stream.  Returns the permutation (None without `randomize`) for
+        apply_permutation — a caller that draws batches AHEAD of launching the rows that read them (the update-step
+        driver) applies it only when the row that owns the wrapping batch comes up, so rows drawn before the wrap
+        still read the old order."""
         self.pointer = 0
-        if self.randomize:
-            indices = np.arange(self.num_entries)
-            np.random.shuffle(indices)  # same generator as the reference
+        if not self.randomize:
+            return None
+        indices = np.arange(self.num_entries)
+        np.random.shuffle(indices)  # same generator as the reference
+        return indices
+
+    def apply_permutation(self, indices):
+        """The device half: permute the resident pairs in place, stream-ordered."""
+        if indices is not None:
             # permute in place: the storage address stays fixed (captured HIP graphs read it)
             if self._stage is None:
                 idx = torch.as_tensor(indices).to(self.device)

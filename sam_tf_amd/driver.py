@@ -562,9 +562,14 @@ class UpdateStepDriver(object):
         c = {'d': [], 'a': []}
         for kind in self.dseq:
             idx = self._d_indices(kind, N)
+            # (the reshuffle's np.random.shuffle draw is made here, at its place in the generator's stream; the
+            # device-resident pool is permuted when the row that owns this batch is handed its words — the D rows
+            # of this training step drawn before it are launched first and read the old order, as the reference's
+            # loop does: demo_dataset.py:33-40 reshuffles after handing out batch j - 1)
+            perm = False
             if self.pool.pointer + B >= self.pool.num_entries:
-                self.pool.init_pointer()
-            c['d'].append((idx, self.pool.pointer))
+                perm = self.pool.shuffle_host()
+            c['d'].append((idx, self.pool.pointer, perm))
             self.pool.pointer += B
         if self.pn_freq and t_index % self.pn_freq == 0:
             self._adapt_param_noise()
@@ -591,7 +596,10 @@ class UpdateStepDriver(object):
                 slot.np_e[k] = 0
                 slot.np_idx_p[k] = 0
                 if roles[k] & self.D:
-                    slot.np_idx_p[k], slot.np_e[k] = self._cache['d'].pop(0)
+                    slot.np_idx_p[k], slot.np_e[k], perm = self._cache['d'].pop(0)
+                    if perm is not False:
+                        assert k == 0, "a reshuffle of the expert pool cannot fall inside a multi-row launch"
+                        self.pool.apply_permutation(perm)
                 if roles[k] & self.A:
                     if self.per:
                         slot.np_u[k] = self._cache['a'].pop(0)
