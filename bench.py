@@ -109,6 +109,72 @@ def build_learner(cfg, comm, device, seed, use_graph):
     return mu, d, pool, drv
 
 
+def object_api_loop(mu, d, expert_dataset, comm, n_training_steps, d_steps=1, g_steps=1):
+    """The body of the reference's training loop, call for call (sam.py:369-433, window = None, no parameter
+    noise): per d_step  sample(_uniform) -> get_next_pair_batch -> d.obs_rms.update -> d.get_grads ->
+    d.get_losses -> d.optimize ; per g_step  mu.train() -> mu.update_target_net().  Everything the reference
+    receives as numpy / python objects is received as such here (and kept, as its deques do)."""
+    batch_size = mu.hps.batch_size
+    keep = []
+    for _ in range(n_training_steps):
+        for _ in range(d_steps):
+            sample_ = mu.replay_buffer.sample
+            if hasattr(mu.replay_buffer, 'sample_uniform'):
+                sample_ = mu.replay_buffer.sample_uniform
+            xp_batch_ = sample_(batch_size=batch_size)
+            ob_pol_, ac_pol_ = xp_batch_['obs0'], xp_batch_['acs']
+            ob_exp_, ac_exp_ = expert_dataset.get_next_pair_batch(batch_size=batch_size)
+            assert len(ob_exp_) == len(ob_pol_), "length mismatch"
+            if hasattr(d, "obs_rms"):
+                d.obs_rms.update(np.concatenate((ob_pol_, ob_exp_), axis=0), comm)
+            feeds_ = {d.p_obs: ob_pol_, d.p_acs: ac_pol_, d.e_obs: ob_exp_, d.e_acs: ac_exp_}
+            d_grads = d.get_grads(feeds_)
+            d_losses = d.get_losses(feeds_)
+            d.optimize(feeds_)
+            keep = [d_grads, d_losses]
+        for _ in range(g_steps):
+            losses_and_grads = mu.train()
+            keep.append(losses_and_grads)
+            mu.update_target_net()
+    return keep
+
+
+class HostPairs(object):
+    """expert_dataset of the loop above: the reference's host-side PairDataset behind get_next_pair_batch
+    (demo_dataset.py:6-41,94-101)."""
+
+    def __init__(self, obs0, acs):
+        from sam_tf_amd.demo_dataset import PairDataset
+        self.pairs = PairDataset(np.asarray(obs0, dtype=np.float32), np.asarray(acs, dtype=np.float32), True)
+
+    def get_next_pair_batch(self, batch_size):
+        return self.pairs.get_next_batch(batch_size)
+
+
+def object_api_rate(cfg, comm, device, seed, n, warm, d_steps=1, g_steps=1):
+    """Update steps/s through the OBJECT API (the drop-in surface, one host synchronisation per returned
+    object): the loop body of sam.py:369-433 with d_steps = g_steps = 1, synthetic inputs as everywhere else."""
+    import gc
+    mu, d, pool, drv = build_learner(cfg, comm, device, seed, False)
+    del drv
+    rs = np.random.RandomState(4321)
+    data = HostPairs(rs.randn(32000, cfg['ob']) + 0.5, rs.uniform(-1, 1, (32000, cfg['ac'])))
+    object_api_loop(mu, d, data, comm, warm, d_steps, g_steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    object_api_loop(mu, d, data, comm, n, d_steps, g_steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
+    path = {0: 'layer-wise', 1: 'fused-64', 2: 'role-fused-256'}[mu.L.path(cfg['B'])]
+    del mu, d, pool
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {'steps_per_s': n / el, 'ms_per_step': el / n * 1e3, 'steps': n, 'warmup': warm, 'step_path': path,
+            'finite_params': ok, 'calls_per_step': 'sample_uniform|sample, get_next_pair_batch, d.obs_rms.update, '
+            'd.get_grads, d.get_losses, d.optimize, mu.train, mu.update_target_net (sam.py:369-433)'}
+
+
 def time_passes(drv, cfg, iters=50):
     """Average device time of the step's passes, HIP events recorded on the launch stream (torch's
     current stream is the stream every libsamx call is handed)."""
@@ -250,6 +316,9 @@ def main():
     ap.add_argument('--no-others', action='store_true',
                     help='skip the short C3/C4/C5 runs the default (C2, one GPU) invocation appends as '
                          'config.other_configs')
+    ap.add_argument('--object-api', action='store_true',
+                    help='only measure the update step through the object API (sam.py:369-433 call for call) for '
+                         '--config, print its JSON and exit')
     ap.add_argument('--no-training-step', action='store_true',
                     help='skip the extra d_steps=1 : g_steps=3 training-step figure (config.training_steps_per_s)')
     args = ap.parse_args()
@@ -282,6 +351,10 @@ def main():
     nstep = 96 if args.launcher else (10 if args.argparse_defaults else 0)
     cfg = dict(CONFIGS[args.config], ln=args.layernorm or args.launcher, ret=args.launcher or args.argparse_defaults,
                nstep=nstep if not CONFIGS[args.config]['per'] else 0)
+    if args.object_api:
+        print(json.dumps({'config': args.config, 'object_api': object_api_rate(cfg, comm, device, args.seed,
+                                                                                args.steps, args.warmup)}), flush=True)
+        return
     mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, not args.no_graph)
 
     def timed():
@@ -470,6 +543,16 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         result['config']['other_configs'] = other_configs(comm, device, args)
+        # the same update step through the reference's own object calls (SAMAgent.train, Discriminator.get_grads /
+        # get_losses / optimize, replay sample, obs_rms.update) instead of the update-step driver
+        oa = {}
+        for name, n, warm in (('C2', 1000, 100), ('C4', 300, 30)):
+            try:
+                oa[name] = object_api_rate(dict(CONFIGS[name], ln=False, ret=False, nstep=0), comm, device,
+                                           args.seed, n, warm)
+            except Exception as e:  # noqa: BLE001
+                oa[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+        result['config']['object_api_steps_per_s'] = oa
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline(cfg)

@@ -34,6 +34,10 @@ extern "C" {
 
 const char* samx_last_error(void);
 int samx_version(void);
+/* Wait until everything enqueued on `stream` has completed (hipStreamSynchronize).  The one host wait of an
+ * object-mirror call that returns host values (SAMAgent.train, Discriminator.get_grads / get_losses,
+ * RB.sample: the reference's sess.run blocks the same way, helpers/tf_util.py:11-28). */
+int samx_stream_synchronize(void* stream);
 
 /* ---- network description ------------------------------------------------------------------ */
 /* Two hidden layers, leaky-ReLU(0.2), optional post-activation LayerNorm (eps 1e-8):
@@ -532,7 +536,10 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
  * only [lookahead ->] targets -> batch sums into batch.ret_addvec and returns; after the caller's
  * all-reduce(SUM) of ret_addvec, part bit 5 (value 32) resumes: commit of ret_addvec, PopArt, then the
  * loss/gradient passes as usual against out.targ_q (/ targ_q_n) of the first call.  Same learner, batch,
- * out and workspace in both calls. */
+ * out and workspace in both calls.
+ * Part bit 6 (value 64): the update counters of the roles are NOT advanced — an evaluation that no optimiser
+ * pass follows (d.get_grads / d.get_losses, sam.py:398-399: the reference runs them as sess.runs of their own
+ * before d.optimize). */
 int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const samx_step_out* out,
                          void* ws, size_t ws_bytes, int part, void* stream);
 
@@ -541,7 +548,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const s
  * mode bit 1: grads * grad_scale -> clip_by_global_norm -> Adam -> Polyak on the agent's targets;
  * mode bit 2: recompute the norms first (set it when grads changed after samx_step_grads, i.e. after
  * the all-reduce); mode bit 3 (value 8): leave the reward-net segment out, bit 4 (value 16): leave the
- * actor and critic segments out (role subsets, see samx_step_grads_part).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
+ * actor and critic segments out (role subsets, see samx_step_grads_part); bit 5 (value 32): no Polyak step on
+ * the targets (mu.train() and mu.update_target_net() are separate calls in the reference's loop, sam.py:421,433:
+ * the object mirror runs the target update through samx_polyak).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
  * grad_scale = 1/N.  `ws` must be the workspace samx_step_grads used, B the same batch size. */
 int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale, void* ws,
                     size_t ws_bytes, void* stream);

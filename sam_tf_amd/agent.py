@@ -4,22 +4,35 @@ State in HBM (float32 unless noted):
   params  = [actor | critic]            one flat vector -> ONE all-reduce bucket per update
   targets = [targ_actor | targ_critic]  same layout, Polyak-tracked in one launch
   grads, Adam m/v with the same layout; obs running sums (float64); replay storage (memory.py)
-`train()` keeps the reference's return value (numpy, sam_agent.py:706-711); `train_device()` is the
-same update with everything left on the GPU.
+`train()` keeps the reference's return value (numpy, sam_agent.py:706-711).  It runs the agent roles of the
+whole-step entry points (samx_step_grads_part without the discriminator role + samx_step_apply on the actor /
+critic segments, no Polyak: the fused / role-fused / layer-wise kernels the update-step driver uses), on rows read
+in place from the replay storage; the returned dict is ONE host synchronisation — the kernels store the clipped
+gradients and the losses straight into pinned host memory.  `train_per_role()` is the same update through the
+per-role entry points (samx_targ_q / samx_actor_grad / samx_critic_grad / samx_clip_adam).
 
 Return normalisation + PopArt (sam_agent.py:161-201,554-590,662-672) and n-step returns
 (sam_agent.py:483-498,634-660 ; memory.py:113-175) and adaptive parameter-space noise
 (sam_agent.py:40-58,352-404,727-749) are built.
 """
+import ctypes as C
+import os
+import types
+
 import numpy as np
 import torch
 
+from . import _lib
 from . import memory as XP
 from . import ops
 from .hps import check_supported
 from .mpi_adam import MpiAdam
 from .networks import FlatNet, init_flat
 from .running_mean_std import DeviceRunningMeanStd
+
+
+# SAMX_OBJECT_API=per_role: the object mirror's update calls go through the per-role entry points (A/B runs)
+_PER_ROLE = os.environ.get('SAMX_OBJECT_API', '') == 'per_role'
 
 
 class NormalAcNoise(object):
@@ -111,7 +124,7 @@ class SAMAgent(object):
         self.params, self.targets = L.params[:Pac], L.targets
         self.grads, self.clipped = L.grads[:Pac], L.clipped[:Pac]
         self.params.copy_(torch.as_tensor(init).to(self.device))
-        d.rebind(L.seg(L.params, 2), L.seg(L.grads, 2), L.seg(L.m, 2), L.seg(L.v, 2), L.steps[2:3])
+        d.rebind(L.seg(L.params, 2), L.seg(L.grads, 2), L.seg(L.m, 2), L.seg(L.v, 2), L.steps[2:3], learner=L)
         a, c = slice(0, self.Pa), slice(self.Pa, self.Pa + self.Pc)
         self.actor = FlatNet(self.scope, 'online_actor', self.da, self.params[a])
         self.critic = FlatNet(self.scope, 'online_critic', self.dc, self.params[c])
@@ -343,8 +356,127 @@ class SAMAgent(object):
             self.refresh_priorities(batch)
         return batch
 
+    # ---- the update behind the reference's own call: the agent roles of the whole-step kernels --------------
+    def _fast(self):
+        """One-time set-up of train(): staging, the batch / output structs, a twin of the learner struct whose
+        `clipped` vector lives in pinned host memory (the optimiser pass stores the logged gradients there)."""
+        if getattr(self, '_f', None) is not None:
+            return self._f
+        L, hp, rb = self.L, self.hps, self.replay_buffer
+        B, dev = hp.batch_size, self.device
+        Pac = self.Pa + self.Pc
+        f = types.SimpleNamespace()
+        f.lib = _lib.lib()
+        # pinned results: [actor_losses 3 | critic_losses 4 (td1, wd, total, tdn) | pad | clipped actor | clipped critic]
+        f.pin = torch.zeros(8 + Pac, dtype=torch.float32).pin_memory()
+        f.res = f.pin.numpy()
+        f.c = _lib.Learner.from_buffer_copy(L.c)
+        f.c.clipped = f.pin.data_ptr() + 32
+        f.out = ops.make_step_out(B, dev)
+        f.out.actor_losses = f.pin.data_ptr()
+        f.out.critic_losses = f.pin.data_ptr() + 12
+        f.idx_pin = torch.zeros(B, dtype=torch.int64).pin_memory()
+        f.idx_np = f.idx_pin.numpy()
+        f.idx_dev = torch.zeros(B, dtype=torch.int64, device=dev)
+        st = rb.store
+        kw = {}
+        f.per = bool(hp.prioritized_replay)
+        # uniform replay on the whole-network path: the kernels read the B index words straight from the pinned
+        # staging (each once per tile) — no upload in front of the launch
+        f.idx_zero_copy = bool(not f.per and L.path(B) == 1)
+        idx_words = f.idx_pin if f.idx_zero_copy else f.idx_dev
+        if f.per:
+            f.u_pin = torch.zeros(B, dtype=torch.float64).pin_memory()
+            f.u_np = f.u_pin.numpy()
+            f.u_dev = torch.zeros(B, dtype=torch.float64, device=dev)
+            f.iws = torch.zeros(B, dtype=torch.float64, device=dev)
+            f.iws32 = torch.zeros(B, dtype=torch.float32, device=dev)
+            f.td_post = torch.zeros(B, dtype=torch.float32, device=dev)
+            # the refreshed TD errors and the sampled indices land in pinned host memory (same launch)
+            f.td_pin = torch.zeros(B, dtype=torch.float32).pin_memory()
+            f.pidx_pin = torch.zeros(B, dtype=torch.int64).pin_memory()
+            f.td_np, f.pidx_np = f.td_pin.numpy(), f.pidx_pin.numpy()
+            f.leaf_pin = torch.zeros(B, dtype=torch.float64).pin_memory()
+            f.leaf_np = f.leaf_pin.numpy()
+            f.leaf_dev = torch.zeros(B, dtype=torch.float64, device=dev)
+            kw['iws'] = f.iws32
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            f.tree_s, f.tree_m, f.u_p, f.idx_p = vp(rb.trees.sum), vp(rb.trees.min), vp(f.u_pin), vp(f.idx_dev)
+            f.iws_p, f.iws32_p = vp(f.iws), vp(f.iws32)
+        self.world = self.comm.Get_size()
+        f.popart_split = bool(self.world > 1 and hp.rmsify_rets and hp.enable_popart)
+        if f.popart_split:
+            f.ret_addvec = torch.zeros(6, dtype=torch.float64, device=dev)
+            kw['ret_addvec'] = f.ret_addvec
+        # rows are read in place through the index words; the discriminator's inputs are never read by a call
+        # that leaves its role out (they only have to be non-null)
+        f.batch = ops.make_batch(B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=st['obs0'], e_acs=st['acs'],
+                                 obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1),
+                                 dones1=st['dones1'].view(-1), obs1=st['obs1'], a_idx=idx_words, p_idx=idx_words,
+                                 e_start=idx_words[:1], ring_start=rb.start, ring_len=rb.limit, rng_seed=0,
+                                 label_smoothing=0, num_entries=rb.num_entries, host_ok=f.idx_zero_copy, **kw)
+        f.ws = L.ws(B)
+        f.ws_p, f.ws_n = C.c_void_p(f.ws.data_ptr()), f.ws.numel()
+        self._f = f
+        return f
+
     def train(self):
         """sam_agent.py:631-711."""
+        if _PER_ROLE:
+            return self.train_per_role()
+        f = self._fast()
+        lib, L, rb, hp = f.lib, self.L, self.replay_buffer, self.hps
+        B = hp.batch_size
+        b = f.batch
+        b.ring_start, b.num_entries = rb.start, rb.num_entries   # the ring as this call finds it
+        st = _lib.stream_ptr()
+        chk = _lib.check
+        if f.per:   # memory.py:248-309: stratified draws with `random`, descent and weights on the device trees
+            assert rb.num_entries
+            f.u_np[:] = rb.draw_uniforms(B)
+            # (the sampling kernel reads its B uniforms once: straight from the pinned staging)
+            chk(lib.samx_per_sample(f.tree_s, f.tree_m, rb.st_cap, rb.num_entries, f.u_p, B, rb.beta, f.idx_p,
+                                    f.iws_p, f.iws32_p, st))
+        else:       # memory.py:90
+            f.idx_np[:] = np.random.randint(low=0, high=rb.num_entries, size=B)
+            if not f.idx_zero_copy:
+                f.idx_dev.copy_(f.idx_pin, non_blocking=True)
+        cL, cb, co = C.byref(f.c), C.byref(b), C.byref(f.out)
+        if f.popart_split:   # ret_rms.update all-reduces the targets' sums before PopArt (sam_agent.py:662-672)
+            chk(lib.samx_step_grads_part(cL, cb, co, f.ws_p, f.ws_n, 1 | 4 | 16, st))
+            self.comm.allreduce_(f.ret_addvec)
+            chk(lib.samx_step_grads_part(cL, cb, co, f.ws_p, f.ws_n, 3 | 4 | 32, st))
+        else:
+            chk(lib.samx_step_grads_part(cL, cb, co, f.ws_p, f.ws_n, 3 | 4, st))
+        # flatgrad(..., clip_norm) copies for the caller (tf_util.py:137-151), then MpiAdam: mean over the workers,
+        # clip, Adam (mpi_adam.py:18-36) on the actor and critic segments; no Polyak (update_target_net is its own call)
+        if self.world == 1:
+            chk(lib.samx_step_apply(cL, B, 3 | 8 | 32, 1.0, f.ws_p, f.ws_n, st))
+        else:
+            chk(lib.samx_step_apply(cL, B, 1 | 8, 1.0, f.ws_p, f.ws_n, st))
+            self.comm.allreduce_(self.grads)
+            chk(lib.samx_step_apply(cL, B, 2 | 4 | 8 | 32, 1.0 / self.world, f.ws_p, f.ws_n, st))
+        if f.per:   # TD errors with the POST-update critic (sam_agent.py:693-701), copies to pinned host memory
+            mean, std = self._mean_std()
+            ops.td_errors_rows(self.dc, self.critic.flat, rb.store['obs0'], rb.store['acs'], f.idx_dev, rb.start,
+                               f.out.t['targ_q'], mean, std, f.td_post, ret=self.ret, td_host=f.td_pin,
+                               idx_host=f.pidx_pin)
+        chk(lib.samx_stream_synchronize(st))   # the one host wait of the call
+        r, Pa = f.res, self.Pa
+        cl = r[3:7]
+        out = {'actor_grads': r[8:8 + Pa].copy(),
+               'actor_losses': [float(r[0]), float(r[1]), float(r[2])],
+               'critic_grads': r[8 + Pa:].copy(),
+               'critic_losses': ([float(cl[0]), float(cl[3]), float(cl[1]), float(cl[2])] if hp.n_step_returns
+                                 else [float(cl[0]), float(cl[1]), float(cl[2])])}
+        if f.per:   # sam_agent.py:702-703 -> memory.py:344-379: asserts + libm pow on the host, trees on the device
+            rb.leaves_from_td(f.pidx_np, f.td_np, f.leaf_np)
+            f.leaf_dev.copy_(f.leaf_pin, non_blocking=True)
+            rb.trees.set(f.idx_dev, f.leaf_dev)   # (idx_dev still holds this call's sample)
+        return out
+
+    def train_per_role(self):
+        """train() through the per-role entry points (one launch chain per network pass)."""
         self.train_device()
         cl = self.clipped.cpu().numpy()
         return {'actor_grads': cl[:self.Pa].copy(),

@@ -25,6 +25,11 @@ extern "C" {
 const char* samx_last_error(void) { return samx::err_buf(); }
 int samx_version(void) { return 100; }
 
+int samx_stream_synchronize(void* stream) {
+    SAMX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SAMX_OK;
+}
+
 int64_t samx_mlp_param_count(const samx_mlp* d) {
     if (!d) return -1;
     int64_t ln = d->layernorm ? 2 * (int64_t)(d->h1 + d->h2) : 0;

@@ -1640,7 +1640,7 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         WFinishSeg& s = f.seg[f.nseg++];
         s.n = n; s.grad = grad; s.nblocks = fused::seg_blocks(n);
         s.sumsq = sumsq + k * fused::kMaxSegBlocks;
-        s.step_dev = L->steps + k;
+        s.step_dev = (part & 4) ? nullptr : L->steps + k;   // part bit 2 here: no counter tick
         return s;
     };
     if (do_a) {

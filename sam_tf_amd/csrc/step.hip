@@ -136,7 +136,8 @@ int check_learner(const samx_learner* L, const char* who) {
 }
 
 // segs: bit k set = optimiser segment k (0 actor, 1 critic, 2 reward net) takes part
-fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale, int segs = 7) {
+fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale, int segs = 7,
+                            bool polyak = true) {
     const int64_t Pa = samx_mlp_param_count(&L->actor), Pc = samx_mlp_param_count(&L->critic),
                   Pd = samx_mlp_param_count(&L->reward);
     const int64_t off[3] = {0, Pa, Pa + Pc}, n[3] = {Pa, Pc, Pd};
@@ -152,7 +153,7 @@ fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, fl
         s.param = L->params + off[k];
         s.m = L->adam_m + off[k];
         s.v = L->adam_v + off[k];
-        s.targ = k < 2 ? L->targets + off[k] : nullptr;
+        s.targ = (k < 2 && polyak) ? L->targets + off[k] : nullptr;
         s.clipped = L->clipped ? L->clipped + off[k] : nullptr;
         s.grad = L->grads + off[k];
         s.n = n[k];
@@ -806,8 +807,9 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
 int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                          size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
-    SAMX_REQUIRE((part & ~63) == 0 && (part & 3) != 0 && (part & 12) != 12,
-                 "samx_step_grads_part: part uses bits 0-5, needs bit 0 or 1, and cannot skip both roles");
+    SAMX_REQUIRE((part & ~127) == 0 && (part & 3) != 0 && (part & 12) != 12,
+                 "samx_step_grads_part: part uses bits 0-6, needs bit 0 or 1, and cannot skip both roles");
+    const bool tick = !(part & 64);   // bit 6: an evaluation that no update follows (d.get_grads / d.get_losses)
     const bool do_d = !(part & 4), do_a = !(part & 8);   // roles of this call
     const bool t_only = part & 16, t_done = part & 32;   // PopArt with N processes: the call split at the all-reduce
     if (t_only || t_done) {
@@ -859,7 +861,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     if (!use_fused(L, B) && !wide && !(part & 1)) {  // reduction part only
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
         rc = fused::launch_seg_sumsq(f, st);
-        if (rc != SAMX_OK) return rc;
+        if (rc != SAMX_OK || !tick) return rc;
         return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
                                   do_d ? L->steps + 2 : nullptr, st);
     }
@@ -868,7 +870,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         samx::WideExt we;
         auto roles = [&](const samx::WideExt* e) {
             return samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes,
-                                         w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, part & 3, st, e);
+                                         w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, (part & 3) | (tick ? 0 : 4), st, e);
         };
         if (do_a && (L->ret_mean || L->n_step > 0)) {
             // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
@@ -1033,7 +1035,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         if (!(part & 2)) return SAMX_OK;
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
         rc = fused::launch_seg_sumsq(f, st);
-        if (rc != SAMX_OK) return rc;
+        if (rc != SAMX_OK || !tick) return rc;
         return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
                                   do_d ? L->steps + 2 : nullptr, st);
     }
@@ -1122,7 +1124,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         s.nblocks = fused::seg_blocks(n[k]);
         s.sumsq = w.sumsq + k * fused::kMaxSegBlocks;
         s.wd = 0.f; s.param = nullptr; s.wd0_lo = s.wd0_hi = s.wd1_lo = s.wd1_hi = 0;
-        s.step_dev = L->steps + k;
+        s.step_dev = tick ? L->steps + k : nullptr;
     }
     if (do_a) {   // weight decay on the critic's two hidden kernels (networks.py:385-386,406-412)
         fused::Segment& s = f.seg[1];
@@ -1150,15 +1152,15 @@ int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale
     int rc = check_learner(L, "samx_step_apply");
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(ws && B > 0, "samx_step_apply: null workspace or bad batch");
-    SAMX_REQUIRE((mode & ~31) == 0 && (mode & 3) != 0 && (mode & 24) != 24,
-                 "samx_step_apply: mode uses bits 0-4, needs bit 0 or 1, and cannot skip every segment");
+    SAMX_REQUIRE((mode & ~63) == 0 && (mode & 3) != 0 && (mode & 24) != 24,
+                 "samx_step_apply: mode uses bits 0-5, needs bit 0 or 1, and cannot skip every segment");
     const int segs = ((mode & 16) ? 0 : 3) | ((mode & 8) ? 0 : 4);
     SAMX_REQUIRE(!(mode & 1) || L->clipped, "samx_step_apply: mode bit 0 needs learner.clipped");
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     StepWs w = carve(ar, L, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_step_apply: workspace %zu < %zu", ws_bytes, ar.off);
-    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs);
+    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs, !(mode & 32));
     if (mode & 4) {  // gradients changed since samx_step_grads (all-reduce): recompute the norms
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;

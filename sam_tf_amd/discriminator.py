@@ -1,15 +1,32 @@
 """Discriminator with the reference's surface (imitation_algorithms/discriminator.py:18-236) on
-libsamx.  The TF-random tensors of the graph (GP epsilons, smoothed labels, lines 101-109,130-133)
-are drawn on the device by a seeded torch generator, or injected by the caller (parity tests).
+libsamx.
+
+Once an agent has taken the discriminator's vectors into its learner-wide state (rebind), the feed-dict calls
+of sam.py:392-402 — get_grads / get_losses / optimize — run the DISCRIMINATOR ROLE of the whole-step entry
+points (samx_step_grads_part without the agent roles [+ samx_step_apply on the reward-net segment]): the fused /
+role-fused / layer-wise kernels the update-step driver uses.  The four feed arrays travel in ONE packed upload;
+what a call returns is ONE host synchronisation (the kernels store clipped gradient and losses in pinned host
+memory).  The TF-random tensors of the graph (GP epsilons, smoothed labels, lines 101-109,130-133) are drawn in
+the kernels from Philox keyed by (seed, call number, update count); every call draws afresh, as every sess.run of
+the reference does; ops.disc_randoms(d.last_seed, <update count before the call>, ...) reproduces a call's tensors.
+A discriminator without an agent keeps the per-role entry point (samx_disc_grad) with a seeded torch generator,
+or randoms injected by the caller (parity tests).
 """
+import ctypes as C
+import os
+import types
+
 import numpy as np
 import torch
 
+from . import _lib
 from . import ops
 from .hps import check_supported
 from .mpi_adam import MpiAdam
 from .networks import FlatNet, init_flat
 from .running_mean_std import DeviceRunningMeanStd
+
+_PER_ROLE = os.environ.get('SAMX_OBJECT_API', '') == 'per_role'
 
 LOSS_NAMES = ['d_policy_loss', 'd_expert_loss', 'd_ent_mean', 'd_ent_loss', 'd_policy_acc',
               'd_expert_acc', 'd_grad_pen', 'd_total_loss']
@@ -41,8 +58,13 @@ class Discriminator(object):
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(hps.seed) + 104729 * (comm.Get_rank() + 1))
         self._ws = {}
+        self._L = None
+        self._fp = {}
+        self._calls = 0
+        self.last_seed = None
+        self._seed0 = (int(hps.seed) * 2654435761 + 40503 * (comm.Get_rank() + 1)) & 0xFFFFFFFF
 
-    def rebind(self, flat, grad, m, v, t_dev):
+    def rebind(self, flat, grad, m, v, t_dev, learner=None):
         """Move parameters / gradient / Adam state into views of a learner-wide flat state
         (ops.LearnerState, layout [actor | critic | reward-net]) so one all-reduce and one optimiser
         launch cover the whole step.  Values are carried over."""
@@ -52,6 +74,8 @@ class Discriminator(object):
         self.grad = grad
         self.optimizer = MpiAdam(self.comm, flat, self.hps.clip_norm, self.hps.d_lr, name='d_adam', m=m,
                                  v=v, t_dev=t_dev)
+        self._L = learner
+        self._fp = {}
 
     # ---- helpers
     @property
@@ -116,17 +140,112 @@ class Discriminator(object):
         t = lambda k: torch.as_tensor(np.ascontiguousarray(feeds[k], dtype=np.float32)).to(self.device)
         return t(self.p_obs), t(self.p_acs), t(self.e_obs), t(self.e_acs)
 
+    # ---- the discriminator role of the whole-step kernels behind the feed-dict calls
+    def _fast(self, B):
+        if B in self._fp:
+            return self._fp[B]
+        L, dev = self._L, self.device
+        ob, ac = self.ob_dim, self.ac_dim
+        Pd = self.params.numel()
+        f = types.SimpleNamespace()
+        f.lib = _lib.lib()
+        # the four feed arrays, packed: one pinned staging buffer, one upload
+        W = B * (2 * ob + 2 * ac)
+        f.feed_pin = torch.zeros(W, dtype=torch.float32).pin_memory()
+        f.feed_dev = torch.zeros(W, dtype=torch.float32, device=dev)
+        n = f.feed_pin.numpy()
+        o1, o2, o3 = B * ob, B * (ob + ac), B * (2 * ob + ac)
+        f.views = {self.p_obs: n[:o1].reshape(B, ob), self.p_acs: n[o1:o2].reshape(B, ac),
+                   self.e_obs: n[o2:o3].reshape(B, ob), self.e_acs: n[o3:].reshape(B, ac)}
+        # whole-network kernels (64x64 nets) read every feed row once or twice: small batches are read by the
+        # kernels straight from the pinned staging (no upload in front of the launch); every other path re-reads its
+        # inputs tile by tile and gets a device copy
+        f.zero_copy = bool(L.path(B) == 1 and 4 * W <= (256 << 10))
+        dv = f.feed_pin if f.zero_copy else f.feed_dev
+        p_obs, p_acs = dv[:o1].view(B, ob), dv[o1:o2].view(B, ac)
+        e_obs, e_acs = dv[o2:o3].view(B, ob), dv[o3:].view(B, ac)
+        f.event = torch.cuda.Event()
+        f.used = False
+        # pinned results: [d_losses 8 | clipped reward-net gradient]
+        f.pin = torch.zeros(8 + Pd, dtype=torch.float32).pin_memory()
+        f.res = f.pin.numpy()
+        f.c = _lib.Learner.from_buffer_copy(L.c)
+        # (the optimiser pass writes segment k at clipped + offset[k]: the reward-net segment then starts at res[8])
+        f.c.clipped = f.pin.data_ptr() + 32 - 4 * (L.Pa + L.Pc)
+        f.out = ops.make_step_out(B, dev)
+        f.out.d_losses = f.pin.data_ptr()
+        hp = self.hps
+        label_mode = 0 if not hp.label_smoothing else (1 if hp.one_sided_label_smoothing else 2)
+        # the agent's inputs are never read by a call that leaves its roles out (they only have to be non-null)
+        f.batch = ops.make_batch(B, p_obs=p_obs, p_acs=p_acs, e_obs=e_obs, e_acs=e_acs, obs0=p_obs, acs=p_acs,
+                                 rews=dv[:B], dones1=dv[:B], obs1=p_obs, rng_seed=0, label_smoothing=label_mode,
+                                 host_ok=f.zero_copy)
+        f.ws = L.ws(B)
+        f.ws_p, f.ws_n = C.c_void_p(f.ws.data_ptr()), f.ws.numel()
+        self.world = self.comm.Get_size()
+        self._fp[B] = f
+        return f
+
+    def _role(self, feeds, tick):
+        """Upload the feeds, run the discriminator role (losses + unclipped gradient into the learner's flat
+        gradient vector); `tick`: an update follows (the reward net's update count advances)."""
+        B = len(feeds[self.p_obs])
+        f = self._fast(B)
+        if f.used:
+            f.event.synchronize()   # whatever read the staging buffer last (upload / kernels) has finished
+            f.used = False
+        for k, v in f.views.items():
+            np.copyto(v, feeds[k], casting='same_kind')
+        if not f.zero_copy:
+            f.feed_dev.copy_(f.feed_pin, non_blocking=True)
+            f.event.record()
+            f.used = True
+        # fresh draws per call (every sess.run of the reference re-draws its tf.random_uniform tensors)
+        self._calls += 1
+        f.batch.rng_seed = (self._seed0 + 7919 * self._calls) & 0xFFFFFFFFFFFF
+        self.last_seed = int(f.batch.rng_seed)
+        st = _lib.stream_ptr()
+        _lib.check(f.lib.samx_step_grads_part(C.byref(f.c), C.byref(f.batch), C.byref(f.out), f.ws_p, f.ws_n,
+                                              3 | 8 | (0 if tick else 64), st))
+        return f, B, st
+
+    def _use_fast(self):
+        return self._L is not None and not _PER_ROLE
+
     def get_grads(self, feeds):
-        self.grads_device(*self._feeds(feeds))
-        return ops.clip_copy(self.grad, self.hps.clip_norm, self.optimizer.partials).cpu().numpy()
+        """discriminator.py:161,173: flatgrad(d_loss, vars, clip_norm) -> numpy."""
+        if not self._use_fast():
+            self.grads_device(*self._feeds(feeds))
+            return ops.clip_copy(self.grad, self.hps.clip_norm, self.optimizer.partials).cpu().numpy()
+        f, B, st = self._role(feeds, tick=False)
+        _lib.check(f.lib.samx_step_apply(C.byref(f.c), B, 1 | 16, 1.0, f.ws_p, f.ws_n, st))
+        _lib.check(f.lib.samx_stream_synchronize(st))
+        return f.res[8:].copy()
 
     def get_losses(self, feeds):
-        self.grads_device(*self._feeds(feeds))
-        return [float(x) for x in self.losses.cpu().numpy()]
+        """discriminator.py:145-158,172."""
+        if not self._use_fast():
+            self.grads_device(*self._feeds(feeds))
+            return [float(x) for x in self.losses.cpu().numpy()]
+        f, B, st = self._role(feeds, tick=False)
+        _lib.check(f.lib.samx_stream_synchronize(st))
+        return f.res[:8].tolist()
 
     def optimize(self, feeds):
-        self.grads_device(*self._feeds(feeds))
-        self.optimizer.update(self.grad)
+        """discriminator.py:164-168,174: MpiAdam — mean over the workers, clip, Adam."""
+        if not self._use_fast():
+            self.grads_device(*self._feeds(feeds))
+            self.optimizer.update(self.grad)
+            return
+        f, B, st = self._role(feeds, tick=True)
+        if self.world == 1:
+            _lib.check(f.lib.samx_step_apply(C.byref(f.c), B, 2 | 16, 1.0, f.ws_p, f.ws_n, st))
+        else:
+            self.comm.allreduce_(self.grad)
+            _lib.check(f.lib.samx_step_apply(C.byref(f.c), B, 2 | 4 | 16, 1.0 / self.world, f.ws_p, f.ws_n, st))
+        if f.zero_copy:   # the call returns without a host wait: its kernels may still be reading the staging
+            f.event.record()
+            f.used = True
 
     def get_reward(self, ob, ac):
         """discriminator.py:199-224: one (ob, ac) pair -> python float."""

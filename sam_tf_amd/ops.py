@@ -152,15 +152,23 @@ def per_leaves_from_td(td, idxs, cap, num_entries, alpha, num_demos, demos_eps, 
 
 # ------------------------------------------------------------------ replay rows
 
-def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None):
-    """store: dict atom -> tensor [maxlen, dim] ; returns dict atom -> [B, dim]."""
+def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None, host_out=False):
+    """store: dict atom -> tensor [maxlen, dim] ; returns dict atom -> [B, dim].
+    host_out: the tensors of `out` are PINNED HOST memory — the kernel stores the rows there directly."""
     B = idxs.numel()
-    _chk(idxs, I64, (B,), 'idxs')
+    if host_out and not idxs.is_cuda:
+        assert idxs.is_pinned() and idxs.dtype == I64 and idxs.is_contiguous()
+    else:
+        _chk(idxs, I64, (B,), 'idxs')
     maxlen, ob = store['obs0'].shape
     ac = store['acs'].shape[1]
     dims = dict(obs0=ob, acs=ac, rews=1, dones1=1, obs1=ob)
     out = {} if out is None else out
     for k in want:
+        if host_out:
+            t = out[k]
+            assert t.is_pinned() and t.dtype == F32 and tuple(t.shape) == (B, dims[k]) and t.is_contiguous(), k
+            continue
         if k not in out:
             out[k] = torch.empty(B, dims[k], dtype=F32, device=idxs.device)
         _chk(out[k], F32, (B, dims[k]), 'out[%s]' % k)
@@ -186,9 +194,13 @@ def replay_write(store, packed, rows):
 
 # ------------------------------------------------------------------ running mean / std
 
-def rms_batch_sums(x1, x2, addvec):
+def rms_batch_sums(x1, x2, addvec, host_ok=False):
+    """host_ok: x1 may be a PINNED host tensor (read once by the kernel over PCIe)."""
     dim = x1.shape[1]
-    _chk(x1, F32, (x1.shape[0], dim), 'x1')
+    if host_ok and not x1.is_cuda:
+        assert x1.is_pinned() and x1.dtype == F32 and x1.is_contiguous() and x2 is None
+    else:
+        _chk(x1, F32, (x1.shape[0], dim), 'x1')
     if x2 is not None:
         _chk(x2, F32, (x2.shape[0], dim), 'x2')
     _chk(addvec, F64, (2 * dim + 1,), 'addvec')
@@ -563,9 +575,11 @@ _BATCH_F64 = ('d_rms_sums', 'd_rms_addvec', 'ret_addvec')
 _BATCH_INT = ('ring_start', 'ring_len', 'rng_seed', 'label_smoothing', 'num_entries')
 
 
-def make_batch(B, **fields):
+def make_batch(B, host_ok=False, **fields):
     """Fill a `samx_batch`.  float32 / int64 CUDA tensors for the pointer fields, ints for the rest.
-    Row-count checks apply to dense inputs only (indirect inputs address whole storages)."""
+    Row-count checks apply to dense inputs only (indirect inputs address whole storages).
+    host_ok: pointer fields may also be PINNED host tensors (read by the kernels over PCIe; for small inputs that
+    are read once or twice)."""
     b = _lib.Batch()
     b.B = int(B)
     keep = []
@@ -580,7 +594,7 @@ def make_batch(B, **fields):
             continue
         want = F32 if k in _BATCH_F32 else (F64 if k in _BATCH_F64 else I64)
         assert k in _BATCH_F32 or k in _BATCH_I64 or k in _BATCH_F64, 'unknown batch field %s' % k
-        assert t.is_cuda and t.dtype == want and t.is_contiguous(), k
+        assert (t.is_cuda or (host_ok and t.is_pinned())) and t.dtype == want and t.is_contiguous(), k
         dense = k not in _BATCH_F64 and not ((indirect_p and k in ('p_obs', 'p_acs')) or (indirect_e and k in ('e_obs', 'e_acs')) or
                      (indirect_a and k in ('obs0', 'acs', 'rews', 'dones1', 'obs1')) or k == 'e_start')
         if dense:

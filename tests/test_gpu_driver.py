@@ -1224,6 +1224,8 @@ def test_agent_train_matches_oracle(cfg_name, world):
             ref.sync_from(mu, d)
             ret_old = (float(mu.ret_rms.mean.item()), float(mu.ret_rms.std.item()))
         out = mu.train()
+        # train() runs the agent roles of the whole-step kernels (fused / layer-wise by shape)
+        assert mu._f is not None and mu.L.path(B) == (0 if base == 'ragged' else 1)
         mu.update_target_net()
         if forced:
             ref.gpu_ret = dict(old=ret_old, new=(float(mu.ret_rms.mean.item()), float(mu.ret_rms.std.item())))
@@ -1267,10 +1269,34 @@ def test_discriminator_feed_path_matches_oracle(cfg_name, world):
         e_obs, e_acs = h(pool.obs0[k * B:(k + 1) * B]), h(pool.acs[k * B:(k + 1) * B])
         feeds = {d.p_obs: rows['obs0'], d.p_acs: rows['acs'], d.e_obs: e_obs, d.e_acs: e_acs}
         d.obs_rms.update(np.concatenate((feeds[d.p_obs], feeds[d.e_obs])), comm)
-        state = d.gen.get_state()
+        # the feed-dict calls run the discriminator role of the whole-step kernels (fused / role-fused / layer-wise
+        # by shape); every call draws its randoms in the kernels, keyed by (call seed, update count)
+        assert d._use_fast() and mu.L.path(B) == {'C1': 1, 'ragged': 0, 'C4small': 2}[base]
+        t_before = int(d.optimizer.t_dev.item())
+        from sam_tf_amd import ops as _ops
+        NO = ref.NO
+        rms = ref.rms_d.copy()
+        for _ in range(world):
+            rms = NO.rms_update(rms, np.concatenate((rows['obs0'], e_obs)), mu.ob_dim)
+        mean_, std_ = NO.rms_mean_std(rms, mu.ob_dim)
+
+        def oracle_eval():   # losses and unclipped gradient for the randoms the LAST call drew
+            eo, ea, rl, _ = _ops.disc_randoms(d.last_seed, t_before, B, mu.ob_dim, mu.ac_dim, want_real=True)
+            return NO.disc_loss_grad(ref.pd, ref.dc, rows['obs0'], rows['acs'], e_obs, e_acs, h(eo), h(ea), h(rl),
+                                     np.zeros(B), mean_, std_)
+        g_clipped = d.get_grads(feeds)     # an evaluation: no update, the count stays
+        _, eg = oracle_eval()
+        assert_per_var(g_clipped, NO.clip_by_global_norm(eg, d.hps.clip_norm)[0], ref.dc, 1e-5,
+                       'd_feed/%s-w%d/get_grads' % (cfg_name, world))
+        l_eval = d.get_losses(feeds)       # fresh draws, as every sess.run of the reference
+        el, _ = oracle_eval()
+        assert np.max(np.abs(np.asarray(l_eval) - el) / np.maximum(np.abs(el), 1e-3)) < 1e-5, (l_eval, el)
+        assert int(d.optimizer.t_dev.item()) == t_before and len(l_eval) == 8 and g_clipped.shape == (d.params.numel(),)
+        assert np.linalg.norm(g_clipped) <= d.hps.clip_norm * (1 + 1e-5)
         d.optimize(feeds)
-        d.gen.set_state(state)
-        eps_ob, eps_ac, real, fake = d.draw_randoms(B)
+        assert int(d.optimizer.t_dev.item()) == t_before + 1
+        eps_ob, eps_ac, real, fake = _ops.disc_randoms(d.last_seed, t_before, B, mu.ob_dim, mu.ac_dim, want_real=True,
+                                                       want_fake=False)
         assert fake is None
         ref.d_step(idx, e_obs, e_acs, h(eps_ob), h(eps_ac), h(real) if real is not None else np.ones(B))
     _assert_weights(None, d, ref, 3, 'd_feed/%s-w%d' % (cfg_name, world), nets=('reward',))

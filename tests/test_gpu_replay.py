@@ -70,9 +70,29 @@ def test_per_golden(golden_dir, name):
 
 @pytest.mark.parametrize('name', ['replay_rb', 'replay_rb_partial'])
 def test_rb_golden(golden_dir, name):
+    """(numpy batches: the gather kernel stores the rows straight into pinned host memory, memory.RB.batchify)"""
     from sam_tf_amd.memory import RB
     RC.run_rb_fixture(np.load(os.path.join(golden_dir, name + '.npz')),
                       lambda limit, ob, ac: RB(limit, (ob,), (ac,)))
+
+
+@pytest.mark.parametrize('n,dim', [(1, 11), (512, 11), (37, 5), (2048, 376)])
+def test_obs_rms_update_numpy_form(n, dim):
+    """MpiRunningMeanStd.update(x, comm) with numpy rows (mpi_running_mean_std.py:47-59): one row (store_transition),
+    an even batch (one launch: sums + commit), an odd batch, a batch beyond the pinned-read size."""
+    from sam_tf_amd.running_mean_std import DeviceRunningMeanStd
+    from oracle import nets_oracle as NO
+    rs = np.random.RandomState(n)
+    r = DeviceRunningMeanStd(shape=(dim,))
+    exp = NO.rms_init(dim)
+    for _ in range(3):
+        x = (rs.randn(n, dim) * 2 + 0.5).astype(np.float64 if n == 37 else np.float32)
+        r.update(x, None)
+        exp = NO.rms_update(exp, x.astype(np.float32), dim)
+    np.testing.assert_allclose(r.sums.cpu().numpy(), exp, rtol=1e-12)
+    em, es = NO.rms_mean_std(exp, dim)
+    np.testing.assert_allclose(r.mean.cpu().numpy(), em, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r.std.cpu().numpy(), es, rtol=1e-6)
 
 
 @pytest.mark.parametrize('cap_log2,B', [(20, 256), (22, 8192), (10, 1)])
