@@ -495,6 +495,32 @@ int samx_per_row_prologue_td(double* sum_tree, double* min_tree, int32_t* stamp,
                              int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
                              float* iws_f32_out, void* stream);
 
+/* ---- the same sampling / refresh calls with the ring's geometry in DEVICE words -------------------------------
+ * Every store_transition between two training phases changes num_entries and, once the ring is full, its start
+ * (memory.py:36-57,337-342; the reference's loop appends between any two phases, sam.py:317-323).  Passed by value
+ * they are baked into a captured graph, which then has to be captured again after every rollout.  These variants
+ * read geom = int64[2] {ring start, num_entries} from device memory (the caller uploads the two words with the
+ * launch's other host-drawn numbers and has checked 2 <= num_entries <= cap; the kernels clamp to that range for
+ * memory safety), and hand out, next to the sampled LOGICAL indices the trees and the priority update work on
+ * (idxs_out; idx_copy_out, if not NULL, receives a second copy: the pending-update buffer), the STORAGE rows
+ * rows_out[i] = (start + idx) % ring_len (memory.py:33-34) the network kernels gather from with ring_start = 0.
+ * Same arithmetic, same bits as the by-value forms (tests/test_gpu_replay.py). */
+int samx_per_sample_rows(const double* sum_tree, const double* min_tree, int64_t cap, const int64_t* geom,
+                         int64_t ring_len, const double* u, int64_t B, double beta, int64_t* idxs_out,
+                         double* iws_out, float* iws_f32_out, int64_t* rows_out, int64_t* idx_copy_out,
+                         void* stream);
+/* samx_per_row_prologue_td (two-launch form, cap <= 2^30, no D-input sums) on device geometry words. */
+int samx_per_row_prologue_td_rows(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                                  const int64_t* upd_idx, const float* upd_td, int64_t n_upd, double alpha,
+                                  int64_t num_demos, double demos_eps, void* per_state, const int64_t* geom,
+                                  int64_t ring_len, const double* u, int64_t B, double beta, int64_t* idxs_out,
+                                  double* iws_out, float* iws_f32_out, int64_t* rows_out, int64_t* idx_copy_out,
+                                  void* stream);
+/* samx_per_leaves_from_td with num_entries (the bound of the reference's second assert) read from geom[1]. */
+int samx_per_leaves_from_td_geom(const float* td, const int64_t* idxs, int64_t n, int64_t cap, const int64_t* geom,
+                                 double alpha, int64_t num_demos, double demos_eps, double* leaf_out,
+                                 void* per_state, void* stream);
+
 /* a[n] (float) and b[n] (int64) to PINNED HOST memory (device-accessible) in one launch: the refreshed TD
  * errors and the sampled indices a prioritized-replay row hands back to the host (sam_agent.py:693-703). */
 int samx_to_host_pair(const float* a, float* a_host, const int64_t* b, int64_t* b_host, int64_t n, void* stream);

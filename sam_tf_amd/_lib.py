@@ -81,6 +81,10 @@ SIGNATURES = {
     'samx_per_row_prologue_td': (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _D, _I64, _D, _P, _P, _I64, _I64, _P, _P,
                                            _P, _I64, C.c_int, _P, _I64, _P, _D, _P, _P, _P, _P]),
     'samx_per_leaves_from_td': (C.c_int, [_P, _P, _I64, _I64, _I64, _D, _I64, _D, _P, _P, _P]),
+    'samx_per_leaves_from_td_geom': (C.c_int, [_P, _P, _I64, _I64, _P, _D, _I64, _D, _P, _P, _P]),
+    'samx_per_sample_rows': (C.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _D, _P, _P, _P, _P, _P, _P]),
+    'samx_per_row_prologue_td_rows': (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _D, _I64, _D, _P, _P, _I64, _P, _I64,
+                                                _D, _P, _P, _P, _P, _P, _P]),
     'samx_pow_device': (C.c_int, [_P, _D, _I64, _P, _P]),
     'samx_pow_device_f32_range': (C.c_int, [C.c_uint32, _I64, _D, _D, _P, _P]),
     'samx_pow_host_f32_range': (C.c_int, [C.c_uint32, _I64, _D, _D, _P]),

@@ -280,6 +280,7 @@ struct PerRefresh {
     double alpha, demos_eps;
     int64_t num_demos, num_entries;
     samx::PerState* state;
+    const int64_t* geom;      // device {ring start, num_entries}: read instead of num_entries (tree_dev.h: SampleExt)
 };
 
 // PER row prologue: the pending priority update of the trees (workgroup 0) and the D-input sums of the
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(1024) void per_refresh_walk_kernel(
     extern __shared__ double walk_lds[];
     if ((int)blockIdx.x < G) {
         const int64_t sub = cap / G, lo = (int64_t)blockIdx.x * sub;
+        if (rf.geom) rf.num_entries = rf.geom[1];
         samx::tree_walk_sub_body(ts, tm, cap, upd_idx, rf.td, n_upd, levels, lo, lo + sub, rf.num_entries, rf.alpha,
                                  rf.num_demos, rf.demos_eps, rf.state, *reinterpret_cast<samx::WalkLds*>(walk_lds));
     } else {
@@ -353,14 +355,14 @@ __global__ __launch_bounds__(1024) void per_refresh_walk_kernel(
 __global__ __launch_bounds__(1024) void per_top_sample_kernel(
     double* __restrict__ ts, double* __restrict__ tm, int64_t cap, int levels, int64_t n_ent,
     const double* __restrict__ u, int64_t B, double beta, int64_t* __restrict__ idxs_out,
-    double* __restrict__ iws_out, float* __restrict__ iws32_out, int64_t per) {
+    double* __restrict__ iws_out, float* __restrict__ iws32_out, int64_t per, samx::SampleExt x) {
     extern __shared__ double top_lds[];   // [2][kFastTop]
     double* top_s = top_lds;
     double* top_m = top_lds + samx::kFastTop;
     samx::tree_top_body(ts, tm, cap, levels, top_s, top_m, blockIdx.x == 0);
     const int64_t topn = 2 * (cap >> samx::fast_lb(levels));
     samx::per_sample_body(ts, tm, cap, n_ent, u, B, beta, idxs_out, iws_out, iws32_out, blockIdx.x * per, per, top_s,
-                          topn, top_m);
+                          topn, top_m, x);
 }
 
 // two device arrays -> pinned host memory in one launch (the TD errors and sampled indices a PER row
@@ -596,8 +598,14 @@ static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* st
                           const float* pool_obs0, const int64_t* e_start, int64_t B, int ob_dim, double* addvec,
                           int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
                           float* iws_f32_out, const int64_t* copy_src, int64_t* copy_dst, int64_t copy_n,
-                          int64_t copy_skip_lo, int64_t copy_skip_n, void* stream) {
+                          int64_t copy_skip_lo, int64_t copy_skip_n, void* stream,
+                          const samx::SampleExt& sx = samx::SampleExt()) {
     SAMX_REQUIRE(sum_tree && min_tree && stamp && upd_idx && (upd_leaf || rf.td), "samx_per_row_prologue: null tree argument");
+    if (sx.geom) {   // geometry in device words: the by-value entry count is not used (and cannot be checked here)
+        SAMX_REQUIRE(rf.td && u && cap <= (int64_t(1) << 30) && rf.geom == sx.geom && sx.limit > 0 && sx.limit <= cap,
+                     "samx_per_row_prologue_td_rows: needs the TD form, a sample, cap <= 2^30 and ring_len in [1, cap]");
+        num_entries = cap;
+    }
     SAMX_REQUIRE(!rf.td || (rf.state && rf.num_entries >= 0 && rf.num_entries <= cap && samx_pow::in_domain(1.0, rf.alpha)),
                  "samx_per_row_prologue_td: needs the state words, num_entries in [0, cap] and alpha inside the pow domain");
     SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_row_prologue: cap %lld is not a power of two",
@@ -640,7 +648,7 @@ static int per_row_prologue_impl(double* sum_tree, double* min_tree, int32_t* st
         static LdsGrant grant2;
         if (int rc = grant2.ensure((const void*)per_top_sample_kernel, lds2)) return rc;
         per_top_sample_kernel<<<S, 1024, lds2, (hipStream_t)stream>>>(sum_tree, min_tree, cap, levels, num_entries, u,
-                                                                     B, beta, idxs_out, iws_out, iws_f32_out, per);
+                                                                     B, beta, idxs_out, iws_out, iws_f32_out, per, sx);
         SAMX_LAUNCH_CHECK();
         return SAMX_OK;
     }
@@ -678,10 +686,25 @@ int samx_per_row_prologue_td(double* sum_tree, double* min_tree, int32_t* stamp,
                              int64_t num_entries, const double* u, double beta, int64_t* idxs_out, double* iws_out,
                              float* iws_f32_out, void* stream) {
     SAMX_REQUIRE(upd_td && per_state, "samx_per_row_prologue_td: null pointer");
-    PerRefresh rf{upd_td, alpha, demos_eps, num_demos, num_entries, (samx::PerState*)per_state};
+    PerRefresh rf{upd_td, alpha, demos_eps, num_demos, num_entries, (samx::PerState*)per_state, nullptr};
     return per_row_prologue_impl(sum_tree, min_tree, stamp, cap, upd_idx, nullptr, rf, n_upd, replay_obs0, ring_start,
                                  ring_len, p_idx, pool_obs0, e_start, B, ob_dim, addvec, num_entries, u, beta,
                                  idxs_out, iws_out, iws_f32_out, nullptr, nullptr, 0, 0, 0, stream);
+}
+
+int samx_per_row_prologue_td_rows(double* sum_tree, double* min_tree, int32_t* stamp, int64_t cap,
+                                  const int64_t* upd_idx, const float* upd_td, int64_t n_upd, double alpha,
+                                  int64_t num_demos, double demos_eps, void* per_state, const int64_t* geom,
+                                  int64_t ring_len, const double* u, int64_t B, double beta, int64_t* idxs_out,
+                                  double* iws_out, float* iws_f32_out, int64_t* rows_out, int64_t* idx_copy_out,
+                                  void* stream) {
+    SAMX_REQUIRE(upd_td && per_state && geom, "samx_per_row_prologue_td_rows: null pointer");
+    PerRefresh rf{upd_td, alpha, demos_eps, num_demos, 0, (samx::PerState*)per_state, geom};
+    samx::SampleExt sx;
+    sx.geom = geom; sx.limit = ring_len; sx.rows_out = rows_out; sx.idx_copy = idx_copy_out;
+    return per_row_prologue_impl(sum_tree, min_tree, stamp, cap, upd_idx, nullptr, rf, n_upd, nullptr, 0, 0, nullptr,
+                                 nullptr, nullptr, B, 0, nullptr, 0, u, beta, idxs_out, iws_out, iws_f32_out,
+                                 nullptr, nullptr, 0, 0, 0, stream, sx);
 }
 
 int samx_to_host_pair(const float* a, float* a_host, const int64_t* b, int64_t* b_host, int64_t n, void* stream) {

@@ -137,15 +137,17 @@ __global__ void tree_find_kernel(const double* v, int64_t cap, const double* pre
 __global__ __launch_bounds__(256) void per_sample_kernel(
     const double* __restrict__ sumv, const double* __restrict__ minv, int64_t cap, int64_t n_ent,
     const double* __restrict__ u, int64_t B, double beta, int64_t* __restrict__ idxs,
-    double* __restrict__ iws, float* __restrict__ iws32) {
+    double* __restrict__ iws, float* __restrict__ iws32, samx::SampleExt x) {
     samx::per_sample_body(sumv, minv, cap, n_ent, u, B, beta, idxs, iws, iws32,
-                          blockIdx.x * (int64_t)256, 256);   // tree_dev.h
+                          blockIdx.x * (int64_t)256, 256, nullptr, 0, nullptr, x);   // tree_dev.h
 }
 
 // the priority refresh on the device (memory.py:370-379 for the entries of one update)
 __global__ __launch_bounds__(kTreeThreads) void per_leaves_from_td_kernel(
     const float* __restrict__ td, const int64_t* __restrict__ idxs, int n, int64_t cap, int64_t num_entries,
-    double alpha, int64_t num_demos, double demos_eps, double* __restrict__ leaf_out, samx::PerState* state) {
+    double alpha, int64_t num_demos, double demos_eps, double* __restrict__ leaf_out, samx::PerState* state,
+    const int64_t* __restrict__ geom) {
+    if (geom) num_entries = geom[1];   // the ring's entry count as the launch's upload left it (device words)
     samx::leaves_from_td_body(td, idxs, n, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, state);
 }
 
@@ -257,7 +259,24 @@ int samx_per_sample(const double* sum_tree, const double* min_tree, int64_t cap,
     SAMX_REQUIRE(B > 0, "samx_per_sample: batch must be positive");
     SAMX_REQUIRE(beta > 0, "samx_per_sample: beta must be positive");
     per_sample_kernel<<<(unsigned)((B + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        sum_tree, min_tree, cap, num_entries, u, B, beta, idxs_out, iws_out, iws_f32_out);
+        sum_tree, min_tree, cap, num_entries, u, B, beta, idxs_out, iws_out, iws_f32_out, samx::SampleExt());
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_per_sample_rows(const double* sum_tree, const double* min_tree, int64_t cap, const int64_t* geom,
+                         int64_t ring_len, const double* u, int64_t B, double beta, int64_t* idxs_out,
+                         double* iws_out, float* iws_f32_out, int64_t* rows_out, int64_t* idx_copy_out,
+                         void* stream) {
+    SAMX_REQUIRE(sum_tree && min_tree && u && idxs_out && iws_out && geom, "samx_per_sample_rows: null pointer");
+    SAMX_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "samx_per_sample_rows: bad cap");
+    SAMX_REQUIRE(ring_len > 0 && ring_len <= cap, "samx_per_sample_rows: ring_len %lld must be in [1, cap]",
+                 (long long)ring_len);
+    SAMX_REQUIRE(B > 0 && beta > 0, "samx_per_sample_rows: batch and beta must be positive");
+    samx::SampleExt x;
+    x.geom = geom; x.limit = ring_len; x.rows_out = rows_out; x.idx_copy = idx_copy_out;
+    per_sample_kernel<<<(unsigned)((B + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        sum_tree, min_tree, cap, 0, u, B, beta, idxs_out, iws_out, iws_f32_out, x);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -289,7 +308,22 @@ int samx_per_leaves_from_td(const float* td, const int64_t* idxs, int64_t n, int
     SAMX_REQUIRE(cap > 0 && num_entries >= 0 && num_entries <= cap, "samx_per_leaves_from_td: bad cap / num_entries");
     SAMX_REQUIRE(samx_pow::in_domain(1.0, alpha), "samx_per_leaves_from_td: alpha %g outside the pow domain", alpha);
     per_leaves_from_td_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(
-        td, idxs, (int)n, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, (samx::PerState*)per_state);
+        td, idxs, (int)n, cap, num_entries, alpha, num_demos, demos_eps, leaf_out, (samx::PerState*)per_state,
+        nullptr);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int samx_per_leaves_from_td_geom(const float* td, const int64_t* idxs, int64_t n, int64_t cap, const int64_t* geom,
+                                 double alpha, int64_t num_demos, double demos_eps, double* leaf_out,
+                                 void* per_state, void* stream) {
+    SAMX_REQUIRE(td && idxs && leaf_out && per_state && geom, "samx_per_leaves_from_td_geom: null pointer");
+    SAMX_REQUIRE(n > 0 && n <= (1 << 24), "samx_per_leaves_from_td_geom: batch %lld out of range", (long long)n);
+    SAMX_REQUIRE(cap > 0, "samx_per_leaves_from_td_geom: bad cap");
+    SAMX_REQUIRE(samx_pow::in_domain(1.0, alpha), "samx_per_leaves_from_td_geom: alpha %g outside the pow domain",
+                 alpha);
+    per_leaves_from_td_kernel<<<1, kTreeThreads, 0, (hipStream_t)stream>>>(
+        td, idxs, (int)n, cap, 0, alpha, num_demos, demos_eps, leaf_out, (samx::PerState*)per_state, geom);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -662,6 +662,19 @@ __device__ __forceinline__ int64_t prefix_descent(const double* __restrict__ v, 
 }
 
 
+// Ring geometry read from DEVICE memory and the extra outputs that go with it (every member optional).  A sampling
+// kernel inside a captured graph must not carry num_entries / the ring's start as launch arguments: every
+// store_transition between two training phases changes them (memory.py:36-57,337-342) and the graph would have to be
+// captured again.  geom = int64[2] {ring start, num_entries} as the upload of the launch left them.
+struct SampleExt {
+    const int64_t* geom = nullptr;   // device words; num_entries is clamped to [2, cap] (memory safety; the host
+                                     // checked the real value when it wrote the words)
+    int64_t limit = 0;               // ring length
+    int64_t* rows_out = nullptr;     // storage rows (start + idx) % limit of the sampled entries: what the row
+                                     // gathers of the network kernels read (their ring then "starts at 0")
+    int64_t* idx_copy = nullptr;     // second copy of the sampled LOGICAL indices (the pending-update buffer)
+};
+
 // PrioritizedRB._sample_w_priorities + the importance weights (memory.py:266-309) for samples
 // first .. first + span of a batch of B, by ONE workgroup in which every thread calls this (barrier
 // inside); the threads with threadIdx.x < 256 work: three waves take the three scalar range reductions,
@@ -672,7 +685,14 @@ __device__ __forceinline__ void per_sample_body(const double* __restrict__ sumv,
                                                 int64_t B, double beta, int64_t* __restrict__ idxs,
                                                 double* __restrict__ iws, float* __restrict__ iws32,
                                                 int64_t first, int64_t span, const double* ext_top = nullptr,
-                                                int64_t ext_top_n = 0, const double* ext_top_min = nullptr) {
+                                                int64_t ext_top_n = 0, const double* ext_top_min = nullptr,
+                                                const SampleExt& x = SampleExt()) {
+    int64_t ring_start = 0;
+    if (x.geom) {
+        ring_start = x.geom[0];
+        n_ent = x.geom[1];
+        n_ent = n_ent < 2 ? 2 : (n_ent > cap ? cap : n_ent);
+    }
     __shared__ double sh[3];
     __shared__ int64_t nodes[3][2 * kMaxLevels + 2];
     __shared__ double vals[3][2 * kMaxLevels + 2];
@@ -708,6 +728,12 @@ __device__ __forceinline__ void per_sample_body(const double* __restrict__ sumv,
         bool have = false;
         const int64_t idx = prefix_descent(sumv, cap, s, top, top_n, &lv, &have);
         idxs[i] = idx;
+        if (x.idx_copy) x.idx_copy[i] = idx;
+        if (x.rows_out) {
+            int64_t r = ring_start + idx;
+            if (r >= x.limit) r -= x.limit;
+            x.rows_out[i] = r;
+        }
         const double prob = (have ? lv : sumv[cap + idx]) / total;
         const double w = samx_pow::pow_bits(__dmul_rn(n, prob), -beta) / max_w;
         iws[i] = w;

@@ -151,7 +151,10 @@ class UpdateStepDriver(object):
         self.idx_a = self.words[0, B:2 * B]
         self.e_start = self.words[0, 2 * B:2 * B + 1]
         self.u = self.words[0, 2 * B + 1:3 * B + 1].view(torch.float64)
-        self.geom = self.words[0, 2 * B + 1:2 * B + 3]   # uniform replay: {start, num_entries} (see _write_geom)
+        # {start, num_entries} of the ring as a launch finds it (see _write_geom): two spare words of row 0 — the PER
+        # uniforms' place under uniform replay, the host-refresh leaves' place under prioritized replay
+        self.geom_at = (3 * B + 1) if self.per else (2 * B + 1)
+        self.geom = self.words[0, self.geom_at:self.geom_at + 2]
         # PER: the previous step's priority update rides in this launch's upload and is applied by the
         # first kernel of the launch (the host libm pow that produces it is the only host work between
         # two PER steps, memory.py:376-377)
@@ -208,8 +211,16 @@ class UpdateStepDriver(object):
         # reference's loop appends between any two training phases; re-capturing there cost more than the phase).
         # The n-step lookahead needs the ring's geometry (window ends at num_entries): {start, num_entries} ride in
         # two spare words of row 0 of the same upload and the kernel reads them there
-        # (samx_nstep_lookahead_many_rows).  PER works on logical indices on the device (trees) and keeps the start.
-        self.storage_rows = bool(not self.per and os.environ.get('SAMX_STORAGE_ROWS', '1') != '0')
+        # (samx_nstep_lookahead_many_rows).  Prioritized replay with the refresh on the device: the trees and the
+        # priority update work on LOGICAL indices, so the sampling kernels read {start, num_entries} from the same two
+        # device words and write the sampled logical indices (index words, pending-update buffer) NEXT TO their storage
+        # rows (self.rows_a), which is what the network kernels gather from (samx_per_sample_rows /
+        # samx_per_row_prologue_td_rows).  The host-refresh fallback keeps logical index words and re-captures.
+        self.storage_rows = bool((not self.per or self.per_dev) and os.environ.get('SAMX_STORAGE_ROWS', '1') != '0')
+        self.per_rows = bool(self.per and self.storage_rows)
+        if self.per_rows:
+            self.rows_a = torch.zeros(self.K, B, dtype=torch.int64, device=self.dev)
+            self._junk_idx = torch.zeros(B, dtype=torch.int64, device=self.dev)
         self._batch_start = 0 if self.storage_rows else rb.start
         self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
@@ -240,7 +251,8 @@ class UpdateStepDriver(object):
             self.batches.append(ops.make_batch(
                 B, p_obs=st['obs0'], p_acs=st['acs'], e_obs=self.pool.obs0, e_acs=self.pool.acs,
                 obs0=st['obs0'], acs=st['acs'], rews=st['rews'].view(-1), dones1=st['dones1'].view(-1),
-                obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=w[:B], a_idx=w[B:2 * B],
+                obs1=st['obs1'], iws=self.iws32 if self.per else None, p_idx=w[:B],
+                a_idx=self.rows_a[k] if self.per_rows else w[B:2 * B],
                 e_start=w[2 * B:2 * B + 1], ring_start=self._batch_start, ring_len=rb.limit, rng_seed=self.rng_seed,
                 label_smoothing=self.label_mode, num_entries=rb.num_entries,
                 d_rms_sums=r.sums if r else None,
@@ -290,6 +302,10 @@ class UpdateStepDriver(object):
         B, w = self.B, self.words[k]
         return w[B:2 * B], w[2 * B + 1:3 * B + 1].view(torch.float64)
 
+    def _gather_idx(self, k):
+        """What the row gathers of row k's agent kernels read: storage rows, or the logical index words."""
+        return self.rows_a[k] if self.per_rows else self._row_views(k)[0]
+
     def _per_td(self):
         rb = self.mu.replay_buffer
         return (self.pend_td, rb.alpha, rb.num_demos, rb.demos_eps, self.per_state)
@@ -300,6 +316,13 @@ class UpdateStepDriver(object):
         if self.per and role & self.A:
             rb = mu.replay_buffer
             idx_a, u = self._row_views(k)
+            if self.per_rows:   # ring geometry from the launch's device words: the graph survives appends
+                ops.per_leaves_from_td_geom(self.pend_td, self.pend_idx, rb.st_cap, self.geom, rb.alpha, rb.num_demos,
+                                            rb.demos_eps, self.leaf_buf, self.per_state)
+                rb.trees.set(self.pend_idx, self.leaf_buf)
+                ops.per_sample_rows(rb.trees, self.geom, rb.limit, u, mu.hps.beta, idx_a, self.iws, self.iws32,
+                                    self.rows_a[k], idx_copy_out=self.pend_idx)
+                return
             if self.per_dev:
                 ops.per_leaves_from_td(self.pend_td, self.pend_idx, rb.st_cap, rb.num_entries, rb.alpha, rb.num_demos,
                                        rb.demos_eps, self.leaf_buf, self.per_state)
@@ -368,7 +391,9 @@ class UpdateStepDriver(object):
             io = dict(td_host=self._td_host, idx_host=self._idx_host) if self.per_graph_io else {}
             if self.per_dev:
                 io = dict(td_host=self.pend_td, idx_host=self.pend_idx)
-            ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self._row_views(k)[0], self._batch_start,
+            if self.per_rows:   # (the sampling kernel already left the logical indices in the pending-update buffer)
+                io = dict(td_host=self.pend_td, idx_host=self._junk_idx)
+            ops.td_errors_rows(mu.dc, mu.critic.flat, st['obs0'], st['acs'], self._gather_idx(k), self._batch_start,
                                self.out.t['targ_q'], mean, std, self.td_post, ret=mu.ret, **io)
 
     def _grads_of(self, role):
@@ -447,10 +472,16 @@ class UpdateStepDriver(object):
                         elif self.B < 1024 and roles[k] & self.A:
                             # refresh + tree update + this row's stratified sample (samx_per_row_prologue_td)
                             idx_a, u = self._row_views(k)
-                            ops.per_row_prologue(rb.trees, self.pend_idx, None, None, self._batch_start,
-                                                 self.words[k], self.B, None, None,
-                                                 sample=(rb.num_entries, u, self.mu.hps.beta, idx_a, self.iws,
-                                                         self.iws32), td=self._per_td())
+                            if self.per_rows:
+                                ops.per_row_prologue_rows(rb.trees, self.pend_idx, self.pend_td, rb.alpha, rb.num_demos,
+                                                          rb.demos_eps, self.per_state, self.geom, rb.limit, u,
+                                                          self.mu.hps.beta, idx_a, self.iws, self.iws32,
+                                                          self.rows_a[k], idx_copy_out=self.pend_idx)
+                            else:
+                                ops.per_row_prologue(rb.trees, self.pend_idx, None, None, self._batch_start,
+                                                     self.words[k], self.B, None, None,
+                                                     sample=(rb.num_entries, u, self.mu.hps.beta, idx_a, self.iws,
+                                                             self.iws32), td=self._per_td())
                             self._seg_inputs(k, roles[k])
                             self._seg_grads(k, roles[k], trees_done=True)
                         else:
@@ -525,7 +556,8 @@ class UpdateStepDriver(object):
         rb = self.mu.replay_buffer
         if self.storage_rows:
             if rb.start:
-                idx = slot.np_idx[:K]
+                # (prioritized replay: only the discriminator's uniform draws are host-drawn indices)
+                idx = slot.np_idx_p[:K] if self.per else slot.np_idx[:K]
                 idx += rb.start
                 idx[idx >= rb.limit] -= rb.limit
             self._write_geom(slot)
@@ -534,8 +566,9 @@ class UpdateStepDriver(object):
         """{start, num_entries} of the ring as this launch finds it, in the two words behind row 0's e_start (the PER
         uniforms' place, unused under uniform replay): device view self.geom."""
         rb = self.mu.replay_buffer
-        slot.np_words[0, 2 * self.B + 1] = rb.start
-        slot.np_words[0, 2 * self.B + 2] = rb.num_entries
+        assert not self.per or 2 <= rb.num_entries <= rb.st_cap, "prioritized sampling needs 2 <= num_entries <= capacity"
+        slot.np_words[0, self.geom_at] = rb.start
+        slot.np_words[0, self.geom_at + 1] = rb.num_entries
 
     def _fill_pending(self, slot, phase):
         if self.per and not self.per_dev and self.sched[phase] & self.A:

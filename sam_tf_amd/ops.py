@@ -150,6 +150,41 @@ def per_leaves_from_td(td, idxs, cap, num_entries, alpha, num_demos, demos_eps, 
                                        int(num_demos), float(demos_eps), ptr(leaf_out), ptr(state), stream_ptr()))
 
 
+def per_leaves_from_td_geom(td, idxs, cap, geom, alpha, num_demos, demos_eps, leaf_out, state):
+    """per_leaves_from_td with num_entries read from the device words geom = int64[2] {start, num_entries}."""
+    n = td.numel()
+    _chk(td, F32, (n,), 'td'); _chk(idxs, I64, (n,), 'idxs'); _chk(leaf_out, F64, (n,), 'leaf_out')
+    _chk(state, F64, (2,), 'state'); _chk(geom, I64, (2,), 'geom')
+    check(_L().samx_per_leaves_from_td_geom(ptr(td), ptr(idxs), n, int(cap), ptr(geom), float(alpha), int(num_demos),
+                                            float(demos_eps), ptr(leaf_out), ptr(state), stream_ptr()))
+
+
+def per_sample_rows(trees, geom, ring_len, u, beta, idxs_out, iws_out, iws32_out, rows_out, idx_copy_out=None):
+    """trees.per_sample on device geometry words; rows_out receives the storage rows (include/samx.h)."""
+    B = u.numel()
+    _chk(u, F64, (B,), 'u'); _chk(geom, I64, (2,), 'geom')
+    _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out'); _opt(iws32_out, F32, (B,), 'iws32_out')
+    _chk(rows_out, I64, (B,), 'rows_out'); _opt(idx_copy_out, I64, (B,), 'idx_copy_out')
+    check(_L().samx_per_sample_rows(ptr(trees.sum), ptr(trees.min), trees.cap, ptr(geom), int(ring_len), ptr(u), B,
+                                    float(beta), ptr(idxs_out), ptr(iws_out), ptr(iws32_out), ptr(rows_out),
+                                    ptr(idx_copy_out), stream_ptr()))
+
+
+def per_row_prologue_rows(trees, upd_idx, upd_td, alpha, num_demos, demos_eps, state, geom, ring_len, u, beta,
+                          idxs_out, iws_out, iws32_out, rows_out, idx_copy_out=None):
+    """Pending priority update given as TD errors + the row's stratified sample, ring geometry in device words
+    (samx_per_row_prologue_td_rows): refresh, tree update, sample; rows_out = storage rows of the sample."""
+    n, B = upd_idx.numel(), u.numel()
+    _chk(upd_idx, I64, (n,), 'upd_idx'); _chk(upd_td, F32, (n,), 'upd_td'); _chk(state, F64, (2,), 'state')
+    _chk(geom, I64, (2,), 'geom'); _chk(u, F64, (B,), 'u')
+    _chk(idxs_out, I64, (B,), 'idxs_out'); _chk(iws_out, F64, (B,), 'iws_out'); _opt(iws32_out, F32, (B,), 'iws32_out')
+    _chk(rows_out, I64, (B,), 'rows_out'); _opt(idx_copy_out, I64, (B,), 'idx_copy_out')
+    check(_L().samx_per_row_prologue_td_rows(
+        ptr(trees.sum), ptr(trees.min), ptr(trees.stamp), trees.cap, ptr(upd_idx), ptr(upd_td), n, float(alpha),
+        int(num_demos), float(demos_eps), ptr(state), ptr(geom), int(ring_len), ptr(u), B, float(beta), ptr(idxs_out),
+        ptr(iws_out), ptr(iws32_out), ptr(rows_out), ptr(idx_copy_out), stream_ptr()))
+
+
 # ------------------------------------------------------------------ replay rows
 
 def replay_gather(store, start, idxs, want=('obs0', 'acs', 'rews', 'dones1', 'obs1'), out=None, host_out=False):

@@ -339,8 +339,9 @@ def test_k_steps_match_oracle(cfg_name, graph):
         assert drv.fused or (base == 'C4' and drv.wide)   # LayerNorm included: whole-network kernels of fused_ln.hip
     drv.prepare()
     if wrapped:
-        # the ring is full: 45 appended transitions move its start.  Uniform replay: the driver's index words carry
-        # storage rows and its captured plans are the ones made BEFORE the appends; PER re-captures.
+        # the ring is full: 45 appended transitions move its start.  The driver's captured plans are the ones made
+        # BEFORE the appends: uniform replay's index words carry storage rows; prioritized replay's sampling kernels
+        # read {start, num_entries} from device words and hand the network kernels storage rows.
         rs = np.random.RandomState(9)
         assert mu.replay_buffer.num_entries == mu.replay_buffer.limit
         plans_before = dict(drv.plans)
@@ -349,7 +350,7 @@ def test_k_steps_match_oracle(cfg_name, graph):
                                 rs.uniform(-1, 1, mu.ac_dim).astype(np.float32), float(rs.rand()),
                                 rs.randn(mu.ob_dim).astype(np.float32), float(t % 13 == 12))
         assert mu.replay_buffer.start == 45
-        assert drv.storage_rows == (not cfg['per'] and os.environ.get('SAMX_STORAGE_ROWS', '1') != '0')
+        assert drv.storage_rows == ((not cfg['per'] or drv.per_dev) and os.environ.get('SAMX_STORAGE_ROWS', '1') != '0')
     ref = OracleLearner(mu, d, pool, cfg['per'])
     # Return normalisation (rmsify_rets, the reference's default): the K-step trajectory is ill-conditioned — the
     # critic's TD error q * std + mean - (target - mean) / std cancels O(10) terms, and Adam turns every gradient

@@ -448,3 +448,47 @@ def test_row_head_from_td_errors_vs_c_oracle(cap_log2, pattern):
         assert np.array_equal(iws.cpu().numpy(), wc), what
         st = state.cpu().numpy()
         assert st[0] == max_c and st.view(np.uint64)[1] == 0, what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,cap_log2', [(256, 12), (37, 9), (2048, 14)])
+def test_per_geometry_words_equal_by_value_forms(B, cap_log2):
+    """samx_per_sample_rows / samx_per_row_prologue_td_rows / samx_per_leaves_from_td_geom read {ring start,
+    num_entries} from device words (captured graphs survive appends): same indices, weights, leaves, trees and
+    state bits as the by-value forms, plus the storage rows (start + idx) % limit (memory.py:33-34)."""
+    from sam_tf_amd import ops
+    cap = 1 << cap_log2
+    limit, n_ent, start = cap - 3, cap - 3, 41
+    rs = np.random.RandomState(B)
+    leaves = np.zeros(cap)
+    leaves[:n_ent] = rs.rand(n_ent) ** 3 + 1e-3
+    mk = lambda: ops.DeviceTrees(cap)
+    ta, tb = mk(), mk()
+    all_idx = torch.arange(cap, dtype=torch.int64, device='cuda')
+    for t in (ta, tb):
+        t.set(all_idx[:n_ent], torch.as_tensor(leaves[:n_ent]).cuda())
+    u = torch.as_tensor(rs.rand(B)).cuda()
+    geom = torch.tensor([start, n_ent], dtype=torch.int64, device='cuda')
+    z = lambda dt: torch.zeros(B, dtype=dt, device='cuda')
+    i0, w0, f0 = ta.per_sample(n_ent, u, 0.6, iws32_out=z(torch.float32))[0], None, None
+    i0, w0 = ta.per_sample(n_ent, u, 0.6)
+    i1, w1, f1, rows, cp = z(torch.int64), z(torch.float64), z(torch.float32), z(torch.int64), z(torch.int64)
+    ops.per_sample_rows(tb, geom, limit, u, 0.6, i1, w1, f1, rows, idx_copy_out=cp)
+    assert torch.equal(i0, i1) and torch.equal(w0, w1) and torch.equal(cp, i1)
+    assert torch.equal(rows, (i1 + start) % limit) and torch.equal(f1, w1.float())
+    # leaves from TD errors: an index at / beyond num_entries raises bit 1 in both forms
+    td = torch.as_tensor((rs.randn(B) * 2).astype(np.float32)).cuda()
+    idx = i0.clone()
+    idx[0] = -1                                   # nothing pending
+    sa, sb = ops.make_per_state(1.0), ops.make_per_state(1.0)
+    la, lb = z(torch.float64), z(torch.float64)
+    ops.per_leaves_from_td(td, idx, cap, n_ent, 0.3, 0, 0.1, la, sa)
+    ops.per_leaves_from_td_geom(td, idx, cap, geom, 0.3, 0, 0.1, lb, sb)
+    assert torch.equal(la, lb) and torch.equal(sa, sb)
+    if B < 1024:   # the two-launch row head: refresh + walk + top rebuild + sample
+        ops.per_row_prologue(ta, idx, None, None, 0, u, B, None, None, sample=(n_ent, u, 0.6, i0, w0, None),
+                             td=(td, 0.3, 0, 0.1, sa))
+        ops.per_row_prologue_rows(tb, idx, td, 0.3, 0, 0.1, sb, geom, limit, u, 0.6, i1, w1, f1, rows, idx_copy_out=cp)
+        assert torch.equal(ta.sum, tb.sum) and torch.equal(ta.min, tb.min) and torch.equal(sa, sb)
+        assert torch.equal(i0, i1) and torch.equal(w0, w1) and torch.equal(cp, i1)
+        assert torch.equal(rows, (i1 + start) % limit)

@@ -12,8 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench  # noqa: E402
 from sam_tf_amd.comm import TorchComm  # noqa: E402
 
-cfg = dict(bench.CONFIGS['C2'], mem=65536, d_steps=1, g_steps=3)
-if len(sys.argv) > 1 and sys.argv[1] == 'launcher':   # LayerNorm, return normalisation + PopArt, n-step returns n = 96
+base = 'C3' if 'C3' in sys.argv[1:] else 'C2'   # C3: prioritized replay (sampling kernels on device geometry words)
+cfg = dict(bench.CONFIGS[base], mem=65536, d_steps=1, g_steps=3)
+if 'launcher' in sys.argv[1:]:   # LayerNorm, return normalisation + PopArt, n-step returns n = 96
     cfg.update(ln=True, ret=True, nstep=96)
 mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 0, True)
 assert mu.replay_buffer.num_entries == mu.replay_buffer.limit
@@ -39,4 +40,4 @@ for mode in (False, True, False):
     n = 10
     for _ in range(n):
         iteration(mode)
-    print('%s: %.2f ms per iteration (4 appends + 75 rows)' % ('re-capture per iteration' if mode else 'plans kept', (time.perf_counter() - t0) / n * 1e3))
+    print(base + ' %s: %.2f ms per iteration (4 appends + 75 rows)' % ('re-capture per iteration' if mode else 'plans kept', (time.perf_counter() - t0) / n * 1e3))
