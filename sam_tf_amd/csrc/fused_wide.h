@@ -13,10 +13,18 @@ constexpr int kH = 256;     // hidden width (both layers)
 constexpr int kRows = 16;   // batch rows per workgroup
 constexpr int kMaxIn = 416; // widest network input (a multiple of 32)
 
-struct Net {   // plain leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat parameter vector)
+struct Net {   // leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat parameter vector)
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int in, out;
+    // LayerNorm behind each hidden activation (networks.py:53-70, network_util.py:32-39), null without it; all
+    // networks of a learner carry it or none does (hps.with_layernorm)
+    const float *be1 = nullptr, *ga1 = nullptr, *be2 = nullptr, *ga2 = nullptr;
 };
+
+// Per-tile gradient slot of a network with LayerNorm: [W3 (256) | b3 | beta1 | gamma1 | beta2 | gamma2]; without
+// it only the first kH + 1 floats exist.  (The actor's slot has no head part: kLnSlot floats, beta1 first.)
+constexpr int kLnSlot = 4 * 256;
+inline int slot_width(bool ln) { return 256 + 1 + (ln ? kLnSlot : 0); }
 
 struct AgentArgs {
     const float *obs0, *acs, *rews, *dones1, *obs1, *iws, *td_len, *mean, *stdv;
@@ -30,7 +38,14 @@ struct AgentArgs {
     float *targ_q, *td_out;
     float *Xc, *A1c, *A2c, *DZ1c, *DZ2c;   // [B][ob+ac], [B][256] x 4
     float *row_hub, *row_dq;               // [B] huber * iw ; d loss / d score
-    float* w3c_part;                       // [B/16][257]: per-tile A2c^T dq (256) and sum dq: the head's gradient
+    float* w3c_part;                       // [B/16][slot_width]: per-tile A2c^T dq (256) and sum dq: the head's
+                                           // gradient [+ the critic's LayerNorm gradients of the tile's rows]
+    // LayerNorm only: normalised activations x^ [B][256] per hidden layer, written by the forward and read back BY
+    // THE SAME THREAD in the backward (critic of the target+critic role; actor and critic of the actor role), and
+    // the actor's per-tile LayerNorm gradient slots [B/16][kLnSlot].  With LayerNorm A1* / A2* hold the LayerNorm
+    // OUTPUTS (what the next layer reads: the weight-gradient products' operands).
+    float *XH1c = nullptr, *XH2c = nullptr, *XH1a = nullptr, *XH2a = nullptr, *XH1q = nullptr, *XH2q = nullptr;
+    float* lna_part = nullptr;
     // actor role
     float *Xa, *A1a, *A2a, *DZ1a, *DZ2a;   // [B][ob+ac] (obz0 | mu(obz0)), [B][256] x 4
     float *dPre, *row_q;                   // [B][ac] ; [B] Q(obz0, mu(obz0))
@@ -67,10 +82,15 @@ struct DiscArgs {
     int64_t B;
     float ent_scale;
     // rows [0,B) policy, [B,2B) expert, [2B,3B) interpolates (for those: X = V, A1/A2 = the tangents)
-    float *X, *A1, *A2, *DZ1, *DZ2;   // [3B][ob+ac], [3B][256] x 4
+    // With LayerNorm the interpolates take two row blocks: [2B,3B) the primal stream P (X = the
+    // interpolated inputs, A1 = n1, DZ* = P_z*), [3B,4B) the tangent stream T (X = V, A1 = ndot1, DZ* = T_z*); A2 is
+    // not used for them.  XH1 / XH2 [3B][256]: normalised activations (same-thread read-back); TN1, PA1 [B][256]:
+    // the tangent stream's cotangent of n1 and the primal cotangent the first tangent LayerNorm sends back.
+    float *X, *A1, *A2, *DZ1, *DZ2;   // [3B or 4B][ob+ac], [3B or 4B][256] x 4
+    float *XH1 = nullptr, *XH2 = nullptr, *TN1 = nullptr, *PA1 = nullptr;
     float *DS, *ce, *ent, *sg;        // [3B] ; [2B] x 3
     double* gp_part;                  // [B/16][2]
-    // per-tile head gradient [3B/16][257], tiles in launch order: interpolate (sum a2dot, 0), policy, expert
+    // per-tile head gradient [3B/16][slot_width], tiles in launch order: interpolate (sum a2dot, 0), policy, expert
     float* w3_part;
 };
 

@@ -525,6 +525,266 @@ __device__ __forceinline__ void load_rows(const Lds& L, int k32, const float* __
     rows_commit(L, x, k32, mean, stdv, ob, acw, hbm, hrow, ldh);
 }
 
+// ================================================================================================
+// LayerNorm behind every hidden activation (networks.py:53-70, network_util.py:32-39: a = lrelu(xW + b),
+// xh = (a - mean a) rs, rs = (var a + 1e-8)^-1/2 with the biased variance, n = gamma xh + beta).
+// The 256 columns of a row are spread over the four compute waves in the accumulator layout, so every LayerNorm
+// step is a MINI-PHASE between two products in the "rows mapping": the product's epilogue leaves its raw tile in
+// LDS, then thread t of the 256 compute threads owns row t >> 4 and the 16 columns (t & 15) + 16 u and reduces with
+// shuffles inside its 16-lane group (mean, then the centred sum of squares: two passes like tf.nn.moments).
+// What a backward mini-phase needs from the forward one of the same layer travels PER THREAD: the lrelu mask as 16
+// bits in a register, rs per row in a 16-float LDS strip, and xh through HBM — written and read back by the same
+// thread (same mapping), so no cross-thread visibility of global stores is ever needed.  The tiles of the forward
+// (a, n) are not kept: the LDS budget is the ring + X + two tiles, as without LayerNorm.
+// Per-tile gradients of beta / gamma (column sums over the tile's 16 rows) go through a scratch [4 waves][512] in
+// the ring slot the weight stream leaves free between two products (free_slot) and one more barrier.
+constexpr float kLnEps = 1e-8f;
+constexpr float kInvH = 1.f / (float)H;
+constexpr int LNU = H / 16;
+__device__ __forceinline__ float sum_rows4(float v) {   // over the 4 rows a wave holds in the rows mapping
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// T holds a = lrelu(z) [16][256]; on return T holds n.  xh_hbm / n_hbm (either may be null): [rows][256] arrays in
+// HBM, this tile's rows start at grow0.  Returns the mask bits (a >= 0) of this thread's 16 elements.
+__device__ __forceinline__ unsigned ln_fwd_rows(float* T, const float* __restrict__ be, const float* __restrict__ ga,
+                                                float* __restrict__ xh_hbm, float* __restrict__ n_hbm, int64_t grow0,
+                                                float* rs_strip) {
+    const int t = opaque_tid(), r = t >> 4, c0 = t & 15;
+    float a[LNU], g[LNU], b[LNU];
+    float s = 0.f;
+    unsigned bits = 0;
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) { g[u] = ga[c0 + 16 * u]; b[u] = be[c0 + 16 * u]; }
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        a[u] = T[r * LDT + c0 + 16 * u];
+        s += a[u];
+        bits |= (a[u] >= 0.f ? 1u : 0u) << u;
+    }
+    const float mu = sum16(s) * kInvH;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) { const float d = a[u] - mu; q = fmaf(d, d, q); }
+    const float rs = 1.f / sqrtf(sum16(q) * kInvH + kLnEps);
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        const float xh = (a[u] - mu) * rs;
+        a[u] = xh;
+        T[r * LDT + c0 + 16 * u] = fmaf(g[u], xh, b[u]);
+    }
+    if (rs_strip && c0 == 0) rs_strip[r] = rs;
+    // the HBM copies last (stores count in vmcnt like loads)
+    if (xh_hbm) {
+        float* o = xh_hbm + (grow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = a[u];
+    }
+    if (n_hbm) {
+        float* o = n_hbm + (grow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = fmaf(g[u], a[u], b[u]);
+    }
+    return bits;
+}
+
+// Backward through lrelu -> LayerNorm of one layer: cotangent of n -> cotangent of the pre-activation z.
+//   dn = T[r][c], or dq[r] w3[c] (HEAD: the layer under a 1-output head)
+//   dxh = dn gamma ; da = rs (dxh - mean dxh - xh mean(dxh xh)) [+ add] ; dz = da lrelu'(a)
+// dz -> T (in place) and dz_hbm rows drow0.. (null: LDS only); tn_hbm (optional): keeps dn (rows trow0..);
+// add_hbm (optional, rows trow0..): a primal cotangent of a added before the mask (gradient penalty, P stream).
+// SLOTS: per-wave column sums of dn (-> dbeta) and dn xh (-> dgamma) over the wave's 4 rows -> scratch[w][512].
+template <bool HEAD, bool SLOTS>
+__device__ __forceinline__ void ln_bwd_rows(float* T, const float* dq, const float* __restrict__ w3,
+                                            const float* __restrict__ ga, const float* __restrict__ xh_hbm,
+                                            int64_t grow0, const float* rs_strip, unsigned bits,
+                                            const float* __restrict__ add_hbm, float* __restrict__ dz_hbm,
+                                            int64_t drow0, float* __restrict__ tn_hbm, int64_t trow0,
+                                            float* scratch) {
+    const int t = opaque_tid(), r = t >> 4, c0 = t & 15, lane = t & 63, wv = t >> 6;
+    float xh[LNU], dn[LNU], dx[LNU];
+    {
+        const float* xi = xh_hbm + (grow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) xh[u] = xi[16 * u];
+    }
+    const float rs = rs_strip[r];
+    float s1 = 0.f, s2 = 0.f;
+    const float dqr = HEAD ? dq[r] : 0.f;
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        const int c = c0 + 16 * u;
+        dn[u] = HEAD ? dqr * w3[c] : T[r * LDT + c];
+        dx[u] = dn[u] * ga[c];
+        s1 += dx[u];
+        s2 = fmaf(dx[u], xh[u], s2);
+    }
+    const float m1 = sum16(s1) * kInvH, m2 = sum16(s2) * kInvH;
+    float ad[LNU];
+    if (add_hbm) {
+        const float* ai = add_hbm + (trow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) ad[u] = ai[16 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        float da = rs * (dx[u] - m1 - xh[u] * m2);
+        if (add_hbm) da += ad[u];
+        dx[u] = da * ((bits >> u) & 1u ? 1.f : 0.2f);
+        T[r * LDT + c0 + 16 * u] = dx[u];
+    }
+    if (SLOTS) {
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) {
+            const float b = sum_rows4(dn[u]), g = sum_rows4(dn[u] * xh[u]);
+            if (lane < 16) { scratch[wv * 512 + c0 + 16 * u] = b; scratch[wv * 512 + 256 + c0 + 16 * u] = g; }
+        }
+    }
+    if (dz_hbm) {
+        float* o = dz_hbm + (drow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = dx[u];
+    }
+    if (tn_hbm) {
+        float* o = tn_hbm + (trow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = dn[u];
+    }
+}
+// the four waves' column sums in a fixed order: thread c < 256
+__device__ __forceinline__ float ln_col4(const float* scratch, int o) {
+    return (scratch[o] + scratch[512 + o]) + (scratch[1024 + o] + scratch[1536 + o]);
+}
+// dst[0..256) = dbeta, dst[256..512) = dgamma (contiguous in the flat layout)
+__device__ __forceinline__ void ln_cols_commit(const float* scratch, float* __restrict__ dst) {
+    const int t = threadIdx.x;
+    dst[t] = ln_col4(scratch, t);
+    dst[256 + t] = ln_col4(scratch, 256 + t);
+}
+
+// Tangent of lrelu -> LayerNorm along zdot (T holds the raw tangent pre-activation) and the primal cotangent the
+// tangent LayerNorm sends back (gradient penalty's second-order term; nets.hip ln_tan_kernel):
+//   adot = zdot lrelu'(a) ; d = adot - mean adot ; c = mean(xh adot) ; u = rs (d - c xh) ; ndot = gamma u
+//   ub = gamma tn ; Aq = <ub, d> ; Bq = <ub, xh> ; ta = rs (ub - mean ub - xh Bq/H)
+//   pa = -(rs^2 (Aq - c Bq)/H) xh - (rs Bq/H) u - rs c ta
+// tn = the tangent stream's cotangent of n: tn_hbm rows trow0.. (same-thread read-back) or w3[c] (layer under the head).
+// LAYER2 = false: T <- ndot (next product's operand), nd_hbm rows drow0.. <- ndot, pa_hbm rows trow0.. <- pa (unmasked);
+//                 scratch[w][256..512) <- column sums of tn u.
+// LAYER2 = true : T <- pa lrelu'(a) (= P_z2), pz_hbm rows drow0.. <- the same; scratch[w][0..256) <- column sums of ndot,
+//                 [256..512) <- of tn u.
+template <bool LAYER2>
+__device__ __forceinline__ void ln_tan_rows(float* T, const float* __restrict__ ga, const float* __restrict__ xh_hbm,
+                                            int64_t grow0, const float* rs_strip, unsigned bits,
+                                            const float* __restrict__ tn_hbm, const float* __restrict__ w3,
+                                            int64_t trow0, float* __restrict__ out_hbm, int64_t drow0,
+                                            float* __restrict__ pa_hbm, float* scratch) {
+    const int t = opaque_tid(), r = t >> 4, c0 = t & 15, lane = t & 63, wv = t >> 6;
+    float xh[LNU], ad[LNU], ub[LNU], tn[LNU];
+    {
+        const float* xi = xh_hbm + (grow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) xh[u] = xi[16 * u];
+        if (!LAYER2) {
+            const float* ti = tn_hbm + (trow0 + r) * H + c0;
+#pragma unroll
+            for (int u = 0; u < LNU; ++u) tn[u] = ti[16 * u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < LNU; ++u) tn[u] = w3[c0 + 16 * u];
+        }
+    }
+    const float rs = rs_strip[r];
+    float s1 = 0.f, s2 = 0.f, sa = 0.f, su = 0.f, sb = 0.f;
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        const int c = c0 + 16 * u;
+        ad[u] = T[r * LDT + c] * ((bits >> u) & 1u ? 1.f : 0.2f);
+        ub[u] = ga[c] * tn[u];
+        s1 += ad[u];
+        s2 = fmaf(xh[u], ad[u], s2);
+        sa = fmaf(ub[u], ad[u], sa);
+        su += ub[u];
+        sb = fmaf(ub[u], xh[u], sb);
+    }
+    const float mean_ad = sum16(s1) * kInvH, cc = sum16(s2) * kInvH;
+    const float su_ = sum16(su), Aq = sum16(sa) - mean_ad * su_, Bq = sum16(sb);
+    const float k1 = -(rs * rs * (Aq - cc * Bq) * kInvH), k2 = -(rs * Bq * kInvH), k3 = -(rs * cc);
+    const float mub = su_ * kInvH, mbx = Bq * kInvH;
+    float o1[LNU], o2[LNU];
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        const int c = c0 + 16 * u;
+        const float uu = rs * ((ad[u] - mean_ad) - cc * xh[u]);
+        const float nd = ga[c] * uu;
+        const float ta = rs * (ub[u] - mub - xh[u] * mbx);
+        const float pa = k1 * xh[u] + k2 * uu + k3 * ta;
+        const float pz = pa * ((bits >> u) & 1u ? 1.f : 0.2f);
+        T[r * LDT + c] = LAYER2 ? pz : nd;
+        o1[u] = LAYER2 ? pz : nd;
+        o2[u] = pa;
+        const float sg = sum_rows4(tn[u] * uu);
+        if (lane < 16) scratch[wv * 512 + 256 + c] = sg;
+        if (LAYER2) {
+            const float sn = sum_rows4(nd);
+            if (lane < 16) scratch[wv * 512 + c] = sn;
+        }
+    }
+    {
+        float* o = out_hbm + (drow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = o1[u];
+    }
+    if (!LAYER2) {
+        float* o = pa_hbm + (trow0 + r) * H + c0;
+#pragma unroll
+        for (int u = 0; u < LNU; ++u) o[16 * u] = o2[u];
+    }
+}
+
+// hidden layer with LayerNorm: T <- n = LN(lrelu(A W + b)); two barriers more than hidden_fwd.  Called by all
+// waves; returns the mask bits of this (compute) thread's elements IN THE ROWS MAPPING.
+template <bool CW>
+__device__ __forceinline__ unsigned hidden_fwd_ln(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                                  const float* A, int lda, const float* __restrict__ b,
+                                                  const float* __restrict__ be, const float* __restrict__ ga,
+                                                  float* ring, float* T, float* __restrict__ xh_hbm,
+                                                  float* __restrict__ n_hbm, int64_t grow0, float* rs_strip) {
+    f32x4 acc[4];
+    zero_acc(acc);
+    wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
+    if constexpr (CW) for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = lrelu(v + b[c]); });
+    bar();
+    unsigned bits = 0;
+    if constexpr (CW) bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
+    bar();
+    return bits;
+}
+// either form of a hidden layer behind one call (the forward-only chains of the target networks):
+// layer 1 or 2 of net n; hbm: where the next layer's input goes for the weight-gradient products (or null)
+template <bool CW, bool LN>
+__device__ __forceinline__ unsigned hfwd(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                         const float* A, int lda, const Net& n, int layer, float* ring, float* T,
+                                         float* __restrict__ hbm, float* __restrict__ xh_hbm, int64_t grow0,
+                                         float* rs_strip) {
+    if constexpr (LN)
+        return hidden_fwd_ln<CW>(pipe, cur, next, has_next, A, lda, layer == 1 ? n.b1 : n.b2,
+                                 layer == 1 ? n.be1 : n.be2, layer == 1 ? n.ga1 : n.ga2, ring, T, xh_hbm, hbm, grow0,
+                                 rs_strip);
+    else
+        return hidden_fwd<CW>(pipe, cur, next, has_next, A, lda, layer == 1 ? n.b1 : n.b2, ring, T, hbm, grow0);
+}
+// raw product output into a tile (the cotangent / tangent a LayerNorm mini-phase takes next); all waves
+template <bool CW>
+__device__ __forceinline__ void prod_to_tile(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                             const float* A, int lda, float* ring, float* T) {
+    f32x4 acc[4];
+    zero_acc(acc);
+    wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
+    if constexpr (CW) for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = v; });
+    bar();
+}
+
 // actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac);
 // called by all waves
 template <bool CW>
@@ -562,7 +822,7 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
 // ------------------------------------------------------------------------------------------------
 // TD targets only (return normalisation + PopArt / n-step).  pass 0: the 1-step target of the sampled rows;
 // pass 1: the n-step target (rows n_idx, dense n_rews / n_dones / n_len).
-template <bool CW>
+template <bool CW, bool LN>
 __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) {
     const int tid = threadIdx.x;
     constexpr bool cw = CW;
@@ -588,15 +848,15 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
     }
     if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
     bar();
-    hidden_fwd<CW>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
+    hfwd<CW, LN>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     HeadStage hs;
     stage_head_issue(hs, a.targ_actor.W3, ac);
-    hidden_fwd<CW>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    hfwd<CW, LN>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
-    hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
+    hfwd<CW, LN>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     HeadRegs hd;
     if (cw) head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
-    hidden_fwd<CW>(pipe, tc2, tc2, false, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
+    hfwd<CW, LN>(pipe, tc2, tc2, false, L.T1, LDT, a.targ_critic, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     if (cw) head1(L.T2, hd, L.s_);
     bar();
     if (cw && tid < R) {
@@ -608,7 +868,7 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
     }
 }
 
-template <bool CW>
+template <bool CW, bool LN>
 __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
     constexpr bool cw = CW;
@@ -648,22 +908,22 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
     bar();
     WTRACE(wg, 0, 1);
-    hidden_fwd<CW>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor.b1, L.ring, L.T1, nullptr, 0);
+    hfwd<CW, LN>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 2);
     HeadStage hs;
     stage_head_issue(hs, a.targ_actor.W3, ac);
-    hidden_fwd<CW>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor.b2, L.ring, L.T2, nullptr, 0);
+    hfwd<CW, LN>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 3);
     actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
     WTRACE(wg, 0, 4);
-    hidden_fwd<CW>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic.b1, L.ring, L.T1, nullptr, 0);
+    hfwd<CW, LN>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 5);
     // the online critic's input rows travel while the target critic's second layer runs
     if (cw) {
         rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
         head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
     }
-    hidden_fwd<CW>(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic.b2, L.ring, L.T2, nullptr, 0);
+    hfwd<CW, LN>(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 6);
     if (cw) head1(L.T2, hd, L.s_);
     bar();
@@ -681,10 +941,13 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     WTRACE(wg, 0, 15);
     bar();
     WTRACE(wg, 0, 8);
-    hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, a.A1c, row0);
+    // (LayerNorm: mask bits per layer in the rows mapping, rs strips in L.red, xh through HBM — see ln_fwd_rows)
+    float* rs1 = L.red;
+    float* rs2 = L.red + 16;
+    const unsigned m1 = hfwd<CW, LN>(pipe, c1, c2, true, L.X, L.px, a.critic, 1, L.ring, L.T1, a.A1c, a.XH1c, row0, rs1);
     WTRACE(wg, 0, 9);
     if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
-    hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, a.A2c, row0);
+    const unsigned m2 = hfwd<CW, LN>(pipe, c2, c3, true, L.T1, LDT, a.critic, 2, L.ring, L.T2, a.A2c, a.XH2c, row0, rs2);
     WTRACE(wg, 0, 10);
     if (cw) head1(L.T2, hd, L.s_);
     bar();
@@ -715,6 +978,26 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         if (a.td_out) a.td_out[row0 + tid] = td;
     }
     bar();
+    if constexpr (LN) {
+        float* slot = a.w3c_part + (int64_t)wg * (H + 1 + kLnSlot);
+        if (cw) head_grad_slot(L.T2, L.dq, slot);   // T2 = n2: the head's input
+        bar();
+        float* scratch = free_slot(L.ring, pipe);
+        if (cw)
+            ln_bwd_rows<true, true>(L.T2, L.dq, a.critic.W3, a.critic.ga2, a.XH2c, row0, rs2, m2, nullptr, a.DZ2c,
+                                    row0, nullptr, 0, scratch);
+        bar();
+        if (cw) ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
+        prod_to_tile<CW>(pipe, c3, c3, false, L.T2, LDT, L.ring, L.T1);   // cotangent of n1
+        scratch = free_slot(L.ring, pipe);
+        if (cw)
+            ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, a.critic.ga1, a.XH1c, row0, rs1, m1, nullptr, a.DZ1c,
+                                     row0, nullptr, 0, scratch);
+        bar();
+        if (cw) ln_cols_commit(scratch, slot + (H + 1));
+        return;
+    }
+    (void)m1; (void)m2;
     if (cw) {
         head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
         head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
@@ -737,7 +1020,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
 #endif
 }
 
-template <bool CW>
+template <bool CW, bool LN>
 __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr bool cw = CW;
@@ -757,22 +1040,38 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         for (int t = tid; t < R * PP; t += NC) L.PRE[t] = 0.f;
     }
     bar();
-    const unsigned m1a = hidden_fwd<CW>(pipe, a1, a2, true, L.X, L.px, a.actor.b1, L.ring, L.T1, a.A1a, row0);
+    // (LayerNorm: rs strips of actor 1 / 2 and critic 1 / 2 in L.red; mask bits in the rows mapping)
+    float* rs = L.red;
+    const unsigned m1a = hfwd<CW, LN>(pipe, a1, a2, true, L.X, L.px, a.actor, 1, L.ring, L.T1, a.A1a, a.XH1a, row0, rs);
     HeadStage hs;
     stage_head_issue(hs, a.actor.W3, ac);
-    const unsigned m2a = hidden_fwd<CW>(pipe, a2, c1, true, L.T1, LDT, a.actor.b2, L.ring, L.T2, a.A2a, row0);
+    const unsigned m2a = hfwd<CW, LN>(pipe, a2, c1, true, L.T1, LDT, a.actor, 2, L.ring, L.T2, a.A2a, a.XH2a, row0, rs + 16);
     actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0, free_slot(L.ring, pipe), hs);
     // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
-    hidden_fwd<CW>(pipe, c1, c2, true, L.X, L.px, a.critic.b1, L.ring, L.T1, nullptr, 0);
+    const unsigned m1c = hfwd<CW, LN>(pipe, c1, c2, true, L.X, L.px, a.critic, 1, L.ring, L.T1, nullptr, a.XH1q, row0, rs + 32);
     HeadRegs hd;
     if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
-    hidden_fwd<CW>(pipe, c2, c3, true, L.T1, LDT, a.critic.b2, L.ring, L.T2, nullptr, 0);
+    const unsigned m2c = hfwd<CW, LN>(pipe, c2, c3, true, L.T1, LDT, a.critic, 2, L.ring, L.T2, nullptr, a.XH2q, row0, rs + 48);
+    (void)m1c; (void)m2c;
     if (cw) {
         head1(L.T2, hd, L.s_);
         // (d(de-normalised Q)/d(critic output) = ret_std, sam_agent.py:184-187)
         if (tid < R) L.dq[tid] = a.ret_std ? -a.q_scale / (float)a.B * a.ret_std[0] : -a.q_scale / (float)a.B;
     }
     bar();
+    if constexpr (LN) {
+        if (cw) {
+            if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
+            ln_bwd_rows<true, false>(L.T2, L.dq, a.critic.W3, a.critic.ga2, a.XH2q, row0, rs + 48, m2c, nullptr, nullptr,
+                                     0, nullptr, 0, nullptr);   // dZ2c in place
+        }
+        bar();
+        prod_to_tile<CW>(pipe, c3, c4, true, L.T2, LDT, L.ring, L.T1);   // cotangent of the critic's n1
+        if (cw)
+            ln_bwd_rows<false, false>(L.T1, nullptr, nullptr, a.critic.ga1, a.XH1q, row0, rs + 32, m1c, nullptr, nullptr,
+                                      0, nullptr, 0, nullptr);   // dZ1c in place
+        bar();
+    } else {
     if (cw) {
         if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
         for (int t = tid; t < R * H; t += NC) {   // dZ2c in place
@@ -788,6 +1087,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         if (cw) for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
     }
     bar();
+    }
     {   // dQ/da = dZ1c W1c[ob:ob+ac, :]^T, through clip (identity inside the range) and tanh
         f32x4 acc[4];
         zero_acc(acc);
@@ -826,6 +1126,25 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
                     acc[nb] = mfma4(av, slot[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
             }
         bar();
+        if constexpr (LN) {
+            // the cotangent of the actor's n2 (raw), then back through LayerNorm 2, W2a^T, LayerNorm 1
+            if (cw) for_acc(acc, [&](int r_, int c, float v, int) { L.T2[r_ * LDT + c] = v; });
+            bar();
+            float* lslot = a.lna_part + (int64_t)wg * kLnSlot;
+            if (cw)
+                ln_bwd_rows<false, true>(L.T2, nullptr, nullptr, a.actor.ga2, a.XH2a, row0, rs + 16, m2a, nullptr,
+                                         a.DZ2a, row0, nullptr, 0, slot);   // (the head matrix in `slot` is dead)
+            bar();
+            if (cw) ln_cols_commit(slot, lslot + 2 * H);
+            prod_to_tile<CW>(pipe, a3, a3, false, L.T2, LDT, L.ring, L.T1);
+            float* scratch = free_slot(L.ring, pipe);
+            if (cw)
+                ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, a.actor.ga1, a.XH1a, row0, rs, m1a, nullptr, a.DZ1a,
+                                         row0, nullptr, 0, scratch);
+            bar();
+            if (cw) ln_cols_commit(scratch, lslot);
+            return;
+        }
         if (cw)
             for_acc(acc, [&](int r_, int c, float v, int bi) {
                 const float z = v * ((m2a >> bi) & 1u ? 1.f : 0.2f);
@@ -846,7 +1165,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     if (cw) WTRACE(wg, 1, 1);
 }
 
-template <bool CW>
+template <bool CW, bool LN>
 __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
     constexpr bool cw = CW;
@@ -942,11 +1261,172 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
                     }
                     const float v = eps * pv + (1.f - eps) * ev;
                     xr[16 * u] = c < in ? v : 0.f;
+                    xp.v[u] = v;
                 }
+            }
+            if constexpr (LN) {   // the primal stream's layer input (x^T P_z1 of the weight gradient)
+                float* hr = a.X + (hrow0 + (t >> 4)) * in + c0;
+#pragma unroll
+                for (int u = 0; u < kRowRegs; ++u)
+                    if (c0 + 16 * u < in) hr[16 * u] = xp.v[u];
             }
         }
     }
     bar();
+    if constexpr (LN) {
+        // ================= LayerNorm networks (mini-phases: ln_fwd_rows / ln_bwd_rows / ln_tan_rows) =================
+        float* rs1 = L.red + 32;   // (L.red[0..32) takes the interpolate tiles' sums of squares)
+        float* rs2 = L.red + 48;
+        float* slot = a.w3_part + (int64_t)wg * (H + 1 + kLnSlot);
+        if (sect != 2) {
+            // ---- policy / expert rows: forward, BCE terms, backward with the LayerNorm gradients of the tile
+            const unsigned m1 = hidden_fwd_ln<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, n.be1, n.ga1, L.ring, L.T1, a.XH1,
+                                                  a.A1, hrow0, rs1);
+            HeadRegs hd;
+            if (cw) head_issue(hd, n.W3, n.b3);
+            const unsigned m2 = hidden_fwd_ln<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, n.be2, n.ga2, L.ring, L.T2, a.XH2,
+                                                  a.A2, hrow0, rs2);
+            if (cw) head1(L.T2, hd, L.s_);
+            bar();
+            if (cw && tid < R) {
+                const int64_t g = row0 + tid;
+                const float s = L.s_[tid];
+                float z;
+                if (a.eps_ob) {  // injected tensors
+                    z = sect == 0 ? (a.fake ? a.fake[g] : 0.f) : (a.real ? a.real[g] : 1.f);
+                } else {         // drawn here (discriminator.py:89-109)
+                    const uint64_t step = (uint64_t)a.rng_step[0];
+                    if (sect == 0)
+                        z = a.label_smoothing == 2 ? fake_label(philox_uniform(a.rng_seed, step, RNG_FAKE, (uint64_t)g))
+                                                   : 0.f;
+                    else
+                        z = a.label_smoothing >= 1 ? real_label(philox_uniform(a.rng_seed, step, RNG_REAL, (uint64_t)g))
+                                                   : 1.f;
+                }
+                const float sg = sigmoidf_(s);
+                const float dq = (sg - z) / (float)a.B + a.ent_scale * s * sg * (1.f - sg) / (float)(2 * a.B);
+                L.dq[tid] = dq;
+                a.DS[hrow0 + tid] = dq;
+                a.ce[hrow0 + tid] = sig_ce(s, z);
+                a.ent[hrow0 + tid] = sig_ce(s, sg);
+                a.sg[hrow0 + tid] = sg;
+            }
+            bar();
+            if (cw) head_grad_slot(L.T2, L.dq, slot);   // T2 = n2: the head's input
+            bar();
+            float* scratch = free_slot(L.ring, pipe);
+            if (cw)
+                ln_bwd_rows<true, true>(L.T2, L.dq, n.W3, n.ga2, a.XH2, hrow0, rs2, m2, nullptr, a.DZ2, hrow0, nullptr, 0,
+                                        scratch);
+            bar();
+            if (cw) ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
+            prod_to_tile<CW>(pipe, d3, d3, false, L.T2, LDT, L.ring, L.T1);   // cotangent of n1
+            scratch = free_slot(L.ring, pipe);
+            if (cw)
+                ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hrow0, rs1, m1, nullptr, a.DZ1, hrow0,
+                                         nullptr, 0, scratch);
+            bar();
+            if (cw) ln_cols_commit(scratch, slot + (H + 1));
+            return;
+        }
+        // ---- interpolate rows.  The gradient penalty is no longer piecewise linear: next to the tangent stream T
+        // (the first backward that yields g, then the forward along V) a primal cotangent stream P runs back from the
+        // two tangent LayerNorms.  HBM rows: hP = [2B, 3B) the primal stream (X = x, A1 = n1,
+        // DZ* = P_z*), hT = [3B, 4B) the tangent stream (X = V, A1 = ndot1, DZ* = T_z*).
+        const int64_t hP = hrow0, hT = hrow0 + a.B;
+        const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
+        const WDesc t1 = w_nn(n.W1, in), t2 = w_nn(n.W2, H);
+        const unsigned m1 = hidden_fwd_ln<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, n.be1, n.ga1, L.ring, L.T1, a.XH1,
+                                              a.A1, hP, rs1);
+        const unsigned m2 = hidden_fwd_ln<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, n.be2, n.ga2, L.ring, L.T2, a.XH2,
+                                              nullptr, hP, rs2);
+        if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
+        bar();
+        if (cw)   // T_z2: the head's cotangent is w3 (d score = 1)
+            ln_bwd_rows<true, false>(L.T2, L.dq, n.W3, n.ga2, a.XH2, hP, rs2, m2, nullptr, a.DZ2, hT, nullptr, 0, nullptr);
+        bar();
+        prod_to_tile<CW>(pipe, d3, g0, true, L.T2, LDT, L.ring, L.T1);   // T_n1
+        if (cw)   // T_z1 in place; T_n1 kept for the tangent LayerNorm of layer 1 (same-thread read-back)
+            ln_bwd_rows<false, false>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, nullptr, a.DZ1, hT, a.TN1, row0,
+                                      nullptr);
+        bar();
+        {   // g = T_z1 W1^T, 256 input columns at a time, over X (x is in HBM by now)
+            auto put = [&](const f32x4 (&acc)[4], int j0) {
+                if (cw)
+                    for_acc(acc, [&](int r, int c, float v, int) {
+                        if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
+                    });
+            };
+            f32x4 acc[4];
+            zero_acc(acc);
+            if (in > H) {
+                wprod<CW>(pipe, g0, g1, true, L.T1, LDT, L.ring, acc);
+                put(acc, 0);
+                zero_acc(acc);
+                wprod<CW>(pipe, g1, t1, true, L.T1, LDT, L.ring, acc);
+                put(acc, H);
+            } else {
+                wprod<CW>(pipe, g0, t1, true, L.T1, LDT, L.ring, acc);
+                put(acc, 0);
+            }
+        }
+        bar();
+        if (cw) {
+            const int r = tid >> 4, q = tid & 15;
+            float so = 0.f, sa = 0.f;
+            for (int c = q; c < in; c += 16) {
+                const float g = L.X[r * L.px + c];
+                if (c < ob) so = fmaf(g, g, so); else sa = fmaf(g, g, sa);
+            }
+            so = sum16(so); sa = sum16(sa);
+            if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
+        }
+        bar();
+        if (cw && tid == 0) {
+            double o = 0.0, c = 0.0;
+            for (int r = 0; r < R; ++r) { o += (double)L.red[r]; c += (double)L.red[16 + r]; }
+            a.gp_part[2 * (wg % tiles_b)] = o;
+            a.gp_part[2 * (wg % tiles_b) + 1] = c;
+        }
+        if (cw) {
+            const float co = 1.f / ((float)a.B * (float)ob), ca = 1.f / ((float)a.B * (float)ac);
+            const int r = tid >> 4, c0 = tid & 15;
+            for (int c = c0; c < in; c += 16) {
+                const float v = L.X[r * L.px + c] * (c < ob ? co : ca);
+                L.X[r * L.px + c] = v;
+                a.X[(hT + r) * in + c] = v;   // V: the tangent stream's layer input
+            }
+        }
+        bar();
+        prod_to_tile<CW>(pipe, t1, t2, true, L.X, L.px, L.ring, L.T1);   // zdot1 = V W1
+        float* scratch = free_slot(L.ring, pipe);
+        if (cw)   // ndot1 -> T1 and A1[hT]; PA1 (unmasked) -> HBM; column sums of tn1 u1 (part of dgamma1)
+            ln_tan_rows<false>(L.T1, n.ga1, a.XH1, hP, rs1, m1, a.TN1, nullptr, row0, a.A1, hT, a.PA1, scratch);
+        bar();
+        if (cw) slot[(H + 1) + H + tid] = ln_col4(scratch, 256 + tid);
+        prod_to_tile<CW>(pipe, t2, d3, true, L.T1, LDT, L.ring, L.T2);   // zdot2 = ndot1 W2
+        scratch = free_slot(L.ring, pipe);
+        if (cw)   // P_z2 -> T2 and DZ2[hP]; column sums of ndot2 (-> dW3) and of tn2 u2 (-> dgamma2)
+            ln_tan_rows<true>(L.T2, n.ga2, a.XH2, hP, rs2, m2, nullptr, n.W3, row0, a.DZ2, hP, nullptr, scratch);
+        bar();
+        if (cw) {
+            slot[tid] = ln_col4(scratch, tid);                              // sum ndot2 (without k)
+            slot[(H + 1) + 2 * H + tid] = 0.f;                               // dbeta2
+            slot[(H + 1) + 3 * H + tid] = ln_col4(scratch, 256 + tid);     // dgamma2
+            if (tid == 0) slot[H] = 0.f;
+        }
+        prod_to_tile<CW>(pipe, d3, d3, false, L.T2, LDT, L.ring, L.T1);   // P_n1 = P_z2 W2^T
+        scratch = free_slot(L.ring, pipe);
+        if (cw)   // P_z1 = J1(gamma1 P_n1) + PA1, masked -> DZ1[hP]; dbeta1, dgamma1 (P part)
+            ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, a.PA1, a.DZ1, hP, nullptr, row0,
+                                     scratch);
+        bar();
+        if (cw) {
+            slot[(H + 1) + tid] = ln_col4(scratch, tid);
+            slot[(H + 1) + H + tid] += ln_col4(scratch, 256 + tid);   // (this thread stored the tangent part above)
+        }
+        return;
+    }
     if (sect != 2) {
         // ---- policy / expert rows
         hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
@@ -1134,6 +1614,7 @@ __device__ inline void role_wd(const AgentArgs& a, int b) {
     }
 }
 
+template <bool LN>
 __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
@@ -1143,30 +1624,33 @@ __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     if (g < s.g_tc) {
         const int wg = j * s.g_tc + g;
         if (wg >= s.n_tc) return;
-        if (cw) role_tc<true>(s.a, wg, lds); else role_tc<false>(s.a, wg, lds);
+        if (cw) role_tc<true, LN>(s.a, wg, lds); else role_tc<false, LN>(s.a, wg, lds);
     } else if (g < s.g_tc + s.g_a) {
         const int wg = j * s.g_a + (g - s.g_tc);
         if (wg >= s.n_a) return;
-        if (cw) role_a<true>(s.a, wg, lds); else role_a<false>(s.a, wg, lds);
+        if (cw) role_a<true, LN>(s.a, wg, lds); else role_a<false, LN>(s.a, wg, lds);
     } else {
         const int wg = j * (8 - s.g_tc - s.g_a) + (g - s.g_tc - s.g_a);   // interpolate tiles come first
         if (wg >= s.n_d) return;
-        if (cw) role_d<true>(s.d, wg, lds); else role_d<false>(s.d, wg, lds);
+        if (cw) role_d<true, LN>(s.d, wg, lds); else role_d<false, LN>(s.d, wg, lds);
     }
 }
 
+template <bool LN>
 __global__ __launch_bounds__(NT, 1) void targets_kernel(AgentArgs a, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pass = blockIdx.x / tiles, wg = blockIdx.x % tiles;
-    if (is_compute()) role_t<true>(a, wg, lds, pass); else role_t<false>(a, wg, lds, pass);
+    if (is_compute()) role_t<true, LN>(a, wg, lds, pass); else role_t<false, LN>(a, wg, lds, pass);
 }
 
-bool net_ok(const samx_mlp* d) { return d && !d->layernorm && d->h1 == kH && d->h2 == kH; }
+bool net_ok(const samx_mlp* d) { return d && d->h1 == kH && d->h2 == kH; }
 
 }  // namespace
 
 bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B) {
-    return net_ok(actor) && net_ok(critic) && net_ok(reward) && ob > 0 && ac > 0 && ac <= 32 &&
+    // (LayerNorm: all of a learner's networks or none, hps.with_layernorm)
+    return net_ok(actor) && net_ok(critic) && net_ok(reward) && !actor->layernorm == !critic->layernorm &&
+           !actor->layernorm == !reward->layernorm && ob > 0 && ac > 0 && ac <= 32 &&
            ob + ac <= kMaxIn && B > 0 && B % kRows == 0 && actor->in_dim == ob && actor->out_dim == ac &&
            critic->in_dim == ob + ac && critic->out_dim == 1 && reward->in_dim == ob + ac && reward->out_dim == 1 &&
            lds_floats(ob + ac) * sizeof(float) <= 160 * 1024;
@@ -1209,9 +1693,16 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
     }
     const size_t lds = lds_floats(in) * sizeof(float);
     SAMX_REQUIRE(lds <= 160 * 1024, "wide role kernel needs %zu bytes of LDS", lds);
-    static LdsGrant grant;
-    if (int rc = grant.ensure((const void*)roles_kernel, lds)) return rc;
-    roles_kernel<<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
+    const bool ln = (a && (roles & 3)) ? a->critic.ga1 != nullptr : (d && d->net.ga1 != nullptr);
+    if (ln) {
+        static LdsGrant grant_ln;
+        if (int rc = grant_ln.ensure((const void*)roles_kernel<true>, lds)) return rc;
+        roles_kernel<true><<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
+    } else {
+        static LdsGrant grant;
+        if (int rc = grant.ensure((const void*)roles_kernel<false>, lds)) return rc;
+        roles_kernel<false><<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
+    }
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }
@@ -1222,9 +1713,15 @@ int launch_targets(const AgentArgs* a, hipStream_t st) {
     const int tiles = (int)(a->B / kRows);
     const size_t lds = lds_floats(a->ob + a->ac) * sizeof(float);
     SAMX_REQUIRE(lds <= 160 * 1024, "wide target kernel needs %zu bytes of LDS", lds);
-    static LdsGrant grant;
-    if (int rc = grant.ensure((const void*)targets_kernel, lds)) return rc;
-    targets_kernel<<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
+    if (a->targ_critic.ga1) {
+        static LdsGrant grant_ln;
+        if (int rc = grant_ln.ensure((const void*)targets_kernel<true>, lds)) return rc;
+        targets_kernel<true><<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
+    } else {
+        static LdsGrant grant;
+        if (int rc = grant.ensure((const void*)targets_kernel<false>, lds)) return rc;
+        targets_kernel<false><<<(unsigned)(tiles * (a->n_idx ? 2 : 1)), NT, lds, st>>>(*a, tiles);
+    }
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

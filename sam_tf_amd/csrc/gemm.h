@@ -54,7 +54,7 @@ int gemm(const GemmArgs& g, hipStream_t stream);
 // The same launch can also add up small per-tile slot arrays (extra workgroups at the end of the grid):
 // out[c] = sum over z < n of slots[z * width + c], 16 lanes per element (lane l takes z = l, l + 16, ...,
 // then a fixed xor tree).
-constexpr int kGemmGroupMax = 10, kSlotSumMax = 3;
+constexpr int kGemmGroupMax = 10, kSlotSumMax = 4;
 struct SlotSum { const float* slots; int n, width; float* out; };
 int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums = nullptr,
                         int nsums = 0);

@@ -1352,8 +1352,10 @@ struct WPiece {
     const float* wdW; float wd; int64_t wd_count;             // weight decay on the first wd_count elements
     int64_t count;                                            // elements of this piece ([W; b] contiguous)
 };
+constexpr int kWPieces = 5;   // [W1; b1] [beta1; gamma1] [W2; b2] [beta2; gamma2] [W3; b3] with LayerNorm, else 3
 struct WFinishSeg {
-    WPiece pc[3];
+    WPiece pc[kWPieces];
+    int npc;
     int64_t n;
     float* grad;
     float* sumsq;
@@ -1501,7 +1503,7 @@ __global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
             if (i < s.n) {
                 int q = 0;
                 int64_t li = i;
-                while (q < 2 && li >= s.pc[q].count) { li -= s.pc[q].count; ++q; }
+                while (q < s.npc - 1 && li >= s.pc[q].count) { li -= s.pc[q].count; ++q; }
                 const WPiece& pc = s.pc[q];
                 p1[e] = pc.p1 + li; n1[e] = pc.n1; s1[e] = pc.s1;
                 if (pc.p2 && li < pc.n2_valid) { p2[e] = pc.p2 + li; n2[e] = pc.n2; s2[e] = pc.s2; }
@@ -1554,20 +1556,28 @@ int wide_nsplit(int64_t R) {   // reduction chunks of 512 rows: 16 stages per wo
 }
 // float layout of the reduction workspace: head slots (critic, D), then one partials buffer per product
 struct WideRed {
-    float *w3c, *w3d, *w3_sum, *P[9], *w3a_tmp;   // w3_sum: [3][257] critic, D policy+expert, D interpolates
+    // w3_sum: [3][sw] critic, D policy+expert, D interpolates (sw = slot width: 257, + the four LayerNorm vectors)
+    float *w3c, *w3d, *w3_sum, *P[9], *w3a_tmp;
+    float *lna, *lna_sum;   // LayerNorm: the actor's per-tile [beta1 | gamma1 | beta2 | gamma2] slots and their sum
     int ns[9];
     int64_t cnt[9];
+    int sw;
 };
-WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B) {
+WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B, bool ln) {
     WideRed w;
     const int64_t tiles = B / wide::kRows, in = ob + ac, H = wide::kH;
-    w.w3c = ar.take<float>(tiles * (H + 1));
-    w.w3d = ar.take<float>(3 * tiles * (H + 1));
-    w.w3_sum = ar.take<float>(3 * (H + 1));
-    const int nsA = wide_nsplit(B), nsD1 = wide_nsplit(2 * B), nsD2 = nsA;
+    w.sw = wide::slot_width(ln);
+    w.w3c = ar.take<float>(tiles * w.sw);
+    w.w3d = ar.take<float>(3 * tiles * w.sw);
+    w.w3_sum = ar.take<float>(3 * w.sw);
+    w.lna = ar.take<float>(ln ? tiles * wide::kLnSlot : 1);
+    w.lna_sum = ar.take<float>(ln ? wide::kLnSlot : 1);
+    // LayerNorm: the interpolate rows' products run over 2B rows (primal stream | tangent stream) and carry a bias
+    // row over the primal half
+    const int nsA = wide_nsplit(B), nsD1 = wide_nsplit(2 * B), nsD2 = ln ? nsD1 : nsA;
     const int ns[9] = {nsA, nsA, nsA, nsA, nsA, nsD1, nsD2, nsD1, nsD2};
     const int64_t cnt[9] = {(H + 1) * H, (in + 1) * H, (H + 1) * ac, (H + 1) * H, (ob + 1) * H,
-                            (H + 1) * H, H * H, (in + 1) * H, in * H};
+                            (H + 1) * H, (ln ? H + 1 : H) * H, (in + 1) * H, (ln ? in + 1 : in) * H};
     for (int p = 0; p < 9; ++p) {
         w.ns[p] = ns[p];
         w.cnt[p] = cnt[p];
@@ -1580,7 +1590,7 @@ WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B) {
 
 size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B) {
     Arena ar(nullptr, 0);
-    carve_wide_red(ar, L->ob_dim, L->ac_dim, B);
+    carve_wide_red(ar, L->ob_dim, L->ac_dim, B, L->critic.layernorm != 0);
     return align_up(ar.off, 256) + 256;
 }
 
@@ -1600,9 +1610,15 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
     const int ob = L->ob_dim, ac = L->ac_dim, in = ob + ac, H = wide::kH;
     const int tiles = (int)(B / wide::kRows);
     const float gp_coeff = 10.f;  // discriminator.py:154
-    auto net = [](const Net& n) { return wide::Net{n.W1, n.b1, n.W2, n.b2, n.W3, n.b3, n.in, n.out}; };
+    const bool ln = dc->layernorm != 0;
+    const int sw = wide::slot_width(ln);
+    auto net = [](const Net& n) {
+        wide::Net w{n.W1, n.b1, n.W2, n.b2, n.W3, n.b3, n.in, n.out};
+        w.be1 = n.beta1; w.ga1 = n.gamma1; w.be2 = n.beta2; w.ga2 = n.gamma2;
+        return w;
+    };
     Arena ared(ws_red, red_bytes);
-    WideRed wr = carve_wide_red(ared, ob, ac, B);
+    WideRed wr = carve_wide_red(ared, ob, ac, B, ln);
     if (!ared.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_step_roles: reduction workspace too small");
     GemmArgs gl[9];
     int ng = 0;
@@ -1638,6 +1654,7 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
     };
     auto seg = [&](int k, int64_t n, float* grad) -> WFinishSeg& {
         WFinishSeg& s = f.seg[f.nseg++];
+        s.npc = 3;
         s.n = n; s.grad = grad; s.nblocks = fused::seg_blocks(n);
         s.sumsq = sumsq + k * fused::kMaxSegBlocks;
         s.step_dev = (part & 4) ? nullptr : L->steps + k;   // part bit 2 here: no counter tick
@@ -1658,9 +1675,16 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.ob = ob; a.ac = ac; a.B = B;
         a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
         a.targ_q = o->targ_q; a.td_out = o->td;
-        a.Xc = w1.XC; a.A1c = w1.hc.A1; a.A2c = w1.hc.A2; a.DZ1c = w1.kc.DZ1; a.DZ2c = w1.kc.DZ2;
+        // (with LayerNorm the layer inputs of the weight-gradient products are the LayerNorm outputs N1 / N2 — the
+        // same buffers as A1 / A2 without it; the normalised activations travel through XH*, see fused_wide.h)
+        a.Xc = w1.XC; a.A1c = w1.hc.N1; a.A2c = w1.hc.N2; a.DZ1c = w1.kc.DZ1; a.DZ2c = w1.kc.DZ2;
         a.row_hub = w1.row0; a.row_dq = w1.row1; a.w3c_part = wr.w3c;
-        a.Xa = w2.XC; a.A1a = w2.ha.A1; a.A2a = w2.ha.A2; a.DZ1a = w2.ka.DZ1; a.DZ2a = w2.ka.DZ2;
+        a.Xa = w2.XC; a.A1a = w2.ha.N1; a.A2a = w2.ha.N2; a.DZ1a = w2.ka.DZ1; a.DZ2a = w2.ka.DZ2;
+        if (ln) {
+            a.XH1c = w1.hc.XH1; a.XH2c = w1.hc.XH2;
+            a.XH1a = w2.ha.XH1; a.XH2a = w2.ha.XH2; a.XH1q = w2.hc.XH1; a.XH2q = w2.hc.XH2;
+            a.lna_part = wr.lna;
+        }
         a.dPre = w2.dPre; a.row_q = w2.row0;
         a.ret_mean = L->ret_mean; a.ret_std = L->ret_std; a.tdn_scale = L->td_loss_n_scale;
         a.ext_tq = a.ext_tqn = nullptr; a.n_idx = nullptr; a.n_rews = a.n_dones = a.n_len = nullptr;
@@ -1675,23 +1699,34 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
             }
         }
         // weight-gradient products: critic W2, W1 ; actor W3, W2, W1
-        prob(0, w1.hc.A1, H, H, w1.kc.DZ2, H, H, B, B);
+        prob(0, w1.hc.N1, H, H, w1.kc.DZ2, H, H, B, B);
         prob(1, w1.XC, in, in, w1.kc.DZ1, H, H, B, B);
-        if (w3a_group) prob(2, w2.ha.A2, H, H, w2.dPre, ac, ac, B, B);
-        prob(3, w2.ha.A1, H, H, w2.ka.DZ2, H, H, B, B);
+        if (w3a_group) prob(2, w2.ha.N2, H, H, w2.dPre, ac, ac, B, B);
+        prob(3, w2.ha.N1, H, H, w2.ka.DZ2, H, H, B, B);
         prob(4, w2.XC, in, ob, w2.ka.DZ1, H, H, B, B);
+        // flat layout per network: [W1; b1] ([beta1; gamma1]) [W2; b2] ([beta2; gamma2]) [W3; b3]
         WFinishSeg& sa = seg(0, Pa, L->grads);
-        sa.pc[0] = piece(wr.P[4], wr.ns[4], wr.cnt[4], wr.cnt[4]);
-        sa.pc[1] = piece(wr.P[3], wr.ns[3], wr.cnt[3], wr.cnt[3]);
-        sa.pc[2] = w3a_group ? piece(wr.P[2], wr.ns[2], wr.cnt[2], wr.cnt[2])
-                             : piece(wr.w3a_tmp, 1, wr.cnt[2], wr.cnt[2]);
         WFinishSeg& sc = seg(1, Pc, L->grads + Pa);
-        sc.pc[0] = piece(wr.P[1], wr.ns[1], wr.cnt[1], wr.cnt[1]);
-        sc.pc[0].wdW = nc.W1; sc.pc[0].wd = L->wd_scale; sc.pc[0].wd_count = (int64_t)in * H;
-        sc.pc[1] = piece(wr.P[0], wr.ns[0], wr.cnt[0], wr.cnt[0]);
-        sc.pc[1].wdW = nc.W2; sc.pc[1].wd = L->wd_scale; sc.pc[1].wd_count = (int64_t)H * H;
-        sc.pc[2] = piece(wr.w3_sum, 1, H + 1, H + 1);
-        if (L->wd_scale <= 0.f) { sc.pc[0].wdW = nullptr; sc.pc[1].wdW = nullptr; }
+        const WPiece aW1 = piece(wr.P[4], wr.ns[4], wr.cnt[4], wr.cnt[4]);
+        const WPiece aW2 = piece(wr.P[3], wr.ns[3], wr.cnt[3], wr.cnt[3]);
+        const WPiece aW3 = w3a_group ? piece(wr.P[2], wr.ns[2], wr.cnt[2], wr.cnt[2])
+                                     : piece(wr.w3a_tmp, 1, wr.cnt[2], wr.cnt[2]);
+        WPiece cW1 = piece(wr.P[1], wr.ns[1], wr.cnt[1], wr.cnt[1]);
+        cW1.wdW = nc.W1; cW1.wd = L->wd_scale; cW1.wd_count = (int64_t)in * H;
+        WPiece cW2 = piece(wr.P[0], wr.ns[0], wr.cnt[0], wr.cnt[0]);
+        cW2.wdW = nc.W2; cW2.wd = L->wd_scale; cW2.wd_count = (int64_t)H * H;
+        if (L->wd_scale <= 0.f) { cW1.wdW = nullptr; cW2.wdW = nullptr; }
+        const WPiece cW3 = piece(wr.w3_sum, 1, H + 1, H + 1);
+        if (ln) {
+            sa.npc = sc.npc = 5;
+            sa.pc[0] = aW1; sa.pc[1] = piece(wr.lna_sum, 1, 2 * H, 2 * H); sa.pc[2] = aW2;
+            sa.pc[3] = piece(wr.lna_sum + 2 * H, 1, 2 * H, 2 * H); sa.pc[4] = aW3;
+            sc.pc[0] = cW1; sc.pc[1] = piece(wr.w3_sum + (H + 1), 1, 2 * H, 2 * H); sc.pc[2] = cW2;
+            sc.pc[3] = piece(wr.w3_sum + (H + 1) + 2 * H, 1, 2 * H, 2 * H); sc.pc[4] = cW3;
+        } else {
+            sa.pc[0] = aW1; sa.pc[1] = aW2; sa.pc[2] = aW3;
+            sc.pc[0] = cW1; sc.pc[1] = cW2; sc.pc[2] = cW3;
+        }
     }
     if (do_d) {
         Arena ar(ws_d, disc_bytes);
@@ -1708,20 +1743,35 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
         d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
         d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
-        d.X = w.X; d.A1 = w.h.A1; d.A2 = w.h.A2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
+        d.X = w.X; d.A1 = w.h.N1; d.A2 = w.h.N2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
         d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part; d.w3_part = wr.w3d;
-        // D W2 / W1: policy + expert rows (with the bias row), then the interpolate rows (take the scalar k)
-        prob(5, w.h.A1, H, H, w.k.DZ2, H, H, 2 * B, 2 * B);
-        prob(6, w.h.A1 + 2 * B * H, H, H, w.k.DZ2 + 2 * B * H, H, H, B, -1);
+        if (ln) { d.XH1 = w.h.XH1; d.XH2 = w.h.XH2; d.TN1 = w.TA1; d.PA1 = w.TA2; }
+        // D W2 / W1: policy + expert rows (with the bias row), then the interpolate rows (take the scalar k).
+        // LayerNorm: the interpolate rows are 2B rows [primal stream | tangent stream] — n1^T P_z2 + ndot1^T T_z2 and
+        // x^T P_z1 + V^T T_z1 — with the bias row over the primal half (db = sum P_z)
+        const int64_t RI = ln ? 2 * B : B, onesI = ln ? B : -1;
+        prob(5, w.h.N1, H, H, w.k.DZ2, H, H, 2 * B, 2 * B);
+        prob(6, w.h.N1 + 2 * B * H, H, H, w.k.DZ2 + 2 * B * H, H, H, RI, onesI);
         prob(7, w.X, in, in, w.k.DZ1, H, H, 2 * B, 2 * B);
-        prob(8, w.X + 2 * B * in, in, in, w.k.DZ1 + 2 * B * H, H, H, B, -1);
+        prob(8, w.X + 2 * B * in, in, in, w.k.DZ1 + 2 * B * H, H, H, RI, onesI);
         WFinishSeg& sd = seg(2, Pd, L->grads + Pa + Pc);
-        sd.pc[0] = piece(wr.P[7], wr.ns[7], wr.cnt[7], wr.cnt[7]);
-        sd.pc[0].p2 = wr.P[8]; sd.pc[0].n2 = wr.ns[8]; sd.pc[0].s2 = wr.cnt[8]; sd.pc[0].n2_valid = wr.cnt[8];
-        sd.pc[1] = piece(wr.P[5], wr.ns[5], wr.cnt[5], wr.cnt[5]);
-        sd.pc[1].p2 = wr.P[6]; sd.pc[1].n2 = wr.ns[6]; sd.pc[1].s2 = wr.cnt[6]; sd.pc[1].n2_valid = wr.cnt[6];
-        sd.pc[2] = piece(wr.w3_sum + (H + 1), 1, H + 1, H + 1);
-        sd.pc[2].p2 = wr.w3_sum + 2 * (H + 1); sd.pc[2].n2 = 1; sd.pc[2].s2 = H + 1; sd.pc[2].n2_valid = H;
+        WPiece dW1 = piece(wr.P[7], wr.ns[7], wr.cnt[7], wr.cnt[7]);
+        dW1.p2 = wr.P[8]; dW1.n2 = wr.ns[8]; dW1.s2 = wr.cnt[8]; dW1.n2_valid = wr.cnt[8];
+        WPiece dW2 = piece(wr.P[5], wr.ns[5], wr.cnt[5], wr.cnt[5]);
+        dW2.p2 = wr.P[6]; dW2.n2 = wr.ns[6]; dW2.s2 = wr.cnt[6]; dW2.n2_valid = wr.cnt[6];
+        const float* sumPE = wr.w3_sum + sw;        // policy + expert tiles
+        const float* sumI = wr.w3_sum + 2 * sw;     // interpolate tiles (take k)
+        WPiece dW3 = piece(sumPE, 1, H + 1, H + 1);
+        dW3.p2 = sumI; dW3.n2 = 1; dW3.s2 = H + 1; dW3.n2_valid = H;
+        if (ln) {
+            sd.npc = 5;
+            WPiece l1 = piece(sumPE + (H + 1), 1, 2 * H, 2 * H), l2 = piece(sumPE + (H + 1) + 2 * H, 1, 2 * H, 2 * H);
+            l1.p2 = sumI + (H + 1); l1.n2 = 1; l1.s2 = 2 * H; l1.n2_valid = 2 * H;
+            l2.p2 = sumI + (H + 1) + 2 * H; l2.n2 = 1; l2.s2 = 2 * H; l2.n2_valid = 2 * H;
+            sd.pc[0] = dW1; sd.pc[1] = l1; sd.pc[2] = dW2; sd.pc[3] = l2; sd.pc[4] = dW3;
+        } else {
+            sd.pc[0] = dW1; sd.pc[1] = dW2; sd.pc[2] = dW3;
+        }
         f.gp_seg = f.nseg - 1; f.gp_part = w.gp_part;
     }
     if (run) {
@@ -1730,14 +1780,15 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         if (do_a && L->wd_scale > 0.f) { a.wd_part = w1.wd_part; a.wd_blocks = kWdBlocks; }
         TRY(wide::launch_roles(do_a ? &a : nullptr, do_d ? &d : nullptr, (do_a ? 3 : 0) | (do_d ? 4 : 0), st));
         if (do_a && !w3a_group)   // an action head narrower than 16 bytes: the plain split product
-            TRY(wgrad(w2.ha.A2, H, H, w2.dPre, ac, ac, B, B, wr.w3a_tmp, 0.f, nullptr, w2.partials,
+            TRY(wgrad(w2.ha.N2, H, H, w2.dPre, ac, ac, B, B, wr.w3a_tmp, 0.f, nullptr, w2.partials,
                       w2.partial_floats, st));
-        SlotSum sl[3];
+        SlotSum sl[kSlotSumMax];
         int nsl = 0;
-        if (do_a) sl[nsl++] = SlotSum{wr.w3c, tiles, H + 1, wr.w3_sum};
+        if (do_a) sl[nsl++] = SlotSum{wr.w3c, tiles, sw, wr.w3_sum};
+        if (do_a && ln) sl[nsl++] = SlotSum{wr.lna, tiles, wide::kLnSlot, wr.lna_sum};
         if (do_d) {
-            sl[nsl++] = SlotSum{wr.w3d + (int64_t)tiles * (H + 1), 2 * tiles, H + 1, wr.w3_sum + (H + 1)};
-            sl[nsl++] = SlotSum{wr.w3d, tiles, H + 1, wr.w3_sum + 2 * (H + 1)};
+            sl[nsl++] = SlotSum{wr.w3d + (int64_t)tiles * sw, 2 * tiles, sw, wr.w3_sum + sw};
+            sl[nsl++] = SlotSum{wr.w3d, tiles, sw, wr.w3_sum + 2 * sw};
         }
         TRY(gemm_group_partials(gl, ng, st, sl, nsl));
     }

@@ -81,10 +81,12 @@ def assert_per_var(got, exp, desc, tol, tag, abs_tol=0.0, floors=None, tol_by_va
             record_margin(tag + '/fp32cpu_floor', name, floors[name])
             t = max(t, min(FLOOR_FACTOR * floors[name], FLOOR_CAP))
         den = np.max(np.abs(exp[off:off + n]))
-        if not np.max(np.abs(got[off:off + n] - exp[off:off + n])) <= t * (den if den > 0 else 1.0) + abs_tol:
+        # (abs_tol: a scalar, or one allowance per element of the flat vector — OracleLearner.adam's)
+        at = abs_tol[off:off + n] if isinstance(abs_tol, np.ndarray) else abs_tol
+        if not np.max(np.abs(got[off:off + n] - exp[off:off + n]) - at) <= t * (den if den > 0 else 1.0):
             bad[name] = (errs[name], t)
-    assert not bad, '%s: per-variable error beyond its bar (error, bar) (+ %g absolute): %r (all: %r; floors: %r)' % (
-        tag, abs_tol, bad, errs, floors)
+    assert not bad, '%s: per-variable error beyond its bar (error, bar) (+ %s absolute): %r (all: %r; floors: %r)' % (
+        tag, 'per-element' if isinstance(abs_tol, np.ndarray) else '%g' % abs_tol, bad, errs, floors)
     return errs
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.nets_cases import assert_per_var, make_case, relerr
+from tests.nets_cases import assert_per_var, make_case, record_margin, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -42,19 +42,19 @@ def _setup(name, d_scale, ent, per, rms=True, ln=False):
     return c, L, batch, ops.make_step_out(B)
 
 
-def _oracle(c, d_scale, ent, per, rms=True):
+def _oracle(c, d_scale, ent, per, rms=True, dtype=torch.float64):
     from oracle import nets_oracle as NO
     P, D = c['P'], c['D']
     mean, std = (c['mean'], c['std']) if rms else (0.0, 1.0)
     B = c['B']
     dl, dg = NO.disc_loss_grad(P['pd'], c['dd'], D['obs0'], D['acs'], D['e_obs'], D['e_acs'], D['eps_ob'],
-                               D['eps_ac'], D['real'], D['fake'], mean, std, ent_reg_scale=ent, rmsify=rms)
+                               D['eps_ac'], D['real'], D['fake'], mean, std, ent_reg_scale=ent, rmsify=rms, dtype=dtype)
     tq = NO.targ_q(P['pa_t'], P['pc_t'], c['da'], c['dc'], D['obs1'], D['rews'][:, None],
-                   D['dones1'][:, None], np.ones((B, 1)), mean, std, 0.99, 0.4, rmsify=rms)
+                   D['dones1'][:, None], np.ones((B, 1)), mean, std, 0.99, 0.4, rmsify=rms, dtype=dtype)
     al, ag = NO.actor_loss_grad(P['pa'], c['da'], P['pc'], c['dc'], P['pd'][::-1].copy() if d_scale else None,
-                                c['dd'], D['obs0'], mean, std, 0.4, 1.0, d_scale, rmsify=rms)
+                                c['dd'], D['obs0'], mean, std, 0.4, 1.0, d_scale, rmsify=rms, dtype=dtype)
     cl, cg, td = NO.critic_loss_grad(P['pc'], c['dc'], D['obs0'], D['acs'],
-                                     D['iws'][:, None] if per else None, tq, mean, std, 1e-3, rmsify=rms)
+                                     D['iws'][:, None] if per else None, tq, mean, std, 1e-3, rmsify=rms, dtype=dtype)
     return dict(d_losses=dl, actor_losses=al, critic_losses=cl, targ_q=tq.ravel(), td=td.ravel(),
                 grads=np.concatenate([ag, cg, dg]))
 
@@ -77,21 +77,35 @@ def _oracle(c, d_scale, ent, per, rms=True):
     ('s_20x4', 0.5, 0.0, False, True, True), ('s_13x2', 0.0, 0.0, True, True, True),
     ('s_1x1', 0.5, 0.0, False, True, False), ('s_2x1', 0.0, 1e-3, True, True, False),
     ('s_7x5', 0.5, 1e-3, True, False, False), ('s_20x4', 0.5, 0.0, False, True, False),
-    ('s_13x2', 0.0, 0.0, True, True, False)])
+    ('s_13x2', 0.0, 0.0, True, True, False),
+    # with_layernorm on the role-fused 256-wide path (fused_wide.hip: LayerNorm mini-phases, two-stream GP)
+    ('w_20x3', 0.0, 0.0, False, True, True), ('w_40x32', 0.0, 1e-3, True, True, True),
+    ('w_7x17', 0.0, 0.0, True, False, True)])
 def test_step_grads_vs_oracle(name, d_scale, ent, per, rms, ln):
     from sam_tf_amd import ops
     c, L, batch, out = _setup(name, d_scale, ent, per, rms, ln)
     assert L.fused(c['B']) == (name in ('C1', 'C2', 'C3') or name.startswith('s_'))
+    # 256x256 nets without an actor loss through the reward net: the role-fused path, LayerNorm or not
+    assert (L.path(c['B']) == 2) == ((name == 'C4' or name.startswith('w_')) and d_scale == 0.0)
     exp = _oracle(c, d_scale, ent, per, rms)
     ops.step_grads(L, batch, out)
     torch.cuda.synchronize()
+    tag = 'step_grads/%s%s%s' % (name, '-ln' if ln else '', '-dscale' if d_scale else '')
+    exp32 = None
     for k in ('d_losses', 'actor_losses', 'critic_losses'):
         got = out.t[k].cpu().numpy().astype(np.float64)[:len(exp[k])]
-        assert np.max(np.abs(got - exp[k]) / np.maximum(np.abs(exp[k]), 1e-3)) < TOL, (k, got, exp[k])
+        err = np.max(np.abs(got - exp[k]) / np.maximum(np.abs(exp[k]), 1e-3))
+        if err >= TOL:
+            # a loss is a mean of signed terms (the actor's: -mean Q) and can sit far below its terms' scale: it may
+            # then be off by 4 x what torch float32 ON THE CPU leaves on the same inputs (recorded)
+            exp32 = exp32 or _oracle(c, d_scale, ent, per, rms, dtype=torch.float32)
+            floor = np.max(np.abs(exp32[k] - exp[k]) / np.maximum(np.abs(exp[k]), 1e-3))
+            record_margin(tag + '/loss_fp32cpu_floor', k, floor)
+            record_margin(tag + '/loss_error', k, err)
+            assert err < 4 * floor, (k, got, exp[k], exp32[k])
     assert relerr(out.t['targ_q'].cpu().numpy(), exp['targ_q']) < TOL
     assert relerr(out.t['td'].cpu().numpy(), exp['td']) < TOL
     g = L.grads.cpu().numpy()
-    tag = 'step_grads/%s%s%s' % (name, '-ln' if ln else '', '-dscale' if d_scale else '')
     for k, (net, desc) in enumerate((('actor', c['da']), ('critic', c['dc']), ('reward', c['dd']))):
         # every variable of every network against its own max-norm
         assert_per_var(L.seg(torch.as_tensor(g), k).numpy(), L.seg(torch.as_tensor(exp['grads']), k).numpy(), desc,
