@@ -80,8 +80,22 @@ def build_learner(cfg, comm, device, seed, use_graph):
     r = lambda *s: torch.randn(*s, generator=g, device=device)
     u = lambda *s: torch.rand(*s, generator=g, device=device)
     obs0, obs1 = r(n, cfg['ob']), r(n, cfg['ob'])
-    mu.replay_buffer.extend_device(obs0, u(n, cfg['ac']) * 2 - 1, u(n) * 5, obs1,
-                                   (u(n) < cfg.get('p_done', 1e-3)).float())
+    acs_, rews_, dones_ = u(n, cfg['ac']) * 2 - 1, u(n) * 5, (u(n) < cfg.get('p_done', 1e-3)).float()
+    n_demo = int(cfg.get('demos', 0))
+    if n_demo:
+        # add_demos_to_mem (sam.py:244-246, memory.py:186-198): the first n_demo transitions are pinned in front of
+        # the ring as demonstrations; the rest go in one by one as rollouts would store them (the bulk fill assumes a
+        # ring without demonstrations), plus cfg['demos_extra'] more so that the ring's start moves inside its span
+        import types
+        c = lambda t: t.cpu().numpy()
+        host = [c(t) for t in (obs0, acs_, rews_, obs1, dones_)]
+        mu.replay_buffer.add_demo_transitions_to_mem(types.SimpleNamespace(
+            obs0=host[0][:n_demo], acs=host[1][:n_demo], env_rews=host[2][:n_demo], obs1=host[3][:n_demo],
+            dones1=host[4][:n_demo]))
+        for i in range(n_demo, n + int(cfg.get('demos_extra', 0))):
+            mu.replay_buffer.append(*(h_[i % n] for h_ in host))
+    else:
+        mu.replay_buffer.extend_device(obs0, acs_, rews_, obs1, dones_)
     if hps.rmsify_obs:  # what store_transition would have accumulated (sam_agent.py:627-629)
         mu.obs_rms.update_device(obs0, None, comm)
     del obs0, obs1
@@ -263,6 +277,8 @@ def other_configs(comm, device, args):
     for name, steps, warm in OTHER_RUNS:
         cfg = dict(CONFIGS[name], ln=False, ret=False, nstep=0)
         try:
+            if os.environ.get('SAMX_BENCH_FAIL_OTHER') == name:   # test hook for the "degraded" exit below
+                raise RuntimeError('forced by SAMX_BENCH_FAIL_OTHER')
             mu, d, pool, drv = build_learner(cfg, comm, device, args.seed, True)
             drv.prepare_all()
             drv.run(warm)
@@ -553,10 +569,21 @@ def main():
             except Exception as e:  # noqa: BLE001
                 oa[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         result['config']['object_api_steps_per_s'] = oa
+        # a side run that raised is never silent: the headline line still comes out (its own measurement is
+        # complete), carries a top-level "degraded" naming what was lost, and the process exits 3
+        lost = ['other_configs.%s: %s' % (k, v['error']) for k, v in result['config']['other_configs'].items()
+                if 'error' in v]
+        lost += ['object_api_steps_per_s.%s: %s' % (k, v['error']) for k, v in oa.items()
+                 if isinstance(v, dict) and 'error' in v]
+        if lost:
+            result['degraded'] = result['failed_stage'] = '; '.join(lost)
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
+    if world == 1 and result.get('degraded'):
+        sys.stdout.flush()
+        sys.exit(3)
     if world > 1:
         import torch.distributed as dist
         # the line is out and complete: a stuck teardown must not hold the job; it is reported on stderr

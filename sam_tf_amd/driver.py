@@ -142,7 +142,9 @@ class UpdateStepDriver(object):
         self.ret_addvec = torch.zeros(6, dtype=torch.float64, device=dev) if self.popart_split else None
         f32 = dict(dtype=torch.float32, device=dev)
         rb = mu.replay_buffer
-        assert rb.num_demos == 0, "driver assumes a replay buffer without pinned demos"
+        # (demonstrations pinned in front of the ring — add_demos_to_mem, memory.py:186-198 — need nothing special
+        # here: logical index -> storage row stays (start + idx) % limit, memory.py:25-28, and the priority refresh is
+        # handed num_demos / demos_eps: test_k_steps_match_oracle[C1-demos | C3-demos])
         # static device buffers (their addresses are baked into the captured graphs)
         self.W = 5 * B + 1
         self.words = torch.zeros(self.K, self.W, dtype=torch.int64, device=dev)
