@@ -490,12 +490,22 @@ constexpr int kStaticObMax = 512;   // widest observation the static variant tak
 constexpr size_t kStaticScratchBytes = (size_t)kStatGroupsMax * 2 * kStaticObMax * sizeof(double) + 256;  // 1 MiB + 256
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
-int static_scratch(void** out) {
+int static_scratch(void** out, hipStream_t st) {
     static void* per_dev[64] = {nullptr};
     static std::mutex mu;
     int dev = 0;
     SAMX_CHECK_HIP(hipGetDevice(&dev));
     SAMX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    if (st) {
+        // the array used is the CURRENT device's copy: a stream of another GPU would be handed an address of this
+        // one.  (A query, legal under capture; if the runtime cannot answer, the caller's contract stands.)
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(st, &sdev) == hipSuccess)
+            SAMX_REQUIRE((int)sdev == dev, "samx_d_input_stats_static: the stream belongs to device %d, the current "
+                         "device is %d (make the stream's device current first)", (int)sdev, dev);
+        else
+            (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lock(mu);
     if (!per_dev[dev]) {
         void* ptr = nullptr;
@@ -583,7 +593,7 @@ int samx_d_input_stats_static(const float* replay_obs0, int64_t ring_start, int6
                  "samx_d_input_stats_static: B %lld x ob_dim %d needs %zu scratch bytes, the static scratch holds %zu",
                  (long long)B, ob_dim, samx_d_input_stats_ws_bytes(B, ob_dim), kStaticScratchBytes);
     void* ptr = nullptr;   // this device's copy of the array (never the symbol itself)
-    int rc = static_scratch(&ptr);
+    int rc = static_scratch(&ptr, (hipStream_t)stream);
     if (rc != SAMX_OK) return rc;
     // every word of the partials that the commit kernel reads is written by the partials kernel of the
     // same call first: nothing has to start at zero, the previous call's contents are simply overwritten
@@ -888,7 +898,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
                                   do_d ? L->steps + 2 : nullptr, st);
     }
-    if (wide && !t_only && !t_done) {
+    if (wide) {
         // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions, all on the caller's stream
         samx::WideExt we;
         auto roles = [&](const samx::WideExt* e) {
@@ -899,7 +909,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
             // sam_agent.py:634-672: [n-step lookahead] -> targets with the OLD return statistics / heads ->
             // ret_rms.update + PopArt -> losses with the new ones
             we.tqn = L->n_step > 0 ? (o->targ_q_n ? o->targ_q_n : w.n_tq) : nullptr;
-            if ((part & 1) && L->n_step > 0) {
+            if ((part & 1) && L->n_step > 0 && !t_done) {
                 SAMX_REQUIRE(b->a_idx && b->num_entries > 0,
                              "samx_step_grads: n-step returns need a_idx (ring rows) and num_entries");
                 if (b->n_end) {   // done ahead by the caller (samx_nstep_lookahead_many)
@@ -913,15 +923,21 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                 }
             }
             if (part & 1) {
-                we.targets_only = true;
-                rc = roles(&we);
-                if (rc != SAMX_OK) return rc;
-                we.targets_only = false;
-                if (L->ret_mean && L->enable_popart) {  // sam_agent.py:662-672: batch sums, commit and rescale in ONE launch
+                if (!t_done) {
+                    we.targets_only = true;
+                    rc = roles(&we);
+                    if (rc != SAMX_OK) return rc;
+                    we.targets_only = false;
+                }
+                if (L->ret_mean && L->enable_popart) {
+                    // sam_agent.py:662-672: batch sums, commit and rescale in ONE launch; N processes (bits 4/5):
+                    // the local sums -> batch.ret_addvec [caller: all-reduce] commit of the summed vector + rescale
                     rc = fused::launch_ret_popart(o->targ_q, we.tqn, B, L->ret_sums, L->ret_mean, L->ret_std, 1,
-                                                  L->params + Pa, L->targets + Pa, &L->critic, 0, nullptr, st);
+                                                  L->params + Pa, L->targets + Pa, &L->critic,
+                                                  t_only ? 1 : (t_done ? 2 : 0), b->ret_addvec, st);
                     if (rc != SAMX_OK) return rc;
                 }
+                if (t_only) return SAMX_OK;
             }
             we.use_ext = true;
         }

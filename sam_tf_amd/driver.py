@@ -128,11 +128,11 @@ class UpdateStepDriver(object):
             m *= 2
         # rows per launch: whole training steps
         self.K = m * self.S if (self.use_graph and (not self.per or self.per_dev)) else 1
-        if self.world > 1 and not self.fused:
+        if self.world > 1 and not (self.fused or self.wide):
             self.K = 1   # layer-wise path under N > 1: the three-segment plan, one step per launch
         # N > 1 with a communicator whose all-reduce runs on the caller's stream (sam_tf_amd.rccl): the
         # collectives are captured INSIDE the K-step graph, the host issues one launch per K steps
-        self.collectives_in_graph = bool(self.world > 1 and self.fused and self.use_graph and
+        self.collectives_in_graph = bool(self.world > 1 and (self.fused or self.wide) and self.use_graph and
                                          getattr(self.comm, 'capturable', False) and
                                          os.environ.get('SAMX_RCCL_GRAPH', '1') != '0')
         # N > 1 with return normalisation + PopArt: ret_rms.update all-reduces the targets' batch sums between
@@ -227,7 +227,7 @@ class UpdateStepDriver(object):
         self._batch_entries = rb.num_entries
         # fused path: the d.obs_rms commit rides inside the step kernels; the batch sums come from one
         # kernel per launch (all-reduced once per launch when N > 1)
-        self.inline_stats = bool((self.fused or (self.wide and self.world == 1)) and self.d.hps.rmsify_obs)
+        self.inline_stats = bool((self.fused or self.wide) and self.d.hps.rmsify_obs)
         self.sums_small = 2 * B * self.mu.ob_dim <= 16384   # what the one-workgroup sums kernels hold (samx.h)
         # layer-wise path, one process: samx_step_grads computes and commits the row's D statistics itself,
         # on the discriminator's stream, while the agent roles already run (no separate stats segment)
@@ -503,8 +503,8 @@ class UpdateStepDriver(object):
         #   per row: [statistics -> all-reduce]                                      (layer-wise path)
         #            [targets + local return sums -> all-reduce]                     (PopArt)
         #            gradients (+ local clipped copies) -> all-reduce(grads) -> optimiser pass
-        assert self.fused or K == 1
-        fused_stats = self.inline_stats or (self.fused and not d.hps.rmsify_obs)
+        assert self.fused or self.wide or K == 1
+        fused_stats = self.inline_stats or ((self.fused or self.wide) and not d.hps.rmsify_obs)
         items = []
         if self.inline_stats and any_d:
             items += [('dev', lambda: self._seg_sums(K)), ('ar', lambda: ar(self.addvecs[:K]))]
@@ -921,7 +921,7 @@ class UpdateStepDriver(object):
     def set_collectives(self, in_graph):
         """Choose between collectives captured inside the K-row graph (needs a capturable
         communicator) and collectives issued by the host between graph segments; re-plans."""
-        in_graph = bool(in_graph and self.world > 1 and self.fused and self.use_graph and
+        in_graph = bool(in_graph and self.world > 1 and (self.fused or self.wide) and self.use_graph and
                         getattr(self.comm, 'capturable', False))
         if in_graph != self.collectives_in_graph:
             self.collectives_in_graph = in_graph

@@ -1018,24 +1018,31 @@ class _TwinComm(object):
         pass
 
 
-@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'ragged', 'C1-retn', 'C3-ret', 'ragged-retn', 'C1-launcher'])
+@pytest.mark.parametrize('cfg_name', ['C1', 'C3', 'ragged', 'C1-retn', 'C3-ret', 'ragged-retn', 'C1-launcher',
+                                      'wsmall', 'wsmall-retn', 'wsmall-launcher', 'C4', 'C4-launcher'])
 def test_two_rank_plan_matches_oracle(cfg_name):
     """-ret / -retn / -launcher: return normalisation + PopArt under N > 1 — the targets' batch sums are
-    all-reduced between the target pass and the PopArt rescale (samx_step_grads_part bits 4/5)."""
+    all-reduced between the target pass and the PopArt rescale (samx_step_grads_part bits 4/5).
+    wsmall / C4: the role-fused 256-wide kernels under the N > 1 plan — K rows per launch, the D-input sums of the K
+    rows all-reduced once, and the PopArt split between the target launch and the role launch."""
     import bench
     base, _, opt = cfg_name.partition('-')
     if base == 'ragged':  # not fusable: the layer-wise path under the N > 1 plan
         cfg = dict(ob=5, ac=2, h=(33, 70), B=37, per=False, mem=2048, name='ragged')
+    elif base == 'wsmall':
+        cfg = dict(ob=20, ac=3, h=(256, 256), B=48, per=False, mem=2048, name='wide-small')
     else:
         cfg = dict(bench.CONFIGS[base], mem=2048)
     cfg.update(ln=opt == 'launcher', ret=bool(opt), nstep=7 if opt in ('retn', 'launcher') else 0, p_done=0.1)
     mu, d, pool, drv = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 3, True)
     fusable = base != 'ragged'   # LayerNorm (launcher options) included
+    assert drv.wide == (base in ('wsmall', 'C4'))
     assert drv.world == 2 and drv.inline_stats == fusable and drv.popart_split == bool(opt)
-    assert drv.K == ((16 if opt else 32) if base == 'C1' and fusable else 1)   # uniform replay on the fused path packs K steps
+    # uniform replay on the whole-network / role-fused paths packs K steps
+    assert drv.K == ((16 if opt else 32) if base in ('C1', 'wsmall', 'C4') and fusable else 1)
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
-    K = 4
+    K = 3 if base == 'C4' else 4
     forced = bool(opt)   # return normalisation: every update from the device's state (see test_k_steps_match_oracle)
     ref.floor = forced
     nets = ('actor', 'critic', 'targ_critic', 'reward')
@@ -1050,8 +1057,16 @@ def test_two_rank_plan_matches_oracle(cfg_name):
             ref.gpu_ret = dict(old=ret_old, new=(float(mu.ret_rms.mean.item()), float(mu.ret_rms.std.item())))
         e0 = int(drv.e_start.item())
         eps_ob, eps_ac, real, _ = drv.step_randoms(k)
+        # the flat gradient holds the SUM over ranks after the all-reduce; the mean is what the optimiser pass used
+        # (at full size the oracle is told it, for the units at the lrelu kink: OracleLearner.with_kinks)
+        g_mean = {key: h(drv.L.seg(drv.L.grads, seg)) / drv.world for seg, key in enumerate('acd')}
+        if base == 'C4':
+            ref.gpu_g = g_mean
         out = ref.step(h(drv.idx_p), h(pool.obs0[e0:e0 + drv.B]), h(pool.acs[e0:e0 + drv.B]), h(eps_ob),
                        h(eps_ac), h(real), idx_a=h(drv.idx_a), u=h(drv.u), gpu_td=h(drv.td_post))
+        for key, desc in (('a', ref.da), ('c', ref.dc), ('d', ref.dc)):
+            assert_per_var(g_mean[key], ref.last_g[key], desc, 1e-5, 'two_rank/%s/grads_%s' % (cfg_name, key),
+                           floors=ref.floor_g.get(key) if forced else None)
         o = drv.outputs()
         for name in ('d_losses', 'actor_losses', 'critic_losses'):
             got, exp = h(o[name]).astype(np.float64), out[name]
@@ -1067,15 +1082,19 @@ def test_two_rank_plan_matches_oracle(cfg_name):
         assert abs(mu.ret_rms.sums[2].item() - ref.ret_sums[2]) < 1e-9   # counts: 2 ranks x B x (1 or 2) per step
 
 
+@pytest.mark.parametrize('wide', [False, True])
 @pytest.mark.parametrize('g_steps,retn', [(1, False), (3, False), (1, True), (3, True)])
-def test_two_rank_packed_launch_equals_single_steps(g_steps, retn):
+def test_two_rank_packed_launch_equals_single_steps(g_steps, retn, wide):
     """N > 1, fused path: K rows per host iteration (one all-reduce of the K D-input sum vectors, then
     one gradient all-reduce per row — of the segments the row's roles fill) leave the learner
-    bit-identical to single-row launches; also with the launcher's 1:3 schedule."""
+    bit-identical to single-row launches; also with the launcher's 1:3 schedule.  wide: 256x256 nets with LayerNorm
+    (role-fused kernels)."""
     import random
     import bench
     from sam_tf_amd.driver import UpdateStepDriver
     cfg = dict(bench.CONFIGS['C1'], mem=4096)
+    if wide:
+        cfg = dict(ob=20, ac=3, h=(256, 256), B=48, per=False, mem=4096, name='wide-small', ln=True)
     if retn:   # + return normalisation, PopArt (one more all-reduce per agent row) and n-step returns
         cfg.update(ret=True, nstep=7, p_done=0.1)
     states = []
@@ -1083,7 +1102,7 @@ def test_two_rank_packed_launch_equals_single_steps(g_steps, retn):
         mu, d, pool, _ = bench.build_learner(cfg, _TwinComm(), torch.device('cuda', 0), 5, True)
         drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4 if g_steps == 1 else 6,
                                g_steps=g_steps)
-        assert drv.K == (4 if g_steps == 1 else 6) and drv.world == 2
+        assert drv.K == (4 if g_steps == 1 else 6) and drv.world == 2 and drv.wide == wide
         drv.prepare_all()
         if g_steps == 1:
             assert len(drv.plans[(4, 0)]) == 2 + (4 if retn else 2) * 4 + 1
@@ -1121,8 +1140,11 @@ def test_in_graph_rccl_collectives_equal_host_issued():
                             device_id=dev)
     try:
       # second pass: + return normalisation / PopArt / n-step (the all-reduce of the return sums in the graph)
-      for retn in (False, True):
+      # third pass: 256x256 nets with the launcher's options (role-fused kernels, K rows per graph under N > 1)
+      for retn, wide in ((False, False), (True, False), (True, True)):
         cfg = dict(bench.CONFIGS['C1'], mem=4096)
+        if wide:
+            cfg = dict(ob=20, ac=3, h=(256, 256), B=48, per=False, mem=4096, name='wide-small', ln=True)
         if retn:
             cfg.update(ret=True, nstep=7, p_done=0.1)
         states = []
@@ -1131,7 +1153,7 @@ def test_in_graph_rccl_collectives_equal_host_issued():
             assert comm.capturable
             mu, d, pool, _ = bench.build_learner(cfg, comm, dev, 5, True)
             drv = UpdateStepDriver(mu, d, pool, use_graph=True, steps_per_launch=4)
-            assert drv.collectives_in_graph and drv.K == 4 and drv.popart_split == retn
+            assert drv.collectives_in_graph and drv.K == 4 and drv.popart_split == retn and drv.wide == wide
             assert drv.set_collectives(mode == 'graph') == (mode == 'graph')
             drv.prepare(1); drv.prepare(4)
             assert len(drv.plans[(4, 0)]) == (1 if mode == 'graph' else 2 + (4 if retn else 2) * 4 + 1)
