@@ -297,7 +297,17 @@ def other_configs(comm, device, args):
                  'roofline': {'bound': 'latency' if drv.fused else 'mfma', 'frac': ach / PEAK_FP32_TFLOPS,
                               'achieved_tflops': ach, 'kernel_us': dom * 1e6,
                               'flops_per_launch': flops_per_step(cfg),
+                              # the same flops over the whole timed step (reduction, optimiser pass, replay /
+                              # tree work, launch gaps included): the figure nothing can flatter
+                              'frac_whole_step': flops_per_step(cfg) / (el / steps) / 1e12 / PEAK_FP32_TFLOPS,
                               'traffic': pmc_traffic(name)}}
+            if not (drv.fused or drv.wide):
+                # layer-wise path: the network passes run on three streams, so their HIP-event time is no
+                # kernel's duration — `frac` is the whole-step figure there, the event-timed one is kept beside it;
+                # the per-kernel figure (sum of GEMM flops / sum of GEMM kernel time) is in profiles/ (rocprofv3)
+                o['roofline']['frac_network_passes_hip_events'] = o['roofline']['frac']
+                o['roofline']['frac'] = o['roofline']['frac_whole_step']
+                o['roofline']['achieved_tflops'] = o['roofline']['frac'] * PEAK_FP32_TFLOPS
             del mu, d, pool, drv
             gc.collect()
             torch.cuda.empty_cache()

@@ -565,7 +565,13 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
  * out and workspace in both calls.
  * Part bit 6 (value 64): the update counters of the roles are NOT advanced — an evaluation that no optimiser
  * pass follows (d.get_grads / d.get_losses, sam.py:398-399: the reference runs them as sess.runs of their own
- * before d.optimize). */
+ * before d.optimize).
+ * Under HIP stream capture: on the layer-wise path (samx_step_path 0) the call forks two role streams from
+ * `stream`; `stream` must then be the capture's ORIGIN stream.  A fork of a forked stream crashes
+ * hipStreamEndCapture in the HIP runtime this was built against (torch 2.10.0+rocm7.0) — with plain torch streams
+ * too, libsamx not involved: profiles/r03_nested_fork_capture.txt, tools/exp/nested_fork_capture.py.  The runtime
+ * offers no way to tell an origin stream from a forked one, so the call cannot reject it; SAMX_SERIAL_ROLES=1
+ * makes the call fork nothing.  Paths 1 and 2 never fork. */
 int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const samx_step_out* out,
                          void* ws, size_t ws_bytes, int part, void* stream);
 

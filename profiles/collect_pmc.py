@@ -27,7 +27,7 @@ def avg_counter(d, kernel_sub, counter):
     return (tot / n if n else None), n
 
 
-def main(config, kernel_sub, fetch_dir, write_dir):
+def main(config, kernel_sub, fetch_dir, write_dir, per_step_kernel=None):
     fetch, nf = avg_counter(fetch_dir, kernel_sub, 'FETCH_SIZE')
     write, nw = avg_counter(write_dir, kernel_sub, 'WRITE_SIZE')
     out = {'config': config, 'kernel': kernel_sub, 'launches_fetch': nf, 'launches_write': nw,
@@ -37,6 +37,17 @@ def main(config, kernel_sub, fetch_dir, write_dir):
         out['fetch_bytes_doubled'] = 2 * fetch * 1024
         out['write_bytes'] = write * 1024
         out['traffic_bytes_per_launch'] = 2 * fetch * 1024 + write * 1024
+        if per_step_kernel:
+            # a step of many launches of `kernel_sub` (the layer-wise path's GEMMs): launches per step from a kernel
+            # that runs once per step, and the step's traffic through `kernel_sub` = launches x the average
+            _, n_steps = avg_counter(fetch_dir, per_step_kernel, 'FETCH_SIZE')
+            if n_steps:
+                out['per_step_kernel'] = per_step_kernel
+                out['launches_per_step'] = nf / n_steps
+                out['traffic_bytes_per_launch_avg'] = out['traffic_bytes_per_launch']
+                out['traffic_bytes_per_launch'] = out['traffic_bytes_per_launch_avg'] * nf / n_steps
+                out['note'] = ('traffic_bytes_per_launch is per UPDATE STEP here (all %s launches of a step), to go '
+                               'with a roofline whose flops are per step' % kernel_sub)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_%s.json' % config)
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
@@ -44,4 +55,4 @@ def main(config, kernel_sub, fetch_dir, write_dir):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -25,9 +25,10 @@ class TorchComm(object):
         """Device all-reduces go through librccl on the caller's stream (capturable into hipGraphs)
         instead of the process group's side stream.  Returns True on success on ALL ranks; otherwise every
         rank keeps using torch.distributed.  The all-ranks-or-none agreement is reached stage by stage
-        inside RcclComm's constructor (library / id, communicator rendezvous, probe), so a rank that
-        fails locally never leaves its peers waiting in a different collective; `direct_error` keeps
-        the reason."""
+        inside RcclComm's constructor (library / id, communicator rendezvous, probe): a rank whose stage
+        failed after that stage's collective completed takes its peers with it.  A rank that fails BEFORE
+        it reaches a stage's rendezvous leaves its peers waiting there — bounded by the collectives' timeouts
+        or the caller's watchdog only (see RcclComm); `direct_error` keeps the reason."""
         self.direct_error = None
         if not (self.active and self.Get_size() > 1 and dist.get_backend() == 'nccl'):
             self.direct_error = 'needs an initialised nccl process group with more than one rank'

@@ -107,7 +107,9 @@ class UpdateStepDriver(object):
         # host between them and are packed K per graph like uniform replay.  per_host_pow=True (or
         # SAMX_PER_HOST_POW=1, or a libm the routine does not reproduce) keeps the host refresh of round 1.
         self.per_dev = bool(self.per and self.comm.Get_size() == 1 and not per_host_pow and
-                            os.environ.get('SAMX_PER_HOST_POW', '0') != '1' and ops.pow_matches_host())
+                            os.environ.get('SAMX_PER_HOST_POW', '0') != '1' and ops.pow_matches_host() and
+                            # ... and the device build, with THIS buffer's exponents (alpha, -beta)
+                            ops.pow_device_matches_host(mu.replay_buffer.alpha, mu.replay_buffer.beta, dev))
         # Several consecutive steps per graph launch: possible when nothing between two steps needs
         # the host — one process (no collective) and uniform replay (PER's priority refresh computes
         # p ** alpha with the host libm).  The host RNG draws of those steps are made up front, in the

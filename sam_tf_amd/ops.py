@@ -127,6 +127,31 @@ def pow_matches_host(n=200000):
     return _POW_OK
 
 
+_POW_DEV_OK = {}
+
+
+def pow_device_matches_host(alpha, beta, device='cuda', n=4096):
+    """True when the DEVICE build of the pow routine gives this machine's libm bits for the exponents this replay
+    buffer uses: priority ** alpha on float32-born bases (memory.py:341-342,376-377) and (p * N) ** -beta on
+    double ratios (memory.py:301,308).  pow_matches_host checks the host build of the same source on fixed
+    exponents; the device compiler lowers fma / division on its own, so the driver asks this before it keeps the
+    priority refresh on the device (a mismatch falls back to the host refresh: slower, same results)."""
+    dev = torch.device(device)
+    key = (float(alpha), float(beta), dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _POW_DEV_OK:
+        rs = np.random.RandomState(20241)
+        f32 = np.exp(rs.uniform(np.log(1e-6), np.log(1e4), n)).astype(np.float32).astype(np.float64)
+        f32[:4] = (1e-6, np.float64(np.float32(1e-6)), 1.0, np.float64(np.float32(1e4)))
+        ratio = np.exp(rs.uniform(np.log(1e-9), np.log(1e3), n))
+        ok = True
+        for x, y in ((f32, float(alpha)), (f32 + 0.1, float(alpha)), (ratio, -float(beta))):
+            got = pow_device(torch.as_tensor(x, dtype=F64).to(dev), y).cpu().numpy()
+            exp = np.array([float(v) ** y for v in x], dtype=np.float64)   # CPython float.__pow__ -> libm pow
+            ok = ok and bool(np.array_equal(got.view(np.int64), exp.view(np.int64)))
+        _POW_DEV_OK[key] = ok
+    return _POW_DEV_OK[key]
+
+
 def pow_device(x, y):
     """x float64 device tensor -> x ** y with the host pow's bits (samx_pow_device)."""
     _chk(x, F64, (x.numel(),), 'x')

@@ -55,11 +55,18 @@ def _check(rc, what, lib=None):
 class RcclComm(object):
     """One RCCL communicator over the ranks of the default torch.distributed group.
 
-    Construction is COLLECTIVE and staged so that a rank that fails locally never leaves its peers inside
-    a different collective: after each stage every rank contributes "ok so far" to an all-reduce(MIN) over
-    the torch.distributed group (`agree`), and all ranks go on or all give up (ncclCommAbort where a
-    communicator already exists).  Stages: (1) library loaded, unique id obtained on rank 0;
-    (2) id broadcast + ncclCommInitRank; (3) probe all-reduce with a known answer.
+    Construction is COLLECTIVE and staged: after each stage every rank contributes "ok so far" to an
+    all-reduce(MIN) over the torch.distributed group (`agree`), and all ranks go on or all give up
+    (ncclCommAbort where a communicator already exists).  Stages: (1) library loaded, unique id obtained on
+    rank 0; (2) id broadcast + ncclCommInitRank; (3) probe all-reduce with a known answer.
+    What the agreement covers: a rank whose stage FAILED AFTER the stage's own collective completed (or that
+    failed in purely local work, stage 1) — its peers learn of it in `agree` and nobody goes on alone.
+    What it cannot cover: a rank that fails INSIDE a stage before reaching that stage's rendezvous
+    (ncclCommInitRank returning an error before the bootstrap, ncclAllReduce refusing to enqueue) — its peers are
+    then inside the rendezvous / waiting on the stream while it waits in `agree`, two different collectives.
+    That hang is bounded only by the collectives' own timeouts (NCCL's bootstrap timeout, the process group's
+    timeout) or by the caller's watchdog (bench.py prints a `degraded` line and exits 3);
+    tests/test_comm_gloo.py::test_direct_rccl_failure_before_the_rendezvous_is_bounded_by_the_timeout_only shows it.
     N > 1 parity of this path is UNPINNED until it has run on two real GPUs (no multi-GPU box was
     available to tests/; tests/test_comm_gloo.py covers the agreement logic with a stand-in library)."""
 

@@ -5,6 +5,7 @@ surface the reference threads through its helpers) and the exchange arithmetic o
    sync_from_root / check_synced  helpers/mpi_adam.py:38-72
 The GPU kernels themselves are covered by the -m gpu tests; here the collectives' semantics are."""
 import os
+import time
 import socket
 
 import numpy as np
@@ -95,6 +96,8 @@ class _FakeRccl(object):
         return 0
 
     def ncclCommInitRank(self, comm_ref, world, uid, rank):
+        if self.fail_stage == 'before the rendezvous':
+            return 1     # a local failure (bad device, no memory) BEFORE this rank reaches its peers
         dist.barrier()   # a rendezvous, like the real one
         if self.fail_stage == 2:
             return 1
@@ -152,6 +155,46 @@ def _staged_worker(rank, world, port, out):
         out.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
+
+
+def _prebarrier_worker(rank, world, port, out):
+    import datetime
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=8))
+    t0 = time.time()
+    try:
+        from sam_tf_amd.rccl import RcclComm
+        RcclComm(torch.device('cpu'), lib=_FakeRccl(rank, 'before the rendezvous' if rank == 1 else None))
+        out.put((rank, 'set-up succeeded', time.time() - t0))
+    except Exception as e:  # noqa: BLE001
+        out.put((rank, type(e).__name__, time.time() - t0))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - the group is broken after a timed-out collective
+            pass
+
+
+def test_direct_rccl_failure_before_the_rendezvous_is_bounded_by_the_timeout_only():
+    """The residual case the staged agreement does NOT cover (round-2 advice): rank 1 fails inside
+    ncclCommInitRank before it reaches the rendezvous, so rank 0 sits in the rendezvous while rank 1 sits in the
+    agreement's all-reduce — two different collectives.  Nothing in RcclComm can resolve that; what bounds it is the
+    collective's own timeout (here gloo's, 8 s; on GPUs NCCL's bootstrap timeout or bench.py's watchdog, which
+    prints a `degraded` line and exits 3).  Documented behaviour: no rank reports a working communicator, every
+    rank raises, within the timeout."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prebarrier_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=90) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert not p.is_alive()
+    for rank, what, took in res:
+        assert what != 'set-up succeeded', res
+        assert took < 60.0, res
 
 
 def _run_world2(target):

@@ -122,3 +122,21 @@ def test_checkpoint_roundtrip_and_demo_rows(tmp_path):
                              d.obs_rms.sums, mu.ret_rms.sums, mu.ret_rms.std)):
         assert torch.equal(a_, b_)
     assert mu.actor_ops['optimizer'].t == 3
+
+
+def test_layerwise_step_call_captures_on_the_origin_stream_and_serial_on_a_fork():
+    """samx_step_grads[_part] on the layer-wise path forks two role streams from the stream it is handed.  Under
+    stream capture that stream must be the capture's ORIGIN stream: a fork of a forked stream crashes
+    hipStreamEndCapture in this HIP runtime — with torch streams alone, no libsamx involved
+    (profiles/r03_nested_fork_capture.txt; include/samx.h).  The two supported forms, each in a
+    child process (a regression here is a host crash, which must not take the test session with it)."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'exp',
+                        'nested_fork_capture.py')
+    for variant, env_extra in (('samx-on-origin', {}), ('samx-on-fork-serial', {'SAMX_SERIAL_ROLES': '1'})):
+        r = subprocess.run([sys.executable, tool, variant], env=dict(os.environ, **env_extra), capture_output=True,
+                           text=True, timeout=240)
+        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (variant, r.returncode, r.stdout[-300:],
+                                                                       r.stderr[-300:])

@@ -91,3 +91,11 @@ def test_leaves_from_td_on_the_device_match_the_host_refresh():
     ops.per_leaves_from_td(torch.as_tensor(td).cuda(), torch.as_tensor(idx_d).cuda(), cap, n_ent, 0.6, n_demos, 0.1,
                            leaf, state)
     assert int(state.cpu().numpy().view(np.uint64)[1]) == 2
+
+
+@pytest.mark.parametrize('alpha,beta', [(0.3, 1.0), (0.6, 0.4), (1.0, 0.5)])
+def test_driver_gate_checks_the_device_build_with_the_buffers_exponents(alpha, beta):
+    """What UpdateStepDriver asks before it keeps the priority refresh on the device (round-2 advice: the host
+    self-check alone never ran the device build, nor the configured alpha / -beta)."""
+    assert ops.pow_device_matches_host(alpha, beta, 'cuda')
+    assert (float(alpha), float(beta), torch.cuda.current_device()) in ops._POW_DEV_OK

@@ -4,7 +4,7 @@
 # kernel of C2 and of C4, kernel-trace stats + timeline of C4, kernel-trace stats of C3/C5.
 set -o pipefail
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof
 mkdir -p $O
 prof() {  # prof <tag> <bench args...>: kernel trace -> $O/<tag>_results.db
@@ -22,12 +22,12 @@ python3 profiles/summarize_rocpd.py $DBL > $O/${R}_c2_launcher_kernel_stats.txt 
 python3 profiles/timeline_rocpd.py $DBL targets_kernel_ln 1000 > $O/${R}_c2_launcher_step_timeline.txt || exit 1
 grep "^{\"metric\"" $O/c2l_bench.log | tail -1 > $O/${R}_bench_c2_launcher_under_rocprof.json
 rm -f $DBL
-for P in "C2 step_kernel" "C4 roles_kernel"; do
+for P in "C2 step_kernel" "C4 roles_kernel" "C5 gemm_kernel"; do
   set -- $P
   c=$(echo $1 | tr A-Z a-z)
-  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$c -o f --output-format csv -- python3 bench.py --no-cpu --no-others --config $1 --steps 200 --warmup 50 > $O/pmc_f_$c.log 2>&1 || exit 1
-  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$c -o w --output-format csv -- python3 bench.py --no-cpu --no-others --config $1 --steps 200 --warmup 50 > $O/pmc_w_$c.log 2>&1 || exit 1
-  python3 profiles/collect_pmc.py $1 $2 $O/pmc_fetch_$c $O/pmc_write_$c > $O/pmc_collect_$c.log 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$c -o f --output-format csv -- python3 bench.py --no-cpu --no-others --config $1 --steps $([ $1 = C5 ] && echo 30 || echo 200) --warmup $([ $1 = C5 ] && echo 6 || echo 50) --no-training-step > $O/pmc_f_$c.log 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$c -o w --output-format csv -- python3 bench.py --no-cpu --no-others --config $1 --steps $([ $1 = C5 ] && echo 30 || echo 200) --warmup $([ $1 = C5 ] && echo 6 || echo 50) --no-training-step > $O/pmc_w_$c.log 2>&1 || exit 1
+  python3 profiles/collect_pmc.py $1 $2 $O/pmc_fetch_$c $O/pmc_write_$c $([ $1 = C5 ] && echo apply_kernel) > $O/pmc_collect_$c.log 2>&1 || exit 1
   cp profiles/pmc_$1.json $O/pmc_$1.json
 done
 DB4=$(prof c4 --config C4 --steps 300 --warmup 50) || exit 1
