@@ -44,6 +44,8 @@ struct GemmArgs {
     // weight matrices are followed by their bias in the flat vector); otherwise such operands are
     // staged with dword DMAs.
     bool overread_ok = false;
+    // tile order of the launch: 0 = blockIdx as it comes, 1 = XCD-aware (set by gemm(): see xcd_tile in gemm.hip)
+    int tile_order = 0;
 };
 
 int gemm(const GemmArgs& g, hipStream_t stream);

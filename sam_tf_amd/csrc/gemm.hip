@@ -445,9 +445,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #endif
 }
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD
+// has its own L2: with blockIdx taken as it comes the gx column tiles of one 64-row panel of A land on gx different
+// XCDs and every one of them fetches the panel from HBM / Infinity Cache (measured at 8192x400x376: 65 MB fetched
+// per launch against 13 MB of operands, profiles/pmc_C5.json of round 3's first pass).  Here the linear block
+// number L is read as (xcd = L % 8, slot = L / 8) and consecutive slots of one XCD walk the tiles of ONE panel:
+// panel = (by, bz) with gx tiles for unsplit products; for split products (bz = a chunk of the reduction: its
+// tiles share both operand chunks) panel = bz with gx * gy tiles.  A bijection on the full groups of 8 panels;
+// the remainder keeps its own number.  Affinity only — nothing depends on where a block runs.
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int gz, int& bx, int& by, int& bz) {
+    const int inner = gz >= 8 ? gx * gy : gx;          // tiles per panel
+    const int panels = gz >= 8 ? gz : gy * gz;
+    const int L = bx + gx * (by + gy * bz);
+    const int full = (panels >> 3) << 3;
+    if (L >= inner * full) return;
+    const int xcd = L & 7, slot = L >> 3;
+    const int panel = (slot / inner) * 8 + xcd, t = slot % inner;
+    if (gz >= 8) { bz = panel; by = t / gx; bx = t % gx; }
+    else { bx = t; by = panel % gy; bz = panel / gy; }
+}
+
 template <bool A_RC, bool B_RC, int KS, bool A_W, bool B_W, int NSU>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? (NSU == 2 ? 4 : 3) : 1) void gemm_kernel(GemmArgs g) {
-    gemm_tile<A_RC, B_RC, KS, A_W, B_W, NSU>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.tile_order == 1) xcd_tile(gridDim.x, gridDim.y, gridDim.z, bx, by, bz);
+    gemm_tile<A_RC, B_RC, KS, A_W, B_W, NSU>(g, bx, by, bz);
 }
 
 // Several weight-gradient products (TN: both operands free-contiguous, 16-byte staging, split over the
@@ -540,7 +562,11 @@ int launch_layout(const GemmArgs& g, dim3 grid, bool few, hipStream_t stream) {
     return launch_inst<A_RC, B_RC, 1, false, false>(g, grid, stream);
 }
 
-int launch(const GemmArgs& g, hipStream_t stream) {
+int launch(const GemmArgs& g_in, hipStream_t stream) {
+    GemmArgs g = g_in;
+    static int xcd = -1;   // SAMX_GEMM_XCD=0: blockIdx as it comes (A/B experiments)
+    if (xcd < 0) { const char* e = getenv("SAMX_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
+    g.tile_order = xcd ? 1 : 0;
     const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
     dim3 grid(cdiv(g.N, BN), cdiv(Mo, BM), g.nsplit);
     // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
