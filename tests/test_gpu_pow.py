@@ -99,3 +99,21 @@ def test_driver_gate_checks_the_device_build_with_the_buffers_exponents(alpha, b
     self-check alone never ran the device build, nor the configured alpha / -beta)."""
     assert ops.pow_device_matches_host(alpha, beta, 'cuda')
     assert (float(alpha), float(beta), torch.cuda.current_device()) in ops._POW_DEV_OK
+
+
+def test_driver_falls_back_to_the_host_refresh_when_the_device_gate_fails(monkeypatch):
+    """A device build that does not reproduce this machine's libm for the buffer's exponents: the driver keeps the
+    host refresh (one row per launch, logical indices) instead of the device one."""
+    import bench
+    from sam_tf_amd.comm import TorchComm
+    cfg = dict(bench.CONFIGS['C3'], mem=2048)
+    mu, d, pool, drv = bench.build_learner(cfg, TorchComm('cuda'), torch.device('cuda', 0), 3, True)
+    assert drv.per_dev and drv.K > 1
+    rb = mu.replay_buffer
+    monkeypatch.setitem(ops._POW_DEV_OK, (float(rb.alpha), float(rb.beta), torch.cuda.current_device()), False)
+    from sam_tf_amd.driver import UpdateStepDriver
+    drv2 = UpdateStepDriver(mu, d, pool, use_graph=True)
+    assert not drv2.per_dev and drv2.K == 1 and not drv2.per_rows
+    drv2.run(3)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(t).all()) for t in (mu.params, d.params))
