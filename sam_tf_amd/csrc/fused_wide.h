@@ -16,6 +16,9 @@ constexpr int kMaxIn = 416; // widest network input (a multiple of 32)
 struct Net {   // leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat parameter vector)
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int in, out;
+    // k-interleaved images of W1 / W2 for the forward products (launch_pack writes them from W1 / W2 at the head of
+    // every launch sequence: element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3), packed_rows(in) / 256 rows)
+    const float *W1p = nullptr, *W2p = nullptr;
     // LayerNorm behind each hidden activation (networks.py:53-70, network_util.py:32-39), null without it; all
     // networks of a learner carry it or none does (hps.with_layernorm)
     const float *be1 = nullptr, *ga1 = nullptr, *be2 = nullptr, *ga2 = nullptr;
@@ -97,6 +100,10 @@ struct DiscArgs {
 bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* reward, int ob, int ac, int64_t B);
 // roles: bit 0 actor, bit 1 target+critic, bit 2 discriminator
 int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t st);
+// rows of the k-interleaved image of a [K][256] matrix (whole 32-deep stages; the rows beyond K are zero)
+inline int packed_rows(int K) { return (K + 31) / 32 * 32; }
+// k-interleaved images of up to 10 matrices in ONE launch: dst[i] (packed_rows(K[i]) * 256 floats) from W[i] ([K[i]][256])
+int launch_pack(const float* const* W, float* const* dst, const int* K, int n, hipStream_t st);
 // TD targets only: the 1-step targets of the sampled rows into a->targ_q and, with a->n_idx, the n-step targets
 // into a->targ_qn (de-normalised with the CURRENT return statistics, sam_agent.py:196-205)
 int launch_targets(const AgentArgs* a, hipStream_t st);

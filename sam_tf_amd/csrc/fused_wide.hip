@@ -36,8 +36,8 @@ namespace samx {
 namespace wide {
 namespace {
 
-constexpr int NT = 512;                // threads per workgroup
-constexpr int NC = 256;                // compute threads (waves 0-3); threads NC .. NT-1 are the loader waves
+constexpr int NT = 256;                // threads per workgroup: four waves, one per SIMD, all of them compute
+constexpr int NC = 256;                // (round 2: 512 threads, waves 4-7 streamed the weights through an LDS ring)
 constexpr int R = kRows;
 constexpr int H = kH;
 constexpr int LDT = 260;               // pitch of a [16][256] tile
@@ -102,14 +102,10 @@ __device__ __forceinline__ int64_t ring_row(const int64_t* idx, int64_t start, i
 // Ends with a barrier: afterwards every wave is done with A and with the ring.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte-aligned address
 
-// One 32-deep weight stage (32 KB), register-staged by ONE loader wave: 32 x 16 bytes per lane.
-// LDS-DMA was measured first and dropped here: a 1 KiB DMA instruction costs the issuing wave ~130 cycles;
-// plain 16-byte loads issue in a few cycles and land while the MFMAs run.
-struct WRegs { f32x4 q[32]; };
-
 // one layer product's weight operand:
-//   nt = false: B[k][j] = W[k * ldw + jg0 + j], rows k < K (clamped: the padded A columns are zero)
-//   nt = true : B[k][j] = W[(jg0 + j) * ldw + k], rows jg0 + j < N (clamped)
+//   nt = false: B[k][j] = W[k][jg0 + j] of a [K][256] matrix, read from its K-INTERLEAVED IMAGE (pack_kernel):
+//               element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3), rows up to 32 ceil(K / 32) present (zero)
+//   nt = true : B[k][j] = W[(jg0 + j) * ldw + k], rows jg0 + j < N (clamped), straight from the parameter vector
 // nvalid: number of valid output columns (16-column blocks that start beyond it are skipped)
 struct WDesc {
     const float* W;
@@ -119,7 +115,7 @@ struct WDesc {
 __device__ __forceinline__ int wstages(const WDesc& d) { return (d.K + 31) >> 5; }
 
 // a wave-uniform pointer in SGPRs: loads through it take the scalar-base form (one VGPR offset per lane
-// instead of a 64-bit VGPR address per load: 32 loads in flight would otherwise hold 64 address registers)
+// instead of a 64-bit VGPR address per load)
 typedef const __attribute__((address_space(1))) f32x4u glb_f32x4u;
 __device__ __forceinline__ glb_float* uniform_ptr(const float* p) {
     const uint64_t a = (uint64_t)p;
@@ -132,165 +128,126 @@ __device__ __forceinline__ f32x4 load16(glb_float* base_uniform, unsigned off_fl
 }
 
 // (The lane index goes through an opaque asm so that the per-lane offsets are recomputed where they are
-// used: hoisted out of the stage loop they would hold dozens of registers next to the 128 of the stage.)
+// used instead of being hoisted out of the stage loop.)
 __device__ __forceinline__ int opaque_lane() {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     return lane;
 }
-// No row clamps: a stage may read up to 31 rows (NN) / 255 rows (NT) beyond the matrix.  In the flat
-// [W1 | b1 | W2 | b2 | W3 | b3] layout (samx_mlp) every 256-wide W1 / W2 is followed by more than 256 KB of the
-// same parameter vector, so the reads stay inside it; what they fetch is multiplied by zero-padded activation
-// columns (NN) or lands in output columns >= nvalid that are never stored (NT).
-// Address arithmetic per load is what bounds a loader wave (32 loads per stage): ONE scalar base per stage and
-// per-lane offset register, rows through immediates (NN: 4 rows per 4 KB immediate window, 8 scalar adds) or
-// scalar adds (NT: one per load).
-__device__ __forceinline__ void wstage_load(WRegs& x, const WDesc& d, int t) {
-    const int lane = opaque_lane();
-    const int k0 = t << 5;
-    if (!d.nt) {
-        const float* base = d.W + (int64_t)k0 * H + d.jg0;
-        const unsigned o = 4u * lane;
-#pragma unroll
-        for (int q = 0; q < 32; ++q)   // one instruction = one 1 KB row of W
-            x.q[q] = load16(uniform_ptr(base + (q >> 2) * (4 * H)) + (q & 3) * H, o);
-    } else {
-        const float* base = d.W + (int64_t)d.jg0 * H + k0;
-        const unsigned o = (unsigned)((lane >> 3) * H + 4 * (lane & 7));
-#pragma unroll
-        for (int q = 0; q < 32; ++q)   // one instruction = 128 bytes of each of 8 rows of W
-            x.q[q] = load16(uniform_ptr(base + q * (8 * H)), o);
-    }
-}
-__device__ __forceinline__ void wstage_store(const WRegs& x, bool nt, float* S) {
-    const int lane = opaque_lane();
-    if (!nt) {
-        float* p = S + 4 * lane;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) *(f32x4*)(p + q * WP) = x.q[q];
-    } else {
-        // row jl = 8 q + (lane >> 3), chunk (lane & 7) ^ ((jl >> 1) & 7) = sw ^ 4 (q & 1): two bases + immediates
-        const int sw = (lane & 7) ^ (lane >> 4);
-        float* p0 = S + (lane >> 3) * 32 + (sw << 2);
-        float* p1 = S + (lane >> 3) * 32 + ((sw ^ 4) << 2);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) *(f32x4*)(((q & 1) ? p1 : p0) + q * 256) = x.q[q];
-    }
-}
 
-// The weight stream of a chain of products: stages are numbered through the chain (pipe.s).  Stage s lives
-// in ring slot s % 3 and belongs to loader wave s % 4, which issues its 32 loads five stages ahead and writes
-// it to LDS two stages ahead: three stages (96 KB) are in flight per workgroup, one per loader wave, each in
-// that wave's ONE register set (no register set is ever indexed at run time).  The stream runs across
-// product boundaries (`next`): a product's epilogue runs while the first stages of the next one land.
-constexpr int AHEAD = 5;   // a stage's loads are issued this many stages before it is read
+// The weight operand never touches LDS (round 3).  Every weight element of a product is used by exactly ONE wave
+// (wave w owns the output columns [64 w, 64 w + 64)) and exactly once per 16-row tile, so staging it through a
+// shared ring bought nothing and cost a 32 KB LDS write burst, 32 KB of fragment reads and a workgroup barrier per
+// 32-deep stage.  Each wave loads ITS fragments straight from L2 into registers, in MFMA layout, with 16-byte loads:
+// lane (r = lane & 15, kq = lane >> 4) needs B[32 t + 16 g + 4 kq + m][64 w + 16 nb + r] for m = 0..3 —
+//   NT products (backward): four consecutive floats of row (jg0 + 64 w + 16 nb + r) of W as it lies in the
+//       parameter vector;
+//   NN products (forward): four consecutive floats of the k-interleaved image of W that pack_kernel writes at the
+//       head of the launch sequence (a transposition inside blocks of 4 rows: 3.3 MB for the five networks).
+// Eight loads per wave and stage, NSET - 1 stages in flight; the only barriers left are the two around a product
+// (activation tile complete / everyone done with it).  No row clamps, as before: an NT stage may read rows beyond
+// the matrix but inside the parameter vector (what it fetches lands in output columns >= nvalid that are never
+// stored); the NN image is padded with zero rows.  The k order of every accumulator is what it was with the ring.
+struct BFrag { f32x4 b[2][4]; };   // one stage of this wave: [g][nb], element m = k offset
+constexpr int PRE = 2;             // stages of the NEXT product requested before the current one's epilogue
 struct WPipe {
-    WRegs x;       // loader waves: the stage this wave holds in flight
-    int s;         // stream index of the next product's first stage
-    bool primed;   // its stages 0 and 1 are in LDS and stages 2 .. AHEAD-1 are in flight
+    BFrag pre[PRE];   // stages 0 .. PRE-1 of the next product, in flight across the epilogue
+    int s;            // stages consumed so far by this chain (trace stamps)
+    bool primed;      // pre[] was requested for the product that comes next
 };
 __device__ __forceinline__ void wpipe_init(WPipe& p) { p.s = 0; p.primed = false; }
 
-// LOADER waves: one barrier per stage plus a final one, exactly as wcompute_run.
-__device__ __forceinline__ void wload_run(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
-                                          float* ring) {
-    const int T = wstages(cur), s0 = pipe.s;
-    const int U = T + (has_next ? AHEAD : 0);   // stages this call may load (cur's, then the first of next)
-    const int w = __builtin_amdgcn_readfirstlane(((int)threadIdx.x - NC) >> 6);
-    auto mine = [&](int u) { return ((s0 + u) & 3) == w; };
-    auto ld = [&](int u) {
-        if (u < T) wstage_load(pipe.x, cur, u); else wstage_load(pipe.x, next, u - T);
-    };
-    auto st = [&](int u) {
-        wstage_store(pipe.x, u < T ? cur.nt : next.nt, ring + ((s0 + u) % NSTG) * STAGE_F);
-    };
-    if (!pipe.primed) {   // stages 0 and 1 straight to LDS (two waves side by side), 2 .. AHEAD-1 in flight
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (u < U && mine(u)) { ld(u); st(u); }
-#pragma unroll
-        for (int u = 2; u < AHEAD; ++u)
-            if (u < U && mine(u)) ld(u);
-    }
-#pragma nounroll
-    for (int t = 0; t < T; ++t) {
-        // every compute wave is done with stage t-1: its slot takes stage t+2
-        bar();
-        if (t + AHEAD < U && mine(t + AHEAD)) ld(t + AHEAD);   // never the wave that stores now (AHEAD - 2 = 3)
-        if (t + 2 < U && mine(t + 2)) st(t + 2);
-    }
-    bar();
-}
-
-// COMPUTE waves.  After the barrier that opens stage t, stage t (written during stage t-2) and stage t+1
-// (written during stage t-1) are both in LDS: the fragments of stage t+1 are read while the MFMAs of stage
-// t run from the registers filled one stage earlier (one wave per SIMD computes: nobody else would hide the
-// LDS latency).
-struct WFrag { f32x4 a4[2], b4[2][4]; };
-__device__ __forceinline__ void wcompute_run(const WPipe& pipe, const WDesc cur, const float* A, int lda,
-                                             const float* ring, f32x4 (&acc)[4]) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-    const int T = wstages(cur), s0 = pipe.s;
-    auto rd = [&](int t, WFrag& f) {
-        const float* S = ring + ((s0 + t) % NSTG) * STAGE_F;
-        const int k0 = t << 5;
+__device__ __forceinline__ void bstage_load(BFrag& f, const WDesc& d, int t) {
+    const int lane = opaque_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
+    if (!d.nt) {
+        const unsigned off = (unsigned)((kq * H + 64 * wv + r) * 4);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            f.a4[g] = *(const f32x4*)(A + r * lda + k0 + 16 * g + 4 * kq);
+            glb_float* base = uniform_ptr(d.W + ((int64_t)(8 * t + 4 * g) * H + d.jg0) * 4);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int jl = 64 * wv + 16 * nb + r;
-                if (cur.nt) {
-                    f.b4[g][nb] = *(const f32x4*)(S + jl * 32 + (((4 * g + kq) ^ ((jl >> 1) & 7)) << 2));
-                } else {
-                    const float* p = S + (16 * g + 4 * kq) * WP + jl;
-                    f.b4[g][nb][0] = p[0]; f.b4[g][nb][1] = p[WP]; f.b4[g][nb][2] = p[2 * WP];
-                    f.b4[g][nb][3] = p[3 * WP];
-                }
-            }
+            for (int nb = 0; nb < 4; ++nb) f.b[g][nb] = load16(base + nb * 64, off);
         }
+    } else {
+        const unsigned off = (unsigned)((64 * wv + r) * H + 4 * kq);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                f.b[g][nb] = load16(uniform_ptr(d.W + (int64_t)(d.jg0 + 16 * nb) * H + 32 * t + 16 * g), off);
+    }
+}
+
+// Stage t's MFMAs run from register set t % NSET while the loads of stages t+1 .. t+NSET-1 are in flight (the loop
+// is unrolled by NSET so that no set is indexed at run time) and the activation fragment of stage t+1 is read from
+// LDS.  (Six sets were measured: the same 0.64 us per stage and longer epilogues — more registers to park.)
+struct AFrag { f32x4 a4[2]; };
+#ifndef SAMX_WIDE_NSET
+#define SAMX_WIDE_NSET 4
+#endif
+constexpr int NSET = SAMX_WIDE_NSET;   // even (the activation fragments alternate between two sets)
+static_assert(NSET >= 4 && NSET % 2 == 0, "NSET");
+__device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
+                                             const float* A, int lda, f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const int T = wstages(cur);
+    auto rda = [&](int t, AFrag& f) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) f.a4[g] = *(const f32x4*)(A + r * lda + (t << 5) + 16 * g + 4 * kq);
     };
     // consecutive MFMAs go to different accumulators (a dependent 16x16x4 pair costs 40 cycles, not 32);
     // blocks beyond nvalid compute finite values that are never stored
-    auto mm = [&](const WFrag& f) {
+    auto mm = [&](const AFrag& a, const BFrag& f) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(f.a4[g][m], f.b4[g][nb][m], acc[nb]);
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(a.a4[g][m], f.b[g][nb][m], acc[nb]);
     };
-    WFrag f0, f1;
-    bar();
-    WTRACE_STAGE(s0);
-    rd(0, f0);
-    if (1 < T) rd(1, f1);
-    mm(f0);
+    BFrag f[NSET];
+    if (pipe.primed) {
+        f[0] = pipe.pre[0];
+        f[1] = pipe.pre[1];
+    } else {
+        bstage_load(f[0], cur, 0);
+        if (1 < T) bstage_load(f[1], cur, 1);
+    }
+#pragma unroll
+    for (int u = 2; u < NSET - 1; ++u)
+        if (u < T) bstage_load(f[u], cur, u);
+    bar();   // the activation tile is complete
+    WTRACE_STAGE(pipe.s);
+    AFrag a[2];
+    rda(0, a[0]);
 #pragma nounroll
-    for (int t = 1; t < T; t += 2) {
-        bar();
-        WTRACE_STAGE(s0 + t);
-        if (t + 1 < T) rd(t + 1, f0);
-        mm(f1);
-        if (t + 1 < T) {
-            bar();
-            WTRACE_STAGE(s0 + t + 1);
-            if (t + 2 < T) rd(t + 2, f1);
-            mm(f0);
+    for (int t = 0; t < T; t += NSET) {
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            if (t + i < T) {
+                if (t + i + NSET - 1 < T) bstage_load(f[(i + NSET - 1) % NSET], cur, t + i + NSET - 1);
+                if (t + i + 1 < T) rda(t + i + 1, a[(i + 1) & 1]);
+                if (t + i > 0) WTRACE_STAGE(pipe.s + t + i);
+                mm(a[i & 1], f[i]);
+            }
         }
     }
-    bar();
+    if (has_next) {   // the next product's first stages fly during this product's epilogue
+        bstage_load(pipe.pre[0], next, 0);
+        if (1 < wstages(next)) bstage_load(pipe.pre[1], next, 1);
+    }
+    bar();   // every wave is done with the activation tile
 }
 
-// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for compute wave w's four 16-column blocks; A in LDS with
-// pitch lda (a multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).  Called by ALL waves.
-// Ends with a barrier: afterwards every wave is done with A (the ring slots of `next` stay live).
+// acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for wave w's four 16-column blocks; A in LDS with pitch lda (a
+// multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).  Called by ALL waves.
+// Ends with a barrier: afterwards every wave is done with A.
 template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc next, bool has_next, const float* A,
                                       int lda, float* ring, f32x4 (&acc)[4]) {
-    if (wstages(cur) < AHEAD || wstages(next) < AHEAD) has_next = false;   // short products do not chain
-    if constexpr (CW) wcompute_run(pipe, cur, A, lda, ring, acc);
-    else wload_run(pipe, cur, next, has_next, ring);
+    (void)ring;
+    static_assert(CW, "every wave computes (round 2's loader waves are gone)");
+    wcompute_run(pipe, cur, next, has_next, A, lda, acc);
     pipe.s += wstages(cur);
     pipe.primed = has_next;
 }
@@ -396,11 +353,11 @@ __device__ __forceinline__ float* free_slot(float* ring, const WPipe& pipe) {
 }
 // Two halves (every thread of the workgroup, all waves): the loads go out before the product in front,
 // the LDS writes and the barrier come after it.
-struct HeadStage { f32x4 q[4]; };   // 64 * out <= 2048 chunks of 16 bytes over 512 threads
+struct HeadStage { f32x4 q[2048 / NT]; };   // 64 * out <= 2048 chunks of 16 bytes over the workgroup's threads
 __device__ __forceinline__ void stage_head_issue(HeadStage& hs, const float* __restrict__ W3, int out) {
     const int n4 = 64 * out;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2048 / NT; ++i) {
         const int t = min((int)threadIdx.x + NT * i, n4 - 1);
         hs.q[i] = *(const f32x4u*)(W3 + 4 * t);
     }
@@ -408,10 +365,14 @@ __device__ __forceinline__ void stage_head_issue(HeadStage& hs, const float* __r
 __device__ __forceinline__ void stage_head_commit(const HeadStage& hs, int out, float* slot) {
     const int n4 = 64 * out;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2048 / NT; ++i) {
         const int t = threadIdx.x + NT * i;
         if (t < n4) *(f32x4*)(slot + 4 * t) = hs.q[i];
     }
+    // the backward through the head reads k up to 4 ceil(out / 4) - 1 of every row: behind the LAST row that is up to
+    // 3 floats past the image, times a zero of the padded cotangent — which must not meet a NaN pattern left in LDS
+    // (with the weight ring of round 2 whatever lay there was a finite weight)
+    if (threadIdx.x < 4) slot[256 * out + threadIdx.x] = 0.f;
     bar();
 }
 
@@ -834,8 +795,8 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
     const int64_t pr = cw ? ring_row(idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
-    const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
+    const WDesc ta1 = w_nn(a.targ_actor.W1p, ob), ta2 = w_nn(a.targ_actor.W2p, H);
+    const WDesc tc1 = w_nn(a.targ_critic.W1p, in_c), tc2 = w_nn(a.targ_critic.W2p, H);
     if (cw && tid < R) {
         if (pass) {
             L.rw[tid] = a.n_rews[row0 + tid]; L.dn[tid] = a.n_dones[row0 + tid]; L.tl[tid] = a.n_len[row0 + tid];
@@ -879,9 +840,9 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc ta1 = w_nn(a.targ_actor.W1, ob), ta2 = w_nn(a.targ_actor.W2, H);
-    const WDesc tc1 = w_nn(a.targ_critic.W1, in_c), tc2 = w_nn(a.targ_critic.W2, H);
-    const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    const WDesc ta1 = w_nn(a.targ_actor.W1p, ob), ta2 = w_nn(a.targ_actor.W2p, H);
+    const WDesc tc1 = w_nn(a.targ_critic.W1p, in_c), tc2 = w_nn(a.targ_critic.W2p, H);
+    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_nt(a.critic.W2, H, 0, H);
     const bool ext = a.ext_tq != nullptr;   // the targets were computed ahead (launch_targets)
     if (cw && tid < R) {
         L.iw[tid] = a.iws ? a.iws[row0 + tid] : 1.f;
@@ -1031,8 +992,8 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc a1 = w_nn(a.actor.W1, ob), a2 = w_nn(a.actor.W2, H), a3 = w_nt(a.actor.W2, H, 0, H);
-    const WDesc c1 = w_nn(a.critic.W1, in_c), c2 = w_nn(a.critic.W2, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    const WDesc a1 = w_nn(a.actor.W1p, ob), a2 = w_nn(a.actor.W2p, H), a3 = w_nt(a.actor.W2, H, 0, H);
+    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_nt(a.critic.W2, H, 0, H);
     const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
     if (cw) WTRACE(wg, 1, 0);
     if (cw) {
@@ -1180,7 +1141,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int k32 = ((in + 31) / 32) * 32;
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc d1 = w_nn(n.W1, in), d2 = w_nn(n.W2, H), d3 = w_nt(n.W2, H, 0, H);
+    const WDesc d1 = w_nn(n.W1p, in), d2 = w_nn(n.W2p, H), d3 = w_nt(n.W2, H, 0, H);
     const int tsec = sect == 2 ? 0 : (sect == 0 ? 2 : 4);
     (void)tsec;   // only the SAMX_TRACE build reads it
     if (cw) WTRACE(wg % tiles_b, 2, tsec);
@@ -1335,7 +1296,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         // DZ* = P_z*), hT = [3B, 4B) the tangent stream (X = V, A1 = ndot1, DZ* = T_z*).
         const int64_t hP = hrow0, hT = hrow0 + a.B;
         const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
-        const WDesc t1 = w_nn(n.W1, in), t2 = w_nn(n.W2, H);
+        const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
         const unsigned m1 = hidden_fwd_ln<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, n.be1, n.ga1, L.ring, L.T1, a.XH1,
                                               a.A1, hP, rs1);
         const unsigned m2 = hidden_fwd_ln<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, n.be2, n.ga2, L.ring, L.T2, a.XH2,
@@ -1478,7 +1439,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     // The scalar k = 10 * 2 (N - 1) / N needs every tile's sums: it is applied to these rows' share of the
     // weight gradients after this launch, not here.
     const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
-    const WDesc t1 = w_nn(n.W1, in), t2 = w_nn(n.W2, H);
+    const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
     hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
     const unsigned m2 = hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
     if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
@@ -1618,21 +1579,20 @@ template <bool LN>
 __global__ __launch_bounds__(NT, 1) void roles_kernel(RoleArgs s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
-    const bool cw = is_compute();   // scalar: waves 0-3 compute, waves 4-7 load
     if (b >= 8 * s.per) { role_wd(s.a, b - 8 * s.per); return; }
     const int g = b & 7, j = b >> 3;
     if (g < s.g_tc) {
         const int wg = j * s.g_tc + g;
         if (wg >= s.n_tc) return;
-        if (cw) role_tc<true, LN>(s.a, wg, lds); else role_tc<false, LN>(s.a, wg, lds);
+        role_tc<true, LN>(s.a, wg, lds);
     } else if (g < s.g_tc + s.g_a) {
         const int wg = j * s.g_a + (g - s.g_tc);
         if (wg >= s.n_a) return;
-        if (cw) role_a<true, LN>(s.a, wg, lds); else role_a<false, LN>(s.a, wg, lds);
+        role_a<true, LN>(s.a, wg, lds);
     } else {
         const int wg = j * (8 - s.g_tc - s.g_a) + (g - s.g_tc - s.g_a);   // interpolate tiles come first
         if (wg >= s.n_d) return;
-        if (cw) role_d<true, LN>(s.d, wg, lds); else role_d<false, LN>(s.d, wg, lds);
+        role_d<true, LN>(s.d, wg, lds);
     }
 }
 
@@ -1640,7 +1600,35 @@ template <bool LN>
 __global__ __launch_bounds__(NT, 1) void targets_kernel(AgentArgs a, int tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pass = blockIdx.x / tiles, wg = blockIdx.x % tiles;
-    if (is_compute()) role_t<true, LN>(a, wg, lds, pass); else role_t<false, LN>(a, wg, lds, pass);
+    role_t<true, LN>(a, wg, lds, pass);
+}
+
+// k-interleaved image of a [K][256] matrix (see WDesc); rows beyond K are zero.
+constexpr int kPackMax = 10;
+struct PackArgs {
+    const float* W[kPackMax];
+    float* dst[kPackMax];
+    int K[kPackMax];
+    int first[kPackMax + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    // thread = (4-row group kg, 4 columns j0 .. j0+3): four 16-byte loads (one per row), a 4 x 4 transposition in
+    // registers, 64 contiguous bytes out; a block covers 4 row groups
+    int p = 0;
+    const int b = blockIdx.x;
+    while (p + 1 < a.n && b >= a.first[p + 1]) ++p;
+    const int kg = 4 * (b - a.first[p]) + (threadIdx.x >> 6), j0 = 4 * (threadIdx.x & 63), K = a.K[p];
+    const float* W = a.W[p];
+    f32x4 r[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = 4 * kg + m;
+        r[m] = k < K ? *(const f32x4u*)(W + (int64_t)k * H + j0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float* o = a.dst[p] + ((int64_t)kg * H + j0) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(f32x4*)(o + 4 * c) = f32x4{r[0][c], r[1][c], r[2][c], r[3][c]};
 }
 
 bool net_ok(const samx_mlp* d) { return d && d->h1 == kH && d->h2 == kH; }
@@ -1703,6 +1691,24 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
         if (int rc = grant.ensure((const void*)roles_kernel<false>, lds)) return rc;
         roles_kernel<false><<<(unsigned)(8 * s.per + n_wd), NT, lds, st>>>(s);
     }
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_pack(const float* const* W, float* const* dst, const int* K, int n, hipStream_t st) {
+    SAMX_REQUIRE(n >= 0 && n <= kPackMax, "wide::launch_pack: 0..%d matrices", kPackMax);
+    if (n == 0) return SAMX_OK;
+    PackArgs a;
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        SAMX_REQUIRE(W[i] && dst[i] && K[i] > 0, "wide::launch_pack: matrix %d", i);
+        a.W[i] = W[i]; a.dst[i] = dst[i]; a.K[i] = K[i];
+        a.first[i] = blocks;
+        blocks += packed_rows(K[i]) / 16;   // one 256-thread block per 16 rows
+    }
+    a.first[n] = blocks;
+    pack_kernel<<<blocks, 256, 0, st>>>(a);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

@@ -34,6 +34,9 @@ bool wide_step_supported(const samx_learner* L, int64_t B);
 // use_ext: the roles read out.targ_q / tqn instead of computing the targets.
 struct WideExt {
     bool targets_only = false, use_ext = false;
+    // packed: the k-interleaved weight images of every network this call's roles need were written by the
+    // targets_only launch of the SAME samx_step_grads_part call (nothing but the critic heads changed since)
+    bool packed = false;
     const int64_t* n_idx = nullptr;
     const float *n_rews = nullptr, *n_dones = nullptr, *n_len = nullptr;
     float* tqn = nullptr;

@@ -1559,6 +1559,9 @@ struct WideRed {
     // w3_sum: [3][sw] critic, D policy+expert, D interpolates (sw = slot width: 257, + the four LayerNorm vectors)
     float *w3c, *w3d, *w3_sum, *P[9], *w3a_tmp;
     float *lna, *lna_sum;   // LayerNorm: the actor's per-tile [beta1 | gamma1 | beta2 | gamma2] slots and their sum
+    // k-interleaved images of W1 / W2 (fused_wide.h: Net::W1p / W2p) of actor, critic, reward net, target actor,
+    // target critic — scratch, rewritten from the parameter vectors at the head of every launch sequence
+    float* pk[5][2];
     int ns[9];
     int64_t cnt[9];
     int sw;
@@ -1584,6 +1587,11 @@ WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B, bool ln) {
         w.P[p] = ar.take<float>((size_t)ns[p] * cnt[p]);
     }
     w.w3a_tmp = ar.take<float>((H + 1) * ac);
+    const int kin[5] = {ob, (int)in, (int)in, ob, (int)in};
+    for (int n = 0; n < 5; ++n) {
+        w.pk[n][0] = ar.take<float>((size_t)wide::packed_rows(kin[n]) * H);
+        w.pk[n][1] = ar.take<float>((size_t)H * H);
+    }
     return w;
 }
 }  // namespace
@@ -1639,6 +1647,19 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
     f.nseg = 0; f.gp_seg = -1; f.gp_part = nullptr; f.gp_tiles = tiles; f.ob = ob; f.ac = ac; f.B = B;
     f.gp_coeff = gp_coeff;
     f.rms_sums = nullptr; f.rms_addvec = nullptr; f.rms_mean = f.rms_std = nullptr;
+    const float* pk_src[5][2] = {};
+    auto pack = [&](int mask) -> int {   // bit n: network n of [actor, critic, reward, target actor, target critic]
+        const float* W[10];
+        float* dst[10];
+        int K[10], n = 0;
+        const int kin[5] = {ob, in, in, ob, in};
+        for (int q = 0; q < 5; ++q)
+            if (mask & (1 << q)) {
+                W[n] = pk_src[q][0]; dst[n] = wr.pk[q][0]; K[n++] = kin[q];
+                W[n] = pk_src[q][1]; dst[n] = wr.pk[q][1]; K[n++] = H;
+            }
+        return wide::launch_pack(W, dst, K, n, st);
+    };
     wide::AgentArgs a;
     a.wd_part = nullptr; a.wd_blocks = 0;
     wide::DiscArgs d;
@@ -1660,6 +1681,10 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         s.step_dev = (part & 4) ? nullptr : L->steps + k;   // part bit 2 here: no counter tick
         return s;
     };
+    if (do_d) {   // (known before the target launch, which writes every image the call will need)
+        const Net nd0 = split(dd, L->params + Pa + Pc);
+        pk_src[2][0] = nd0.W1; pk_src[2][1] = nd0.W2;
+    }
     if (do_a) {
         Arena a1(ws_tc, nets_bytes), a2(ws_a, nets_bytes);
         w1 = carve_agent(a1, da, dc, nullptr, B);
@@ -1672,6 +1697,12 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.iws = b->iws; a.td_len = b->td_len; a.mean = L->mu_mean; a.stdv = L->mu_std;
         a.idx = b->a_idx; a.ring_start = b->ring_start; a.ring_len = b->ring_len;
         a.actor = net(na); a.critic = net(nc); a.targ_actor = net(ta); a.targ_critic = net(tc);
+        a.actor.W1p = wr.pk[0][0]; a.actor.W2p = wr.pk[0][1];
+        a.critic.W1p = wr.pk[1][0]; a.critic.W2p = wr.pk[1][1];
+        a.targ_actor.W1p = wr.pk[3][0]; a.targ_actor.W2p = wr.pk[3][1];
+        a.targ_critic.W1p = wr.pk[4][0]; a.targ_critic.W2p = wr.pk[4][1];
+        pk_src[0][0] = na.W1; pk_src[0][1] = na.W2; pk_src[1][0] = nc.W1; pk_src[1][1] = nc.W2;
+        pk_src[3][0] = ta.W1; pk_src[3][1] = ta.W2; pk_src[4][0] = tc.W1; pk_src[4][1] = tc.W2;
         a.ob = ob; a.ac = ac; a.B = B;
         a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
         a.targ_q = o->targ_q; a.td_out = o->td;
@@ -1692,7 +1723,10 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         if (ext) {
             a.n_idx = ext->n_idx; a.n_rews = ext->n_rews; a.n_dones = ext->n_dones; a.n_len = ext->n_len;
             a.targ_qn = ext->tqn;
-            if (ext->targets_only) return wide::launch_targets(&a, st);
+            if (ext->targets_only) {
+                TRY(pack(0x1B | (do_d ? 0x04 : 0)));   // the target networks, and what the role launch will need
+                return wide::launch_targets(&a, st);
+            }
             if (ext->use_ext) {
                 a.ext_tq = o->targ_q; a.ext_tqn = ext->tqn;
                 if (ext->tqn) a.row_hubn = w1.row2;
@@ -1743,6 +1777,8 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         d.p_idx = b->p_idx; d.e_start = b->e_start; d.ring_start = b->ring_start; d.ring_len = b->ring_len;
         d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
         d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
+        d.net.W1p = wr.pk[2][0]; d.net.W2p = wr.pk[2][1];
+        pk_src[2][0] = nd.W1; pk_src[2][1] = nd.W2;
         d.X = w.X; d.A1 = w.h.N1; d.A2 = w.h.N2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
         d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part; d.w3_part = wr.w3d;
         if (ln) { d.XH1 = w.h.XH1; d.XH2 = w.h.XH2; d.TN1 = w.TA1; d.PA1 = w.TA2; }
@@ -1775,6 +1811,10 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         f.gp_seg = f.nseg - 1; f.gp_part = w.gp_part;
     }
     if (run) {
+        // the forward products read k-interleaved images of W1 / W2: written here, from the parameter vectors as
+        // they are NOW (scratch of this call; with stored targets the target networks' images are not needed)
+        if (!(ext && ext->packed))
+            TRY(pack((do_a ? (0x03 | ((ext && ext->use_ext) ? 0 : 0x18)) : 0) | (do_d ? 0x04 : 0)));
         // every role in ONE launch (the decayed kernels' sums of squares ride along), then ONE for all
         // weight-gradient products and the head-gradient slot sums
         if (do_a && L->wd_scale > 0.f) { a.wd_part = w1.wd_part; a.wd_blocks = kWdBlocks; }

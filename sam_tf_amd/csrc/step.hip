@@ -928,6 +928,7 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
                     rc = roles(&we);
                     if (rc != SAMX_OK) return rc;
                     we.targets_only = false;
+                    we.packed = !t_only;   // (the weight images written there serve the role launch below)
                 }
                 if (L->ret_mean && L->enable_popart) {
                     // sam_agent.py:662-672: batch sums, commit and rescale in ONE launch; N processes (bits 4/5):
