@@ -36,8 +36,10 @@ namespace samx {
 namespace wide {
 namespace {
 
-constexpr int NT = 256;                // threads per workgroup: four waves, one per SIMD, all of them compute
-constexpr int NC = 256;                // (round 2: 512 threads, waves 4-7 streamed the weights through an LDS ring)
+constexpr int NT = 512;                // threads per workgroup: eight waves, two per SIMD; every wave owns 32 output
+                                       // columns of every product (round 2: waves 4-7 streamed the weights through LDS)
+constexpr int NC = 256;                // "row threads" (waves 0-3): everything that is not a product or its epilogue
+constexpr int NB = 2;                  // 16-column accumulator blocks per wave
 constexpr int R = kRows;
 constexpr int H = kH;
 constexpr int LDT = 260;               // pitch of a [16][256] tile
@@ -81,6 +83,7 @@ __device__ __forceinline__ void bar() {
 }
 // wave-uniform (scalar) role of this wave
 __device__ __forceinline__ bool is_compute() { return __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NC; }
+__device__ __forceinline__ bool is_row() { return is_compute(); }   // wave-uniform: one of the 256 row threads
 __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
@@ -148,7 +151,7 @@ __device__ __forceinline__ int opaque_lane() {
 // (activation tile complete / everyone done with it).  No row clamps, as before: an NT stage may read rows beyond
 // the matrix but inside the parameter vector (what it fetches lands in output columns >= nvalid that are never
 // stored); the NN image is padded with zero rows.  The k order of every accumulator is what it was with the ring.
-struct BFrag { f32x4 b[2][4]; };   // one stage of this wave: [g][nb], element m = k offset
+struct BFrag { f32x4 b[2][NB]; };   // one stage of this wave: [g][nb], element m = k offset
 constexpr int PRE = 2;             // stages of the NEXT product requested before the current one's epilogue
 struct WPipe {
     BFrag pre[PRE];   // stages 0 .. PRE-1 of the next product, in flight across the epilogue
@@ -161,19 +164,19 @@ __device__ __forceinline__ void bstage_load(BFrag& f, const WDesc& d, int t) {
     const int lane = opaque_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
     if (!d.nt) {
-        const unsigned off = (unsigned)((kq * H + 64 * wv + r) * 4);
+        const unsigned off = (unsigned)((kq * H + 16 * NB * wv + r) * 4);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             glb_float* base = uniform_ptr(d.W + ((int64_t)(8 * t + 4 * g) * H + d.jg0) * 4);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) f.b[g][nb] = load16(base + nb * 64, off);
+            for (int nb = 0; nb < NB; ++nb) f.b[g][nb] = load16(base + nb * 64, off);
         }
     } else {
-        const unsigned off = (unsigned)((64 * wv + r) * H + 4 * kq);
+        const unsigned off = (unsigned)((16 * NB * wv + r) * H + 4 * kq);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 f.b[g][nb] = load16(uniform_ptr(d.W + (int64_t)(d.jg0 + 16 * nb) * H + 32 * t + 16 * g), off);
     }
 }
@@ -188,7 +191,7 @@ struct AFrag { f32x4 a4[2]; };
 constexpr int NSET = SAMX_WIDE_NSET;   // even (the activation fragments alternate between two sets)
 static_assert(NSET >= 4 && NSET % 2 == 0, "NSET");
 __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
-                                             const float* A, int lda, f32x4 (&acc)[4]) {
+                                             const float* A, int lda, f32x4 (&acc)[NB]) {
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const int T = wstages(cur);
     auto rda = [&](int t, AFrag& f) {
@@ -203,7 +206,7 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(a.a4[g][m], f.b[g][nb][m], acc[nb]);
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma4(a.a4[g][m], f.b[g][nb][m], acc[nb]);
     };
     BFrag f[NSET];
     if (pipe.primed) {
@@ -244,7 +247,7 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
 // Ends with a barrier: afterwards every wave is done with A.
 template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc next, bool has_next, const float* A,
-                                      int lda, float* ring, f32x4 (&acc)[4]) {
+                                      int lda, float* ring, f32x4 (&acc)[NB]) {
     (void)ring;
     static_assert(CW, "every wave computes (round 2's loader waves are gone)");
     wcompute_run(pipe, cur, next, has_next, A, lda, acc);
@@ -253,23 +256,24 @@ __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc 
 }
 template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const float* A, int lda, float* ring,
-                                      f32x4 (&acc)[4]) {   // last product of a chain
+                                      f32x4 (&acc)[NB]) {   // last product of a chain
     wprod<CW>(pipe, cur, cur, false, A, lda, ring, acc);
 }
 
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NB]) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // f(row, col, value, bit index) over this (compute) wave's accumulator elements
 template <typename F>
-__device__ __forceinline__ void for_acc(const f32x4 (&acc)[4], F f) {
+__device__ __forceinline__ void for_acc(const f32x4 (&acc)[NB], F f) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f((lane >> 4) * 4 + j, 64 * wv + 16 * nb + (lane & 15), acc[nb][j], nb * 4 + j);
+        for (int j = 0; j < 4; ++j)
+            f((lane >> 4) * 4 + j, 16 * NB * wv + 16 * nb + (lane & 15), acc[nb][j], nb * 4 + j);
 }
 
 // (ldw is H for every product: the loaders use it as a compile-time constant)
@@ -284,12 +288,11 @@ template <bool CW>
 __device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
                                                const float* A, int lda, const float* __restrict__ b, float* ring,
                                                float* T, float* __restrict__ hbm, int64_t row0) {
-    f32x4 acc[4];
+    f32x4 acc[NB];
     zero_acc(acc);
     wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
     unsigned bits = 0;
-    if constexpr (CW)
-        for_acc(acc, [&](int r, int c, float v, int bi) {
+    for_acc(acc, [&](int r, int c, float v, int bi) {
             const float a = lrelu(v + b[c]);
             T[r * LDT + c] = a;
             if (hbm) hbm[(row0 + r) * H + c] = a;
@@ -711,13 +714,13 @@ __device__ __forceinline__ unsigned hidden_fwd_ln(WPipe& pipe, const WDesc cur, 
                                                   const float* __restrict__ be, const float* __restrict__ ga,
                                                   float* ring, float* T, float* __restrict__ xh_hbm,
                                                   float* __restrict__ n_hbm, int64_t grow0, float* rs_strip) {
-    f32x4 acc[4];
+    f32x4 acc[NB];
     zero_acc(acc);
     wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
-    if constexpr (CW) for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = lrelu(v + b[c]); });
+    for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = lrelu(v + b[c]); });
     bar();
     unsigned bits = 0;
-    if constexpr (CW) bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
+    if (is_row()) bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
     bar();
     return bits;
 }
@@ -739,10 +742,10 @@ __device__ __forceinline__ unsigned hfwd(WPipe& pipe, const WDesc cur, const WDe
 template <bool CW>
 __device__ __forceinline__ void prod_to_tile(WPipe& pipe, const WDesc cur, const WDesc next, const bool has_next,
                                              const float* A, int lda, float* ring, float* T) {
-    f32x4 acc[4];
+    f32x4 acc[NB];
     zero_acc(acc);
     wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
-    if constexpr (CW) for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = v; });
+    for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = v; });
     bar();
 }
 
@@ -786,7 +789,7 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
 template <bool CW, bool LN>
 __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) {
     const int tid = threadIdx.x;
-    constexpr bool cw = CW;
+    const bool cw = is_row();   // the 256 row threads; products and their epilogues run on all eight waves
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
@@ -832,7 +835,7 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
 template <bool CW, bool LN>
 __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
-    constexpr bool cw = CW;
+    const bool cw = is_row();   // the 256 row threads; products and their epilogues run on all eight waves
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
@@ -966,11 +969,11 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     bar();
     WTRACE(wg, 0, 11);
     {
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, c3, L.T2, LDT, L.ring, acc);
         WTRACE(wg, 0, 12);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int) {
                 a.DZ1c[(row0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
             });
@@ -984,7 +987,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
 template <bool CW, bool LN>
 __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr bool cw = CW;
+    const bool cw = is_row();   // the 256 row threads; products and their epilogues run on all eight waves
     const int64_t row0 = (int64_t)wg * R;
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
@@ -1042,15 +1045,15 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
     bar();
     {   // dZ1c = (dZ2c W2c^T) .* lrelu'(A1c), in place over A1c (every wave is past the product's last barrier)
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, c3, c4, true, L.T2, LDT, L.ring, acc);
-        if (cw) for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
+        for_acc(acc, [&](int r, int c, float v, int) { L.T1[r * LDT + c] = v * dlrelu(L.T1[r * LDT + c]); });
     }
     bar();
     }
     {   // dQ/da = dZ1c W1c[ob:ob+ac, :]^T, through clip (identity inside the range) and tanh
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         stage_head_issue(hs, a.actor.W3, ac);   // for the backward through the action head below
         wprod<CW>(pipe, c4, a3, true, L.T1, LDT, L.ring, acc);
@@ -1076,20 +1079,19 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         float* slot = free_slot(L.ring, pipe);
         stage_head_commit(hs, ac, slot);
         const int r = lane & 15, kq = lane >> 4;
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         const int ks = (ac + 3) / 4;
-        if (cw)
-            for (int kk = 0; kk < ks; ++kk) {
-                const float av = L.PRE[r * PP + 4 * kk + kq];
+        for (int kk = 0; kk < ks; ++kk) {   // (every wave: its 32 columns)
+            const float av = L.PRE[r * PP + 4 * kk + kq];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    acc[nb] = mfma4(av, slot[(64 * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
-            }
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = mfma4(av, slot[(16 * NB * wv + 16 * nb + r) * ac + 4 * kk + kq], acc[nb]);
+        }
         bar();
         if constexpr (LN) {
             // the cotangent of the actor's n2 (raw), then back through LayerNorm 2, W2a^T, LayerNorm 1
-            if (cw) for_acc(acc, [&](int r_, int c, float v, int) { L.T2[r_ * LDT + c] = v; });
+            for_acc(acc, [&](int r_, int c, float v, int) { L.T2[r_ * LDT + c] = v; });
             bar();
             float* lslot = a.lna_part + (int64_t)wg * kLnSlot;
             if (cw)
@@ -1106,7 +1108,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
             if (cw) ln_cols_commit(scratch, lslot);
             return;
         }
-        if (cw)
+        
             for_acc(acc, [&](int r_, int c, float v, int bi) {
                 const float z = v * ((m2a >> bi) & 1u ? 1.f : 0.2f);
                 L.T2[r_ * LDT + c] = z;
@@ -1115,10 +1117,10 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
     bar();
     {   // dZ1a = (dZ2a W2a^T) .* lrelu'(A1a)
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, a3, L.T2, LDT, L.ring, acc);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int bi) {
                 a.DZ1a[(row0 + r) * H + c] = v * ((m1a >> bi) & 1u ? 1.f : 0.2f);
             });
@@ -1129,7 +1131,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
 template <bool CW, bool LN>
 __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tid = threadIdx.x;
-    constexpr bool cw = CW;
+    const bool cw = is_row();   // the 256 row threads; products and their epilogues run on all eight waves
     const int tiles_b = (int)(a.B / R);
     // interpolate tiles first (the longest chain), then policy, then expert
     const int sect = wg < tiles_b ? 2 : (wg < 2 * tiles_b ? 0 : 1);
@@ -1312,13 +1314,13 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
                                       nullptr);
         bar();
         {   // g = T_z1 W1^T, 256 input columns at a time, over X (x is in HBM by now)
-            auto put = [&](const f32x4 (&acc)[4], int j0) {
-                if (cw)
+            auto put = [&](const f32x4 (&acc)[NB], int j0) {
+                
                     for_acc(acc, [&](int r, int c, float v, int) {
                         if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
                     });
             };
-            f32x4 acc[4];
+            f32x4 acc[NB];
             zero_acc(acc);
             if (in > H) {
                 wprod<CW>(pipe, g0, g1, true, L.T1, LDT, L.ring, acc);
@@ -1425,10 +1427,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
         }
         bar();
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, d3, L.T2, LDT, L.ring, acc);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int) {
                 a.DZ1[(hrow0 + r) * H + c] = v * dlrelu(L.T1[r * LDT + c]);
             });
@@ -1447,10 +1449,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     if (cw) head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);                                            // gz2
     bar();
     {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, d3, g0, true, L.T2, LDT, L.ring, acc);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int) {
                 const float z = v * dlrelu(L.T1[r * LDT + c]);
                 L.T2[r * LDT + c] = z;
@@ -1459,13 +1461,13 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     }
     bar();
     {   // g = gz1 W1^T, 256 input columns at a time, over X (dead by now)
-        auto put = [&](const f32x4 (&acc)[4], int j0) {
-            if (cw)
+        auto put = [&](const f32x4 (&acc)[NB], int j0) {
+            
                 for_acc(acc, [&](int r, int c, float v, int) {
                     if (j0 + c < k32) L.X[r * L.px + j0 + c] = j0 + c < in ? v : 0.f;
                 });
         };
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         if (in > H) {
             wprod<CW>(pipe, g0, g1, true, L.T2, LDT, L.ring, acc);
@@ -1507,10 +1509,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     }
     bar();
     {   // a1dot = (V W1) .* m1, in place over A1
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, t1, t2, true, L.X, L.px, L.ring, acc);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int) {
                 const float z = v * dlrelu(L.T1[r * LDT + c]);
                 L.T1[r * LDT + c] = z;
@@ -1519,25 +1521,24 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     }
     bar();
     {   // a2dot = (a1dot W2) .* m2
-        f32x4 acc[4];
+        f32x4 acc[NB];
         zero_acc(acc);
         wprod<CW>(pipe, t2, L.T1, LDT, L.ring, acc);
-        if (cw)
+        
             for_acc(acc, [&](int r, int c, float v, int bi) {
                 a.A2[(hrow0 + r) * H + c] = v * ((m2 >> bi) & 1u ? 1.f : 0.2f);
             });
         // head gradient of these rows: sum_r a2dot[r][c] (without k), rows in a fixed order
         float* slot = a.w3_part + (int64_t)wg * (H + 1);
         const int lane = tid & 63, wv = tid >> 6;
-        if (cw)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {   // (every wave: its 32 columns)
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) sm += acc[nb][j] * ((m2 >> (nb * 4 + j)) & 1u ? 1.f : 0.2f);
             sm += __shfl_xor(sm, 16, 64);
             sm += __shfl_xor(sm, 32, 64);
-            if (lane < 16) slot[64 * wv + 16 * nb + lane] = sm;
+            if (lane < 16) slot[16 * NB * wv + 16 * nb + lane] = sm;
         }
         if (tid == 0) slot[H] = 0.f;
     }
