@@ -152,7 +152,14 @@ __device__ __forceinline__ int opaque_lane() {
 // the matrix but inside the parameter vector (what it fetches lands in output columns >= nvalid that are never
 // stored); the NN image is padded with zero rows.  The k order of every accumulator is what it was with the ring.
 struct BFrag { f32x4 b[2][NB]; };   // one stage of this wave: [g][nb], element m = k offset
-constexpr int PRE = 2;             // stages of the NEXT product requested before the current one's epilogue
+// Stages of the NEXT product requested before the current one's epilogue; the remaining NSET - 1 - PRE are
+// requested when the product starts.  Measured on one box, C4: PRE 2 -> 7.69 / 7.63 k steps/s, PRE 3 (everything a
+// product has in flight, so that no first-stage load queues behind the epilogue's stores) -> 7.60 / 7.57 k: the
+// extra 16 registers cost more than the shorter first stage gains.
+#ifndef SAMX_WIDE_PRE
+#define SAMX_WIDE_PRE 2
+#endif
+constexpr int PRE = SAMX_WIDE_PRE;
 struct WPipe {
     BFrag pre[PRE];   // stages 0 .. PRE-1 of the next product, in flight across the epilogue
     int s;            // stages consumed so far by this chain (trace stamps)
@@ -208,17 +215,19 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma4(a.a4[g][m], f.b[g][nb][m], acc[nb]);
     };
+    static_assert(PRE <= NSET - 1, "a product starts with NSET - 1 stages in flight");
     BFrag f[NSET];
     if (pipe.primed) {
-        f[0] = pipe.pre[0];
-        f[1] = pipe.pre[1];
-    } else {
-        bstage_load(f[0], cur, 0);
-        if (1 < T) bstage_load(f[1], cur, 1);
-    }
 #pragma unroll
-    for (int u = 2; u < NSET - 1; ++u)
-        if (u < T) bstage_load(f[u], cur, u);
+        for (int u = 0; u < PRE; ++u) f[u] = pipe.pre[u];
+#pragma unroll
+        for (int u = PRE; u < NSET - 1; ++u)
+            if (u < T) bstage_load(f[u], cur, u);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NSET - 1; ++u)
+            if (u < T) bstage_load(f[u], cur, u);
+    }
     bar();   // the activation tile is complete
     WTRACE_STAGE(pipe.s);
     AFrag a[2];
@@ -236,8 +245,10 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
         }
     }
     if (has_next) {   // the next product's first stages fly during this product's epilogue
-        bstage_load(pipe.pre[0], next, 0);
-        if (1 < wstages(next)) bstage_load(pipe.pre[1], next, 1);
+        const int Tn = wstages(next);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (u < Tn) bstage_load(pipe.pre[u], next, u);
     }
     bar();   // every wave is done with the activation tile
 }
