@@ -151,6 +151,10 @@ __device__ __forceinline__ int opaque_lane() {
 // (activation tile complete / everyone done with it).  No row clamps, as before: an NT stage may read rows beyond
 // the matrix but inside the parameter vector (what it fetches lands in output columns >= nvalid that are never
 // stored); the NN image is padded with zero rows.  The k order of every accumulator is what it was with the ring.
+// (Measured and dropped: the forward products straight from the row-major matrices, no packed image — number
+// the wave's columns 32 w + 2 r + nb and a lane's two blocks are one 8-byte load per k.  Bit-identical, no pack
+// launch, and slower: C4 7.68 -> 7.55 k steps/s, launcher options 4.72 -> 4.50 k.  Eight 8-byte loads per wave and
+// stage instead of four 16-byte ones: the address path takes 16 cycles per wave-wide load whatever its width.)
 struct BFrag { f32x4 b[2][NB]; };   // one stage of this wave: [g][nb], element m = k offset
 // Stages of the NEXT product requested before the current one's epilogue; the remaining NSET - 1 - PRE are
 // requested when the product starts.  Measured on one box, C4: PRE 2 -> 7.69 / 7.63 k steps/s, PRE 3 (everything a
@@ -293,6 +297,14 @@ __device__ __forceinline__ WDesc w_nt(const float* W, int N, int jg0, int nvalid
     return WDesc{W, H, H, N, jg0, nvalid, true};
 }
 
+// this lane's bias values in the for_acc mapping (column 16 NB wv + 16 nb + (lane & 15) -> b[nb])
+struct BiasRegs { float b[NB]; };
+__device__ __forceinline__ void bias_issue(BiasRegs& bb, const float* __restrict__ b) {
+    const int c0 = 16 * NB * ((int)threadIdx.x >> 6) + ((int)threadIdx.x & 15);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bb.b[nb] = b[c0 + 16 * nb];
+}
+
 // hidden layer: out = lrelu(A W + b) into the LDS tile T and, if hbm, to hbm[(row0 + r)][256].
 // Called by all waves; returns this (compute) lane's 16 mask bits (value >= 0).
 template <bool CW>
@@ -301,10 +313,12 @@ __device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, con
                                                float* T, float* __restrict__ hbm, int64_t row0) {
     f32x4 acc[NB];
     zero_acc(acc);
+    BiasRegs bb;
+    bias_issue(bb, b);   // ahead of the product: behind its last barrier the load would be a bare L2 round trip
     wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
     unsigned bits = 0;
     for_acc(acc, [&](int r, int c, float v, int bi) {
-            const float a = lrelu(v + b[c]);
+            const float a = lrelu(v + bb.b[bi >> 2]);
             T[r * LDT + c] = a;
             if (hbm) hbm[(row0 + r) * H + c] = a;
             bits |= (a >= 0.f ? 1u : 0u) << bi;
@@ -349,11 +363,13 @@ __device__ __forceinline__ void head_grad_slot(const float* T, const float* dq, 
 }
 
 // T[r][c] = dq[r] * w3[c] * lrelu'(T[r][c]) in place, and to hbm
-__device__ __forceinline__ void head_bwd(float* T, const float* dq, const float* __restrict__ w3,
+// (w3c = w3[threadIdx.x], loaded ahead by the caller: thread t only meets column t)
+__device__ __forceinline__ void head_bwd(float* T, const float* dq, const float w3c,
                                          float* __restrict__ hbm, int64_t row0) {
+    static_assert(NC == H, "one column per row thread");
     for (int t = threadIdx.x; t < R * H; t += NC) {
         const int r = t >> 8, c = t & 255;
-        const float v = dq[r] * w3[c] * dlrelu(T[r * LDT + c]);
+        const float v = dq[r] * w3c * dlrelu(T[r * LDT + c]);
         T[r * LDT + c] = v;
         hbm[(row0 + r) * H + c] = v;
     }
@@ -727,8 +743,10 @@ __device__ __forceinline__ unsigned hidden_fwd_ln(WPipe& pipe, const WDesc cur, 
                                                   float* __restrict__ n_hbm, int64_t grow0, float* rs_strip) {
     f32x4 acc[NB];
     zero_acc(acc);
+    BiasRegs bb;
+    bias_issue(bb, b);
     wprod<CW>(pipe, cur, next, has_next, A, lda, ring, acc);
-    for_acc(acc, [&](int r, int c, float v, int) { T[r * LDT + c] = lrelu(v + b[c]); });
+    for_acc(acc, [&](int r, int c, float v, int bi) { T[r * LDT + c] = lrelu(v + bb.b[bi >> 2]); });
     bar();
     unsigned bits = 0;
     if (is_row()) bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
@@ -767,6 +785,7 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
                                            float* __restrict__ hbm, int64_t row0, float* slot,
                                            const HeadStage& hs) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const float b3v = n.b3[min(16 * wv + r, ac - 1)];   // (ahead of the barrier: its round trip hides behind the head)
     stage_head_commit(hs, ac, slot);
     if (CW && 16 * wv < ac) {
         const int jc = min(16 * wv + r, ac - 1);
@@ -780,11 +799,10 @@ __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, i
         const f32x4 acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         const int c = 16 * wv + (lane & 15);
         if (c < ac) {
-            const float b = n.b3[c];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = (lane >> 4) * 4 + j;
-                float v = high * tanhf(acc[j] + b);
+                float v = high * tanhf(acc[j] + b3v);
                 v = fminf(fmaxf(v, -high), high);
                 L.X[row * L.px + ob + c] = v;
                 if (hbm) hbm[(row0 + row) * (ob + ac) + ob + c] = v;
@@ -922,6 +940,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const unsigned m1 = hfwd<CW, LN>(pipe, c1, c2, true, L.X, L.px, a.critic, 1, L.ring, L.T1, a.A1c, a.XH1c, row0, rs1);
     WTRACE(wg, 0, 9);
     if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
+    const float w3c = a.critic.W3[tid & (H - 1)];   // for head_bwd, ahead of the product
     const unsigned m2 = hfwd<CW, LN>(pipe, c2, c3, true, L.T1, LDT, a.critic, 2, L.ring, L.T2, a.A2c, a.XH2c, row0, rs2);
     WTRACE(wg, 0, 10);
     if (cw) head1(L.T2, hd, L.s_);
@@ -972,10 +991,10 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         if (cw) ln_cols_commit(scratch, slot + (H + 1));
         return;
     }
-    (void)m1; (void)m2;
+    (void)m1; (void)m2; (void)w3c;
     if (cw) {
         head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
-        head_bwd(L.T2, L.dq, a.critic.W3, a.DZ2c, row0);
+        head_bwd(L.T2, L.dq, w3c, a.DZ2c, row0);
     }
     bar();
     WTRACE(wg, 0, 11);
@@ -1026,6 +1045,8 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const unsigned m1c = hfwd<CW, LN>(pipe, c1, c2, true, L.X, L.px, a.critic, 1, L.ring, L.T1, nullptr, a.XH1q, row0, rs + 32);
     HeadRegs hd;
     if (cw) head_issue(hd, a.critic.W3, a.critic.b3);
+    const float w3c = a.critic.W3[tid & (H - 1)];   // for dZ2c below, ahead of the product
+    (void)w3c;
     const unsigned m2c = hfwd<CW, LN>(pipe, c2, c3, true, L.T1, LDT, a.critic, 2, L.ring, L.T2, nullptr, a.XH2q, row0, rs + 48);
     (void)m1c; (void)m2c;
     if (cw) {
@@ -1051,7 +1072,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
         for (int t = tid; t < R * H; t += NC) {   // dZ2c in place
             const int r = t >> 8, c = t & 255;
-            L.T2[r * LDT + c] = L.dq[r] * a.critic.W3[c] * dlrelu(L.T2[r * LDT + c]);
+            L.T2[r * LDT + c] = L.dq[r] * w3c * dlrelu(L.T2[r * LDT + c]);
         }
     }
     bar();
@@ -1071,7 +1092,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
         if (cw && wv == 0) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                const int c = 16 * nb + (lane & 15);
+                const int c = 16 * nb + (lane & 15);   // (for_acc's column numbering, wave 0)
                 if (c < ac) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1406,6 +1427,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, a.A1, hrow0);
         HeadRegs hd;
         if (cw) head_issue(hd, n.W3, n.b3);
+        const float w3c = n.W3[tid & (H - 1)];   // for head_bwd, ahead of the product
         hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, a.A2, hrow0);
         if (cw) head1(L.T2, hd, L.s_);
         bar();
@@ -1435,7 +1457,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         bar();
         if (cw) {
             head_grad_slot(L.T2, L.dq, a.w3_part + (int64_t)wg * (H + 1));
-            head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);
+            head_bwd(L.T2, L.dq, w3c, a.DZ2, hrow0);
         }
         bar();
         f32x4 acc[NB];
@@ -1454,10 +1476,11 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
     const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
     hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
+    const float w3c = n.W3[tid & (H - 1)];   // for head_bwd, ahead of the product
     const unsigned m2 = hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
     if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
     bar();
-    if (cw) head_bwd(L.T2, L.dq, n.W3, a.DZ2, hrow0);                                            // gz2
+    if (cw) head_bwd(L.T2, L.dq, w3c, a.DZ2, hrow0);                                             // gz2
     bar();
     {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
         f32x4 acc[NB];
