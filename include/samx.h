@@ -566,6 +566,14 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
  * Part bit 6 (value 64): the update counters of the roles are NOT advanced — an evaluation that no optimiser
  * pass follows (d.get_grads / d.get_losses, sam.py:398-399: the reference runs them as sess.runs of their own
  * before d.optimize).
+ * Part bits 7 and 8 (values 128, 256; samx_step_path 2 only, ignored elsewhere): the 256-wide role kernels read
+ * k-interleaved images of every W1 / W2 for their forward products; by default each call writes the images it
+ * needs from the parameter vectors first (one launch), so nothing can go stale behind the caller's back.  A caller
+ * that runs several update steps back to back on ONE workspace may instead let the optimiser pass keep them
+ * current (samx_step_apply mode bit 6): bit 8 = write the images of ALL five networks in this call, bit 7 = the
+ * images in the workspace are current, write none.  Bit 7 is only valid if since the last call with bit 8 on this
+ * workspace W1 / W2 of the learner's networks and targets were modified by nothing but samx_step_apply calls with
+ * mode bit 6 (PopArt's rescale touches the heads only).
  * Under HIP stream capture: on the layer-wise path (samx_step_path 0) the call forks two role streams from
  * `stream`; `stream` must then be the capture's ORIGIN stream.  A fork of a forked stream crashes
  * hipStreamEndCapture in the HIP runtime this was built against (torch 2.10.0+rocm7.0) — with plain torch streams
@@ -582,7 +590,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* batch, const s
  * the all-reduce); mode bit 3 (value 8): leave the reward-net segment out, bit 4 (value 16): leave the
  * actor and critic segments out (role subsets, see samx_step_grads_part); bit 5 (value 32): no Polyak step on
  * the targets (mu.train() and mu.update_target_net() are separate calls in the reference's loop, sam.py:421,433:
- * the object mirror runs the target update through samx_polyak).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
+ * the object mirror runs the target update through samx_polyak); bit 6 (value 64, with bit 1 and without bit 5;
+ * samx_step_path 2 only, ignored elsewhere): every updated W1 / W2 element, and its Polyak-averaged target, is
+ * also written into the weight images of the workspace (samx_step_grads_part bits 7/8).  Single GPU: one call, mode 3.  N GPUs: mode 1, all-reduce(grads), mode 6 with
  * grad_scale = 1/N.  `ws` must be the workspace samx_step_grads used, B the same batch size. */
 int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale, void* ws,
                     size_t ws_bytes, void* stream);

@@ -116,6 +116,11 @@ struct ApplySeg {
     int nblocks;
     float lr, clip;
     const int64_t* step_dev;
+    // 256-wide path (samx_step_apply mode bit 6): the k-interleaved images of W1 / W2 that the role kernels' forward
+    // products read (fused_wide.h: element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3)) follow the update, for the
+    // segment's network and, with Polyak, its target network.  W1 = [0, img_n1), W2 = [img_o2, img_o2 + 256 * 256).
+    float *img1 = nullptr, *img2 = nullptr, *timg1 = nullptr, *timg2 = nullptr;
+    int64_t img_n1 = 0, img_o2 = 0;
 };
 
 struct ApplyArgs {

@@ -960,7 +960,17 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
             vi = vi + (gi * gi - vi) * (1.f - f.beta2);
             const float pi = p0 - (mi * lr_t) / (sqrtf(vi) + f.eps);
             s.m[i] = mi; s.v[i] = vi; s.param[i] = pi;
-            if (s.targ) s.targ[i] = (1.f - f.tau) * t0 + f.tau * pi;
+            const float ti = (1.f - f.tau) * t0 + f.tau * pi;
+            if (s.targ) s.targ[i] = ti;
+            if (s.img1) {   // 256-wide path: the forward products' weight images follow the update
+                const bool in1 = i < s.img_n1, in2 = i >= s.img_o2 && i < s.img_o2 + 65536;
+                if (in1 || in2) {
+                    const int64_t q = in1 ? i : i - s.img_o2, k = q >> 8, j = q & 255;
+                    const int64_t at = (((k >> 2) << 8) + j) * 4 + (k & 3);
+                    (in1 ? s.img1 : s.img2)[at] = pi;
+                    if (s.targ) (in1 ? s.timg1 : s.timg2)[at] = ti;
+                }
+            }
         }
         const int64_t nx = i + step;
         if (nx < s.n) {

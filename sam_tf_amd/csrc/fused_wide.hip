@@ -1185,6 +1185,38 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     // commit behind this launch (nets.hip wide_finish_kernel), hence the same bits.
     const bool norm = a.rms_sums != nullptr || a.mean != nullptr;
     float* ms = L.T1;   // [0, kMaxIn) mean, [kMaxIn, 2 kMaxIn) std
+    // Every row load goes out FIRST (rows_issue: index word -> 26 + 26 row elements, two dependent HBM round
+    // trips); the statistics and the interpolation weights below are computed while they fly.
+    RowRegs xp, xe;
+    if (cw) {   // rows: policy (ring rows), expert (pool slice)
+        const int64_t g = row0 + (tid >> 4);
+        const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g);
+        const int64_t eg = (a.e_start ? a.e_start[0] : 0) + g;
+        if (sect != 1) rows_issue(xp, k32, a.p_obs, a.p_acs, ob, ac, ac, pg);
+        if (sect != 0) rows_issue(xe, k32, a.e_obs, a.e_acs, ob, ac, ac, eg);
+    }
+    // The interpolation weights of this tile, drawn here (no injected tensors): the tile's elements of either stream
+    // are one contiguous range — rows row0 .. row0 + 15 of a [B][ob] / [B][ac] tensor, as samx_disc_randoms numbers
+    // them — so all eight waves draw them four per Philox into LDS: E[r * ob + c], then E[16 ob + r * ac + c'].
+    float* E = L.ring;
+    if (sect == 2 && !a.eps_ob) {
+        const uint64_t step = (uint64_t)a.rng_step[0];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int w = sidx ? ac : ob;
+            float* Es = sidx ? E + R * ob : E;
+            const int64_t e0 = row0 * w, lo = e0 >> 2, hi = (e0 + (int64_t)R * w - 1) >> 2;
+            for (int64_t grp = lo + tid; grp <= hi; grp += NT) {
+                float u[4];
+                philox_uniform4(a.rng_seed, step, sidx ? RNG_EPS_AC : RNG_EPS_OB, (uint64_t)grp, u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t e = 4 * grp + i - e0;
+                    if (e >= 0 && e < (int64_t)R * w) Es[e] = u[i];
+                }
+            }
+        }
+    }
     if (norm) {
         for (int c = tid; c < ob; c += NT) {   // every thread of the workgroup
             float gm, gs;
@@ -1201,24 +1233,17 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             ms[c] = gm;
             ms[kMaxIn + c] = gs;
         }
-        bar();
     }
-    if (cw) {   // rows: policy (ring rows), expert (pool slice), eps p + (1 - eps) e  (discriminator.py:129-134):
-        // every row load goes out first (rows_issue), then the rows are normalised and written (branch-free,
+    bar();   // statistics and interpolation weights are in LDS
+    if (cw) {   // eps p + (1 - eps) e  (discriminator.py:129-134): the rows are normalised and written (branch-free,
         // the HBM copy last — see rows_commit)
         const int r = tid >> 4;
         const int64_t g = row0 + r;
-        const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g);
-        const int64_t eg = (a.e_start ? a.e_start[0] : 0) + g;
         const float* mp = norm ? ms : nullptr;
-        RowRegs xp, xe;
-        if (sect != 1) rows_issue(xp, k32, a.p_obs, a.p_acs, ob, ac, ac, pg);
-        if (sect != 0) rows_issue(xe, k32, a.e_obs, a.e_acs, ob, ac, ac, eg);
         if (sect == 0) rows_commit(L, xp, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
         else if (sect == 1) rows_commit(L, xe, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
         else {
             // interpolates of the NORMALISED rows; X receives V later, nothing goes to HBM here
-            const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
             const int t = opaque_tid();
             const int c0 = t & 15;
             float* xr = L.X + (t >> 4) * L.px + c0;
@@ -1249,11 +1274,8 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
                         ev = c < ob ? en : ev;
                     }
                     float eps = ee[i];
-                    if (!a.eps_ob) {   // drawn here: stream and element as samx_disc_randoms numbers them
-                        const bool isob = c < ob;
-                        eps = philox_uniform(a.rng_seed, step, isob ? RNG_EPS_OB : RNG_EPS_AC,
-                                             isob ? (uint64_t)(g * ob + c) : (uint64_t)(g * ac + (c - ob)));
-                    }
+                    if (!a.eps_ob)   // drawn above (columns >= in read a valid word; their value is dropped below)
+                        eps = c < ob ? E[r * ob + c] : E[R * ob + r * ac + min(c - ob, ac - 1)];
                     const float v = eps * pv + (1.f - eps) * ev;
                     xr[16 * u] = c < in ? v : 0.f;
                     xp.v[u] = v;
@@ -1475,13 +1497,18 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     // weight gradients after this launch, not here.
     const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
     const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
+#define DTR(i) do { if (cw) WTRACE(wg, 2, 6 + (i)); } while (0)   // interpolate tile 0: phase stamps 6 ..
+    DTR(0);
     hidden_fwd<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, L.ring, L.T1, nullptr, 0);                       // A1 (kept: mask)
+    DTR(1);
     const float w3c = n.W3[tid & (H - 1)];   // for head_bwd, ahead of the product
     const unsigned m2 = hidden_fwd<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, L.ring, L.T2, nullptr, 0);    // A2 -> mask bits
+    DTR(2);
     if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
     bar();
     if (cw) head_bwd(L.T2, L.dq, w3c, a.DZ2, hrow0);                                             // gz2
     bar();
+    DTR(3);
     {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
         f32x4 acc[NB];
         zero_acc(acc);
@@ -1494,6 +1521,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             });
     }
     bar();
+    DTR(4);
     {   // g = gz1 W1^T, 256 input columns at a time, over X (dead by now)
         auto put = [&](const f32x4 (&acc)[NB], int j0) {
             
@@ -1506,6 +1534,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         if (in > H) {
             wprod<CW>(pipe, g0, g1, true, L.T2, LDT, L.ring, acc);
             put(acc, 0);
+            DTR(5);
             zero_acc(acc);
             wprod<CW>(pipe, g1, t1, true, L.T2, LDT, L.ring, acc);
             put(acc, H);
@@ -1515,6 +1544,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         }
     }
     bar();
+    DTR(6);
     if (cw) {
         const int r = tid >> 4, q = tid & 15;
         float so = 0.f, sa = 0.f;
@@ -1526,6 +1556,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
     }
     bar();
+    DTR(7);
     if (cw && tid == 0) {
         double o = 0.0, c = 0.0;
         for (int r = 0; r < R; ++r) { o += (double)L.red[r]; c += (double)L.red[16 + r]; }
@@ -1542,6 +1573,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         }
     }
     bar();
+    DTR(8);
     {   // a1dot = (V W1) .* m1, in place over A1
         f32x4 acc[NB];
         zero_acc(acc);
@@ -1554,6 +1586,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             });
     }
     bar();
+    DTR(9);
     {   // a2dot = (a1dot W2) .* m2
         f32x4 acc[NB];
         zero_acc(acc);

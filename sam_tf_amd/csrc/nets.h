@@ -37,11 +37,18 @@ struct WideExt {
     // packed: the k-interleaved weight images of every network this call's roles need were written by the
     // targets_only launch of the SAME samx_step_grads_part call (nothing but the critic heads changed since)
     bool packed = false;
+    // images_current: every image in the workspace is current (samx_step_grads_part bit 7: the optimiser pass of the
+    // previous row kept them, samx_step_apply mode bit 6) — nothing is packed; pack_all (bit 8): pack all five
+    // networks' images whatever this call's roles need, so that later rows can rely on them
+    bool images_current = false, pack_all = false;
     const int64_t* n_idx = nullptr;
     const float *n_rews = nullptr, *n_dones = nullptr, *n_len = nullptr;
     float* tqn = nullptr;
 };
 size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B);
+// the weight images inside the reduction workspace: img[n][0 / 1] = W1 / W2 of n = actor, critic, reward net, target
+// actor, target critic (for the optimiser pass that keeps them current)
+int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2]);
 // Fills learner.grads, the per-segment sums of squares (sumsq, fused::kMaxSegBlocks per optimiser) and the
 // losses, and ticks the step counters of the roles it ran.  part bit 0: the role launch and the grouped
 // products (with the head-gradient slot sums); bit 1: the reduction that finishes the gradients, with the

@@ -1602,6 +1602,14 @@ size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B) {
     return align_up(ar.off, 256) + 256;
 }
 
+int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2]) {
+    Arena ar(ws_red, red_bytes);
+    WideRed wr = carve_wide_red(ar, L->ob_dim, L->ac_dim, B, L->critic.layernorm != 0);
+    if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_images: reduction workspace too small");
+    for (int n = 0; n < 5; ++n) { img[n][0] = wr.pk[n][0]; img[n][1] = wr.pk[n][1]; }
+    return SAMX_OK;
+}
+
 bool wide_step_supported(const samx_learner* L, int64_t B) {
     return wide::supported(&L->actor, &L->critic, &L->reward, L->ob_dim, L->ac_dim, B) &&
            L->d_actor_loss_scale == 0.f && B / wide::kRows <= kGpBlocks;
@@ -1648,7 +1656,15 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
     f.gp_coeff = gp_coeff;
     f.rms_sums = nullptr; f.rms_addvec = nullptr; f.rms_mean = f.rms_std = nullptr;
     const float* pk_src[5][2] = {};
+    {   // (all five, whatever the roles of this call: WideExt::pack_all)
+        const Net s0 = split(da, L->params), s1 = split(dc, L->params + Pa), s2 = split(dd, L->params + Pa + Pc);
+        const Net s3 = split(da, L->targets), s4 = split(dc, L->targets + Pa);
+        const Net* sn[5] = {&s0, &s1, &s2, &s3, &s4};
+        for (int q = 0; q < 5; ++q) { pk_src[q][0] = sn[q]->W1; pk_src[q][1] = sn[q]->W2; }
+    }
     auto pack = [&](int mask) -> int {   // bit n: network n of [actor, critic, reward, target actor, target critic]
+        if (ext && ext->images_current) return SAMX_OK;
+        if (ext && ext->pack_all) mask = 0x1F;
         const float* W[10];
         float* dst[10];
         int K[10], n = 0;
@@ -1681,10 +1697,6 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         s.step_dev = (part & 4) ? nullptr : L->steps + k;   // part bit 2 here: no counter tick
         return s;
     };
-    if (do_d) {   // (known before the target launch, which writes every image the call will need)
-        const Net nd0 = split(dd, L->params + Pa + Pc);
-        pk_src[2][0] = nd0.W1; pk_src[2][1] = nd0.W2;
-    }
     if (do_a) {
         Arena a1(ws_tc, nets_bytes), a2(ws_a, nets_bytes);
         w1 = carve_agent(a1, da, dc, nullptr, B);
@@ -1701,8 +1713,6 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.critic.W1p = wr.pk[1][0]; a.critic.W2p = wr.pk[1][1];
         a.targ_actor.W1p = wr.pk[3][0]; a.targ_actor.W2p = wr.pk[3][1];
         a.targ_critic.W1p = wr.pk[4][0]; a.targ_critic.W2p = wr.pk[4][1];
-        pk_src[0][0] = na.W1; pk_src[0][1] = na.W2; pk_src[1][0] = nc.W1; pk_src[1][1] = nc.W2;
-        pk_src[3][0] = ta.W1; pk_src[3][1] = ta.W2; pk_src[4][0] = tc.W1; pk_src[4][1] = tc.W2;
         a.ob = ob; a.ac = ac; a.B = B;
         a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
         a.targ_q = o->targ_q; a.td_out = o->td;
@@ -1778,7 +1788,6 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
         d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
         d.net.W1p = wr.pk[2][0]; d.net.W2p = wr.pk[2][1];
-        pk_src[2][0] = nd.W1; pk_src[2][1] = nd.W2;
         d.X = w.X; d.A1 = w.h.N1; d.A2 = w.h.N2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
         d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part; d.w3_part = wr.w3d;
         if (ln) { d.XH1 = w.h.XH1; d.XH2 = w.h.XH2; d.TN1 = w.TA1; d.PA1 = w.TA2; }

@@ -1,7 +1,9 @@
 // Counter-based uniforms for the tensors TensorFlow draws inside the discriminator graph
 // (tf.random_uniform in discriminator.py:101-109,130-133).  Philox4x32-10 keyed by the run seed; the
-// counter is (element index, stream id, update count) so every element of every update has its own
-// draw, identical no matter which kernel (fused or layer-wise) or which thread produces it.
+// counter is (element index / 4, stream id, update count) and element e takes output word e % 4, so every
+// element of every update has its own draw, identical no matter which kernel (fused or layer-wise) or which
+// thread produces it — and a kernel that needs a contiguous range of elements pays one Philox per four (the
+// 256-wide role kernel spent 11 of its 73 us drawing one element per Philox, on half of its waves).
 // TF's own stream cannot be reproduced (and parity tests inject these tensors instead).
 #pragma once
 #include <stdint.h>
@@ -20,10 +22,10 @@ __host__ __device__ inline void philox_round(uint32_t c[4], const uint32_t k[2])
 
 enum RngStream { RNG_EPS_OB = 0, RNG_EPS_AC = 1, RNG_REAL = 2, RNG_FAKE = 3 };
 
-// uniform in [0, 1) with 24 random bits
-__host__ __device__ inline float philox_uniform(uint64_t seed, uint64_t step, uint32_t stream,
-                                                uint64_t elem) {
-    uint32_t c[4] = {(uint32_t)elem, (uint32_t)(elem >> 32) ^ (stream << 28), (uint32_t)step,
+// the uniforms in [0, 1) (24 random bits each) of elements 4 group .. 4 group + 3
+__host__ __device__ inline void philox_uniform4(uint64_t seed, uint64_t step, uint32_t stream, uint64_t group,
+                                                float u[4]) {
+    uint32_t c[4] = {(uint32_t)group, (uint32_t)(group >> 32) ^ (stream << 28), (uint32_t)step,
                      (uint32_t)(step >> 32)};
     uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma unroll
@@ -32,7 +34,16 @@ __host__ __device__ inline float philox_uniform(uint64_t seed, uint64_t step, ui
         k[0] += 0x9E3779B9u;
         k[1] += 0xBB67AE85u;
     }
-    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
+// one element
+__host__ __device__ inline float philox_uniform(uint64_t seed, uint64_t step, uint32_t stream,
+                                                uint64_t elem) {
+    float u[4];
+    philox_uniform4(seed, step, stream, elem >> 2, u);
+    const int w = (int)(elem & 3);
+    return w == 0 ? u[0] : (w == 1 ? u[1] : (w == 2 ? u[2] : u[3]));
 }
 
 // smoothed labels: tf.random_uniform(minval=1.2, maxval=0.7) = 1.2 - 0.5u ; (0.3, 0.0) = 0.3 - 0.3u

@@ -137,7 +137,7 @@ int check_learner(const samx_learner* L, const char* who) {
 
 // segs: bit k set = optimiser segment k (0 actor, 1 critic, 2 reward net) takes part
 fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale, int segs = 7,
-                            bool polyak = true) {
+                            bool polyak = true, float* (*img)[2] = nullptr) {
     const int64_t Pa = samx_mlp_param_count(&L->actor), Pc = samx_mlp_param_count(&L->critic),
                   Pd = samx_mlp_param_count(&L->reward);
     const int64_t off[3] = {0, Pa, Pa + Pc}, n[3] = {Pa, Pc, Pd};
@@ -163,6 +163,13 @@ fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, fl
         s.lr = lr[k];
         s.clip = L->clip_norm;
         s.step_dev = L->steps + k;
+        if (img) {   // k-interleaved images of W1 / W2 of network k and (k < 2) of its target network
+            const samx_mlp* dn = k == 0 ? &L->actor : (k == 1 ? &L->critic : &L->reward);
+            s.img1 = img[k][0]; s.img2 = img[k][1];
+            s.timg1 = k < 2 ? img[3 + k][0] : nullptr; s.timg2 = k < 2 ? img[3 + k][1] : nullptr;
+            s.img_n1 = (int64_t)dn->in_dim * dn->h1;
+            s.img_o2 = s.img_n1 + dn->h1 + (dn->layernorm ? 2 * dn->h1 : 0);
+        }
     }
     return f;
 }
@@ -840,8 +847,9 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
 int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                          size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
-    SAMX_REQUIRE((part & ~127) == 0 && (part & 3) != 0 && (part & 12) != 12,
-                 "samx_step_grads_part: part uses bits 0-6, needs bit 0 or 1, and cannot skip both roles");
+    SAMX_REQUIRE((part & ~511) == 0 && (part & 3) != 0 && (part & 12) != 12 && (part & 384) != 384,
+                 "samx_step_grads_part: part uses bits 0-8, needs bit 0 or 1, cannot skip both roles, and bits 7 and 8 "
+                 "exclude each other");
     const bool tick = !(part & 64);   // bit 6: an evaluation that no update follows (d.get_grads / d.get_losses)
     const bool do_d = !(part & 4), do_a = !(part & 8);   // roles of this call
     const bool t_only = part & 16, t_done = part & 32;   // PopArt with N processes: the call split at the all-reduce
@@ -901,6 +909,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     if (wide) {
         // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions, all on the caller's stream
         samx::WideExt we;
+        we.images_current = (part & 128) != 0;
+        we.pack_all = (part & 256) != 0;
         auto roles = [&](const samx::WideExt* e) {
             return samx::wide_step_roles(L, b, o, w.nets_ws, w.nets_ws2, w.nets_bytes, w.disc_ws, w.disc_bytes,
                                          w.wide_red, w.wide_red_bytes, w.sumsq, do_a, do_d, (part & 3) | (tick ? 0 : 4), st, e);
@@ -1192,15 +1202,22 @@ int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale
     int rc = check_learner(L, "samx_step_apply");
     if (rc != SAMX_OK) return rc;
     SAMX_REQUIRE(ws && B > 0, "samx_step_apply: null workspace or bad batch");
-    SAMX_REQUIRE((mode & ~63) == 0 && (mode & 3) != 0 && (mode & 24) != 24,
-                 "samx_step_apply: mode uses bits 0-5, needs bit 0 or 1, and cannot skip every segment");
+    SAMX_REQUIRE((mode & ~127) == 0 && (mode & 3) != 0 && (mode & 24) != 24,
+                 "samx_step_apply: mode uses bits 0-6, needs bit 0 or 1, and cannot skip every segment");
     const int segs = ((mode & 16) ? 0 : 3) | ((mode & 8) ? 0 : 4);
     SAMX_REQUIRE(!(mode & 1) || L->clipped, "samx_step_apply: mode bit 0 needs learner.clipped");
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     StepWs w = carve(ar, L, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_step_apply: workspace %zu < %zu", ws_bytes, ar.off);
-    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs, !(mode & 32));
+    float* img[5][2];
+    const bool keep = (mode & 64) && (mode & 2) && use_wide(L, B);   // (bit 6 means nothing on the other paths)
+    if (keep) {
+        SAMX_REQUIRE(!(mode & 32), "samx_step_apply: mode bit 6 needs the Polyak step in the same pass (no bit 5)");
+        rc = samx::wide_images(L, B, w.wide_red, w.wide_red_bytes, img);
+        if (rc != SAMX_OK) return rc;
+    }
+    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs, !(mode & 32), keep ? img : nullptr);
     if (mode & 4) {  // gradients changed since samx_step_grads (all-reduce): recompute the norms
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;

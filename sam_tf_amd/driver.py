@@ -120,6 +120,8 @@ class UpdateStepDriver(object):
         # 256x256 learners (samx_step_path 2): layer-wise in how the driver plans launches and collectives,
         # fused in how the D-input statistics ride inside the step (one process)
         self.wide = self.L.path(B) == 2
+        # (SAMX_KEEP_IMAGES=0: every row packs its weight images itself, see _img_bits)
+        self.keep_images = os.environ.get('SAMX_KEEP_IMAGES', '1') != '0'
         # PER on the layer-wise path, one process: the D chain beside the PER work + agent roles (see
         # _seg_grads_two_branches); SAMX_PER_TWO_BRANCHES=0 keeps every row on one chain
         self.per_two_branches = bool(self.per_dev and not self.fused and not self.wide and self.world == 1 and
@@ -336,22 +338,37 @@ class UpdateStepDriver(object):
             rb.trees.per_sample(rb.num_entries, u, mu.hps.beta, idxs_out=idx_a, iws_out=self.iws,
                                 iws32_out=self.iws32)
 
-    def _seg_targets(self, k=0, role=3):
+    def _img_bits(self, k, K):
+        """256-wide path, K rows in one launch: the role kernels' forward products read k-interleaved images of
+        W1 / W2 (fused_wide.hip), normally packed from the parameter vectors at the head of every row (one launch,
+        ~5.5 us at C4).  Inside ONE launch nothing but the optimiser pass rewrites those matrices, so row 0 packs all
+        five networks (part bit 8), every optimiser pass but the last keeps the images current (samx_step_apply mode
+        bit 6) and rows 1 .. K-1 pack nothing (part bit 7).  Returns (part bits of row k's gradient calls, mode bit of
+        its optimiser pass).  Between launches anything may touch the parameters (root sync, checkpoints, the object
+        API), which is why every launch starts with a pack."""
+        if not (self.wide and self.keep_images) or K == 1:
+            return 0, 0
+        return (256 if k == 0 else 128), (64 if k < K - 1 else 0)
+
+    def _seg_targets(self, k=0, role=3, K=1):
         """N > 1 with PopArt: [PER sampling,] the target pass and the local return sums -> ret_addvec."""
         self._seg_trees(role, k)
-        ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 16 | self._masks(role)[0])
+        ops.step_grads_part(self.L, self.batches[k], self.out, 1 | 16 | self._masks(role)[0] | self._img_bits(k, K)[0])
 
-    def _seg_grads(self, k=0, role=3, trees_done=False):
+    def _seg_grads(self, k=0, role=3, trees_done=False, K=1):
         mu, d = self.mu, self.d
         part, mode = self._masks(role)
+        img_part, img_mode = self._img_bits(k, K)
         if d.hps.rmsify_obs and self.world > 1 and not self.inline_stats and role & self.D:
             ops.rms_commit(d.obs_rms.sums, d.obs_rms.addvec, d.obs_rms.mean, d.obs_rms.std)
         split = self.popart_split and role & self.A   # _seg_targets + all-reduce(ret_addvec) came before
         if not trees_done and not split:
             self._seg_trees(role, k)
-        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0))
+        if split and img_part:
+            img_part = 128   # (the target call of this row packed, or found, every image)
+        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0) | img_part)
         # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
-        ops.step_apply(self.L, self.B, (3 if self.world == 1 else 1) | mode, 1.0)
+        ops.step_apply(self.L, self.B, (3 | img_mode if self.world == 1 else 1) | mode, 1.0)
         if self.world == 1:
             self._seg_refresh(role, k)
 
@@ -380,8 +397,8 @@ class UpdateStepDriver(object):
         if last:
             self._seg_refresh(role, k)
 
-    def _seg_apply(self, role=3):
-        ops.step_apply(self.L, self.B, 6 | self._masks(role)[1], 1.0 / self.world)
+    def _seg_apply(self, role=3, k=0, K=1):
+        ops.step_apply(self.L, self.B, 6 | self._masks(role)[1] | self._img_bits(k, K)[1], 1.0 / self.world)
         self._seg_refresh(role)
 
     def _seg_refresh(self, role=3, k=0):
@@ -487,17 +504,17 @@ class UpdateStepDriver(object):
                                                      sample=(rb.num_entries, u, self.mu.hps.beta, idx_a, self.iws,
                                                              self.iws32), td=self._per_td())
                             self._seg_inputs(k, roles[k])
-                            self._seg_grads(k, roles[k], trees_done=True)
+                            self._seg_grads(k, roles[k], trees_done=True, K=K)
                         else:
                             self._seg_inputs(k, roles[k])
-                            self._seg_grads(k, roles[k])
+                            self._seg_grads(k, roles[k], K=K)
                 else:
                     if any_d:
                         self._seg_sums(K)
                     self._seg_lookahead(K)
                     for k in range(K):
                         self._seg_inputs(k, roles[k])
-                        self._seg_grads(k, roles[k])
+                        self._seg_grads(k, roles[k], K=K)
             return [self._capture(run)]
         # N > 1: the launch as a list of device segments and collectives in execution order
         #   [D-input sums of the K rows -> all-reduce of the K float64 sum vectors]   (fused path)
@@ -518,11 +535,11 @@ class UpdateStepDriver(object):
                 if d.hps.rmsify_obs and role & self.D:
                     items.append(('ar', lambda: ar(d.obs_rms.addvec)))
             if self.popart_split and role & self.A:
-                items += [('dev', lambda k=k, role=role: self._seg_targets(k, role)),
+                items += [('dev', lambda k=k, role=role: self._seg_targets(k, role, K=K)),
                           ('ar', lambda: ar(self.ret_addvec))]
-            items += [('dev', lambda k=k, role=role: self._seg_grads(k, role)),
+            items += [('dev', lambda k=k, role=role: self._seg_grads(k, role, K=K)),
                       ('ar', lambda role=role: ar(self._grads_of(role))),
-                      ('dev', lambda role=role: self._seg_apply(role))]
+                      ('dev', lambda k=k, role=role: self._seg_apply(role, k, K))]
         if self.collectives_in_graph:   # collectives on the caller's stream: ONE graph for the launch
             return [self._capture(lambda: [f() for _, f in items])]
         # host-issued collectives: consecutive device segments share one graph (the optimiser pass of row

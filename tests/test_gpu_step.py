@@ -264,3 +264,27 @@ def test_indirect_rows_and_kernel_randoms_match_dense():
                 assert torch.equal(l_ind[k], out.t[k]), k
         else:
             assert relerr(g_ind.cpu().numpy(), L.grads.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('name,ln', [('C4', False), ('w_20x3', False), ('w_20x3', True)])
+def test_weight_images_kept_by_the_optimiser_pass(name, ln):
+    """256-wide path: update steps whose optimiser pass keeps the forward products' weight images current
+    (samx_step_apply mode bit 6, samx_step_grads_part bits 7/8) == the same steps with the images packed from the
+    parameter vectors at the head of every call, bit for bit — parameters, targets, Adam moments, gradients, losses.
+    Role subsets in between (a discriminator-only and an agents-only step) leave the other images valid."""
+    from sam_tf_amd import ops
+    runs = {}
+    for keep in (False, True):
+        c, L, batch, out = _setup(name, 0.0, 1e-3, True, ln=ln)
+        assert L.path(c['B']) == 2
+        seq = [(0, 0), (0, 0), (4, 8), (8, 16), (0, 0)]   # (part role bits, apply role bits): all, all, agents, D, all
+        for k, (pr, ar) in enumerate(seq):
+            img_part = (256 if k == 0 else 128) if keep else 0
+            img_mode = 64 if keep and k < len(seq) - 1 else 0
+            ops.step_grads_part(L, batch, out, 3 | pr | img_part)
+            ops.step_apply(L, c['B'], 3 | ar | img_mode, 1.0)
+        torch.cuda.synchronize()
+        runs[keep] = dict(params=L.params.clone(), targets=L.targets.clone(), m=L.m.clone(), v=L.v.clone(),
+                          grads=L.grads.clone(), **{k: v.clone() for k, v in out.t.items()})
+    for k in runs[False]:
+        assert torch.equal(runs[False][k], runs[True][k]), k

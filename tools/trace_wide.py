@@ -36,6 +36,8 @@ ra, rd = acc[5:, 32:34], acc[5:, 64:70]
 f = lambda x: ' '.join('%.2f' % v for v in np.median((x - base) / 100.0, axis=0))
 print('actor role workgroup 0 (start end):', f(ra))
 print('D role first tiles (interpolate start end | policy start end | expert start end):', f(rd))
+print('D interpolate tile 0 phases (fwd1 start, fwd2 start, fwd2 end, head bwd done, gz1 done, g0 done, g done, '
+      'sums done, V done, tangent 1 done):', f(acc[5:, 70:80]))
 st = acc[5:, 128:]
 n = int((st[0] > 0).sum())
 d = np.median(np.diff(st[:, :n], axis=1), axis=0) / 100.0
