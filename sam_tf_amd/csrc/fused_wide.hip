@@ -45,7 +45,7 @@ constexpr int H = kH;
 constexpr int LDT = 260;               // pitch of a [16][256] tile
 constexpr int WP = 260;                // pitch of a staged weight row (NN image)
 constexpr int STAGE_F = 32 * WP;       // floats per ring stage (NT image: 256 * 32 fits)
-constexpr int NSTG = 3;
+constexpr int NSTG = 2;                // aux slots (the weight ring of round 2; now: head matrices, LayerNorm scratch, E)
 constexpr int PP = 36;                 // pitch of the [16][ac <= 32] tile of the actor's pre-tanh cotangent
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Phase timestamps of workgroup 0 of each role (profiling builds only: -DSAMX_TRACE; never shipped)
@@ -327,7 +327,7 @@ __device__ __forceinline__ unsigned hidden_fwd(WPipe& pipe, const WDesc cur, con
     return bits;
 }
 
-// The helpers below (head1 .. head_bwd, load_rows) are for the compute waves only: threadIdx.x < NC.
+// The helpers below (head1 .. head_bwd) are for the row threads only: threadIdx.x < NC.
 // s[r] = <T[r], w3> + b3  (1-output head; w3 / b3 from global memory)
 // The head's weights travel ahead (head_issue before the product that fills T, head1 after it): their loads
 // would otherwise be a bare L2 round trip in the middle of the chain.
@@ -408,17 +408,19 @@ __device__ __forceinline__ void stage_head_commit(const HeadStage& hs, int out, 
 
 struct Lds {
     float *ring, *X, *T1, *T2, *PRE, *s_, *tq, *dq, *red, *rw, *dn, *iw, *tl;
+    float* st;   // [kMaxIn][2]: (mean, 1 / std) of the input columns the rows are normalised with
     int px;
 };
 // (the full width whatever the input: rows_commit writes all kMaxIn columns)
 __host__ __device__ inline int pitch_x(int) { return kMaxIn + 4; }
 __host__ __device__ inline size_t lds_floats(int in) {
-    return (size_t)NSTG * STAGE_F + (size_t)R * pitch_x(in) + 2 * R * LDT + R * PP + 16 * 8 + 64;
+    return (size_t)NSTG * STAGE_F + 2 * kMaxIn + (size_t)R * pitch_x(in) + 2 * R * LDT + R * PP + 16 * 8 + 64;
 }
 __device__ inline Lds carve(float* p, int in) {
     Lds L;
     L.px = pitch_x(in);
     L.ring = p; p += NSTG * STAGE_F;
+    L.st = p; p += 2 * kMaxIn;
     L.X = p; p += R * L.px;
     L.T1 = p; p += R * LDT;
     L.T2 = p; p += R * LDT;
@@ -429,11 +431,16 @@ __device__ inline Lds carve(float* p, int in) {
 }
 
 // rows [obz | acs] of the batch into X[16][px], zero up to k32 columns; optional dense copy to HBM.
-// Thread t owns row t >> 4 and the columns (t & 15) + 16 u.  Two halves: rows_issue sends ALL the row loads
-// (raw values, one register per column) and returns; rows_commit normalises and writes.  A role issues the
-// next input's rows before a product that does not need X and commits them after it: the HBM gather's
-// latency (2-3 us) hides behind the product.
-constexpr int kRowRegs = kMaxIn / 16;   // 26
+// ALL 512 threads: thread t owns row t >> 5 and the columns (t & 31) + 32 u (a wave-wide load covers two rows x 128
+// contiguous bytes).  Two halves: rows_issue sends ALL the row loads (raw values, one register per column) and
+// returns; rows_commit normalises and writes.  A role issues the next input's rows before a product that does not
+// need X and commits them after it: the HBM gather's latency (2-3 us) hides behind the product.
+// The statistics come from an LDS table of (mean, 1 / std) pairs that the role stages once (stats_stage): with the
+// 16-column mapping on four waves, a division per element and the statistics fetched from global memory inside the
+// commit, a commit cost 2.5 us in the middle of the target+critic chain and the discriminator's interpolate tiles
+// spent 6.5 us combining their two rows.
+constexpr int kRowRegs = kMaxIn / 32;   // 13
+static_assert(kMaxIn % 32 == 0 && NT == 32 * R, "rows mapping: 32 threads per row");
 struct RowRegs { float v[kRowRegs]; };
 // (thread index through an opaque asm, as in the loaders: the per-column predicates must be recomputed where
 // they are used — kept live from the issue to the commit across a product they spill by the hundred)
@@ -446,74 +453,68 @@ __device__ __forceinline__ void rows_issue(RowRegs& x, int k32, const float* __r
                                            const float* __restrict__ acs, int ob, int ac, int acw, int64_t prow) {
     // branch-free: every column loads from a valid address (columns beyond the row re-read its last element;
     // rows_commit zeroes them) — a branch per column costs more than the loads
-    const int c0 = opaque_tid() & 15;
+    const int c0 = opaque_tid() & 31;
     const float* ro = obs + prow * ob;
     const float* ra = acw > 0 ? acs + prow * ac : ro;
     const int amax = acw > 0 ? acw - 1 : 0;
 #pragma unroll
     for (int u = 0; u < kRowRegs; ++u) {
-        const int c = c0 + 16 * u;
+        const int c = c0 + 32 * u;
         const bool isob = c < ob;
         const int ci = isob ? c : min(c - ob, amax);
         x.v[u] = (isob ? ro : ra)[ci];
     }
 }
-// Straight-line on purpose (one uniform branch on `mean` around everything, selects inside): the role
-// kernels run at the SGPR limit, and every branch region reloads its spilled scalars.  All kRowRegs columns
-// are written — X rows always have the full pitch (pitch_x) and columns >= ob + acw get zeros.
-template <bool NORM>
-__device__ __forceinline__ void rows_commit_impl(const Lds& L, RowRegs& x, const float* __restrict__ mean,
-                                                 const float* __restrict__ stdv, int ob, int acw) {
-    const int t = opaque_tid();
-    const int r = t >> 4, c0 = t & 15;
-    constexpr int HB = kRowRegs / 2;   // the statistics come in two batches (13 + 13 columns)
-    float* xr = L.X + r * L.px + c0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float m[HB], sd[HB];
-        if (NORM) {
-#pragma unroll
-            for (int i = 0; i < HB; ++i) {
-                const int ci = min(c0 + 16 * (h * HB + i), ob - 1);
-                m[i] = mean[ci]; sd[i] = stdv[ci];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int u = h * HB + i, c = c0 + 16 * u;
-            float v = x.v[u];
-            if (NORM) {
-                const float vn = fminf(fmaxf((v - m[i]) / sd[i], -5.f), 5.f);   // computed for every lane
-                v = c < ob ? vn : v;
-            }
-            v = c < ob + acw ? v : 0.f;
-            x.v[u] = v;
-            xr[16 * u] = v;
-        }
+// (mean, 1 / std) of the ob normalised columns into the LDS table; all threads; the caller's next barrier publishes it
+__device__ __forceinline__ void stats_stage(const Lds& L, const float* __restrict__ mean,
+                                            const float* __restrict__ stdv, int ob) {
+    if (!mean) return;
+    for (int c = threadIdx.x; c < ob; c += NT) {
+        L.st[2 * c] = mean[c];
+        L.st[2 * c + 1] = 1.f / stdv[c];
     }
 }
-__device__ __forceinline__ void rows_commit(const Lds& L, RowRegs& x, int k32, const float* __restrict__ mean,
-                                            const float* __restrict__ stdv, int ob, int acw,
+// one element: clip((v - mean) / std, -5, 5) for an observation column (as a product with the staged reciprocal),
+// the raw value for an action column, zero beyond the row
+__device__ __forceinline__ float row_norm(const Lds& L, float v, int c, int ob, int acw, bool norm) {
+    if (norm) {
+        const float2 ms = *(const float2*)(L.st + 2 * min(c, ob - 1));
+        const float vn = fminf(fmaxf((v - ms.x) * ms.y, -5.f), 5.f);   // computed for every lane
+        v = c < ob ? vn : v;
+    }
+    return c < ob + acw ? v : 0.f;
+}
+// Straight-line on purpose (selects, no branch per column).  All kMaxIn columns are written — X rows always have the
+// full pitch (pitch_x) and columns >= ob + acw get zeros.  norm: the table was staged (stats_stage + barrier).
+__device__ __forceinline__ void rows_commit(const Lds& L, RowRegs& x, int k32, bool norm, int ob, int acw,
                                             float* __restrict__ hbm, int64_t hrow, int ldh) {
-    if (mean) rows_commit_impl<true>(L, x, mean, stdv, ob, acw);
-    else rows_commit_impl<false>(L, x, mean, stdv, ob, acw);
-    // the HBM copy last: stores count in vmcnt like loads, and a store between two columns would make the
-    // next column's statistics wait for its write acknowledgement
+    const int t = opaque_tid();
+    const int r = t >> 5, c0 = t & 31;
+    float* xr = L.X + r * L.px + c0;
+#pragma unroll
+    for (int u = 0; u < kRowRegs; ++u) {
+        const float v = row_norm(L, x.v[u], c0 + 32 * u, ob, acw, norm);
+        x.v[u] = v;
+        xr[32 * u] = v;
+    }
+    // the HBM copy last: stores count in vmcnt like loads
     if (hbm) {
-        const int c0 = opaque_tid() & 15;
         float* hr = hbm + hrow * ldh + c0;
 #pragma unroll
         for (int u = 0; u < kRowRegs; ++u)
-            if (c0 + 16 * u < ob + acw) hr[16 * u] = x.v[u];
+            if (c0 + 32 * u < ob + acw) hr[32 * u] = x.v[u];
     }
 }
-__device__ __forceinline__ void load_rows(const Lds& L, int k32, const float* __restrict__ obs,
-                                          const float* __restrict__ acs, const float* __restrict__ mean,
-                                          const float* __restrict__ stdv, int ob, int ac, int acw, int64_t prow,
-                                          float* __restrict__ hbm, int64_t hrow, int ldh) {
+// the first rows of a role: loads out, statistics staged while they fly, barrier, commit
+__device__ __forceinline__ void load_rows_first(const Lds& L, int k32, const float* __restrict__ obs,
+                                                const float* __restrict__ acs, const float* __restrict__ mean,
+                                                const float* __restrict__ stdv, int ob, int ac, int acw, int64_t prow,
+                                                float* __restrict__ hbm, int64_t hrow, int ldh) {
     RowRegs x;
     rows_issue(x, k32, obs, acs, ob, ac, acw, prow);
-    rows_commit(L, x, k32, mean, stdv, ob, acw, hbm, hrow, ldh);
+    stats_stage(L, mean, stdv, ob);
+    bar();
+    rows_commit(L, x, k32, mean != nullptr, ob, acw, hbm, hrow, ldh);
 }
 
 // ================================================================================================
@@ -824,7 +825,7 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
     Lds L = carve(lds, in_c);
     const int k32c = ((in_c + 31) / 32) * 32;
     const int64_t* idx = pass ? a.n_idx : a.idx;
-    const int64_t pr = cw ? ring_row(idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
+    const int64_t pr = ring_row(idx, a.ring_start, a.ring_len, row0 + (tid >> 5));
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc ta1 = w_nn(a.targ_actor.W1p, ob), ta2 = w_nn(a.targ_actor.W2p, H);
@@ -839,7 +840,7 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
             L.tl[tid] = a.td_len ? a.td_len[row0 + tid] : 1.f;
         }
     }
-    if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
+    load_rows_first(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
     bar();
     hfwd<CW, LN>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     HeadStage hs;
@@ -869,7 +870,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
     const int k32c = ((in_c + 31) / 32) * 32;
-    const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
+    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 5));
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc ta1 = w_nn(a.targ_actor.W1p, ob), ta2 = w_nn(a.targ_actor.W2p, H);
@@ -891,14 +892,16 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     RowRegs x0;
     HeadRegs hd;
     if (ext) {
-        if (cw) rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
+        rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
+        stats_stage(L, a.mean, a.stdv, ob);
+        bar();
     } else {
     // ---- TD target with the target nets on obs1
     WTRACE(wg, 0, 0);
 #ifdef SAMX_TRACE
     if (cw && wg == 0 && tid == 0) g_wtrace[120] = clock64();   // shader clock beside the 100 MHz wall clock
 #endif
-    if (cw) load_rows(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
+    load_rows_first(L, k32c, a.obs1, nullptr, a.mean, a.stdv, ob, ac, 0, pr, nullptr, 0, 0);
     bar();
     WTRACE(wg, 0, 1);
     hfwd<CW, LN>(pipe, ta1, ta2, true, L.X, L.px, a.targ_actor, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
@@ -912,10 +915,8 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     hfwd<CW, LN>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 5);
     // the online critic's input rows travel while the target critic's second layer runs
-    if (cw) {
-        rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
-        head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
-    }
+    rows_issue(x0, k32c, a.obs0, a.acs, ob, ac, ac, pr);
+    if (cw) head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
     hfwd<CW, LN>(pipe, tc2, c1, true, L.T1, LDT, a.targ_critic, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 6);
     if (cw) head1(L.T2, hd, L.s_);
@@ -930,7 +931,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     }   // !ext
     // ---- online critic on (obz0, acs): forward, loss, backward
     WTRACE(wg, 0, 14);
-    if (cw) rows_commit(L, x0, k32c, a.mean, a.stdv, ob, ac, a.Xc, row0 + (tid >> 4), in_c);
+    rows_commit(L, x0, k32c, a.mean != nullptr, ob, ac, a.Xc, row0 + (tid >> 5), in_c);
     WTRACE(wg, 0, 15);
     bar();
     WTRACE(wg, 0, 8);
@@ -1022,17 +1023,15 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int ob = a.ob, ac = a.ac, in_c = ob + ac;
     Lds L = carve(lds, in_c);
     const int k32c = ((in_c + 31) / 32) * 32;
-    const int64_t pr = cw ? ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 4)) : 0;
+    const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 5));
     WPipe pipe;
     wpipe_init(pipe);
     const WDesc a1 = w_nn(a.actor.W1p, ob), a2 = w_nn(a.actor.W2p, H), a3 = w_nt(a.actor.W2, H, 0, H);
     const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_nt(a.critic.W2, H, 0, H);
     const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
     if (cw) WTRACE(wg, 1, 0);
-    if (cw) {
-        load_rows(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 4), in_c);
-        for (int t = tid; t < R * PP; t += NC) L.PRE[t] = 0.f;
-    }
+    load_rows_first(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 5), in_c);
+    for (int t = tid; t < R * PP; t += NT) L.PRE[t] = 0.f;
     bar();
     // (LayerNorm: rs strips of actor 1 / 2 and critic 1 / 2 in L.red; mask bits in the rows mapping)
     float* rs = L.red;
@@ -1179,44 +1178,52 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int tsec = sect == 2 ? 0 : (sect == 0 ? 2 : 4);
     (void)tsec;   // only the SAMX_TRACE build reads it
     if (cw) WTRACE(wg % tiles_b, 2, tsec);
-    // statistics the rows are normalised with, staged in LDS (over T1, unused until the first product).
+    // statistics the rows are normalised with, staged in LDS (L.st: mean, 1 / std).
     // d.obs_rms.update folded into the step: the batch's float64 column sums were computed ahead, every
     // workgroup derives the mean/std that INCLUDE this batch from sums + addvec — the same arithmetic as the
     // commit behind this launch (nets.hip wide_finish_kernel), hence the same bits.
     const bool norm = a.rms_sums != nullptr || a.mean != nullptr;
-    float* ms = L.T1;   // [0, kMaxIn) mean, [kMaxIn, 2 kMaxIn) std
-    // Every row load goes out FIRST (rows_issue: index word -> 26 + 26 row elements, two dependent HBM round
+    // Every row load goes out FIRST (rows_issue: index word -> 13 + 13 row elements, two dependent HBM round
     // trips); the statistics and the interpolation weights below are computed while they fly.
     RowRegs xp, xe;
-    if (cw) {   // rows: policy (ring rows), expert (pool slice)
-        const int64_t g = row0 + (tid >> 4);
+    const int64_t g = row0 + (tid >> 5);   // this thread's row inside the section
+    {   // rows: policy (ring rows), expert (pool slice)
         const int64_t pg = ring_row(a.p_idx, a.ring_start, a.ring_len, g);
         const int64_t eg = (a.e_start ? a.e_start[0] : 0) + g;
         if (sect != 1) rows_issue(xp, k32, a.p_obs, a.p_acs, ob, ac, ac, pg);
         if (sect != 0) rows_issue(xe, k32, a.e_obs, a.e_acs, ob, ac, ac, eg);
     }
-    // The interpolation weights of this tile, drawn here (no injected tensors): the tile's elements of either stream
-    // are one contiguous range — rows row0 .. row0 + 15 of a [B][ob] / [B][ac] tensor, as samx_disc_randoms numbers
-    // them — so all eight waves draw them four per Philox into LDS: E[r * ob + c], then E[16 ob + r * ac + c'].
+    // The interpolation weights of this tile into LDS, E[r * ob + c] then E[16 ob + r * ac + c'].  The tile's elements
+    // of either tensor are one contiguous range — rows row0 .. row0 + 15 of a [B][ob] / [B][ac] tensor, as
+    // samx_disc_randoms numbers them — so when they are drawn here all eight waves draw them four per Philox.
     float* E = L.ring;
-    if (sect == 2 && !a.eps_ob) {
-        const uint64_t step = (uint64_t)a.rng_step[0];
+#define PTR(i) do { if (cw && sect == 2) WTRACE(wg, 2, 16 + (i)); } while (0)   // interpolate tile 0: prologue stamps
+    PTR(0);
+    if (sect == 2) {
+        const uint64_t step = a.eps_ob ? 0 : (uint64_t)a.rng_step[0];
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             const int w = sidx ? ac : ob;
             float* Es = sidx ? E + R * ob : E;
-            const int64_t e0 = row0 * w, lo = e0 >> 2, hi = (e0 + (int64_t)R * w - 1) >> 2;
-            for (int64_t grp = lo + tid; grp <= hi; grp += NT) {
-                float u[4];
-                philox_uniform4(a.rng_seed, step, sidx ? RNG_EPS_AC : RNG_EPS_OB, (uint64_t)grp, u);
+            const int64_t e0 = row0 * w;
+            if (a.eps_ob) {   // injected tensors
+                const float* src = (sidx ? a.eps_ac : a.eps_ob) + e0;
+                for (int e = tid; e < R * w; e += NT) Es[e] = src[e];
+            } else {
+                const int64_t lo = e0 >> 2, hi = (e0 + (int64_t)R * w - 1) >> 2;
+                for (int64_t grp = lo + tid; grp <= hi; grp += NT) {
+                    float u[4];
+                    philox_uniform4(a.rng_seed, step, sidx ? RNG_EPS_AC : RNG_EPS_OB, (uint64_t)grp, u);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t e = 4 * grp + i - e0;
-                    if (e >= 0 && e < (int64_t)R * w) Es[e] = u[i];
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t e = 4 * grp + i - e0;
+                        if (e >= 0 && e < (int64_t)R * w) Es[e] = u[i];
+                    }
                 }
             }
         }
     }
+    PTR(1);
     if (norm) {
         for (int c = tid; c < ob; c += NT) {   // every thread of the workgroup
             float gm, gs;
@@ -1230,62 +1237,39 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             } else {
                 gm = a.mean[c]; gs = a.stdv[c];
             }
-            ms[c] = gm;
-            ms[kMaxIn + c] = gs;
+            L.st[2 * c] = gm;
+            L.st[2 * c + 1] = 1.f / gs;
         }
     }
+    PTR(2);
     bar();   // statistics and interpolation weights are in LDS
-    if (cw) {   // eps p + (1 - eps) e  (discriminator.py:129-134): the rows are normalised and written (branch-free,
+    PTR(3);
+    {   // eps p + (1 - eps) e  (discriminator.py:129-134): the rows are normalised and written (branch-free,
         // the HBM copy last — see rows_commit)
-        const int r = tid >> 4;
-        const int64_t g = row0 + r;
-        const float* mp = norm ? ms : nullptr;
-        if (sect == 0) rows_commit(L, xp, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
-        else if (sect == 1) rows_commit(L, xe, k32, mp, mp + kMaxIn, ob, ac, a.X, hrow0 + r, in);
+        const int r = tid >> 5;
+        if (sect == 0) rows_commit(L, xp, k32, norm, ob, ac, a.X, hrow0 + r, in);
+        else if (sect == 1) rows_commit(L, xe, k32, norm, ob, ac, a.X, hrow0 + r, in);
         else {
             // interpolates of the NORMALISED rows; X receives V later, nothing goes to HBM here
             const int t = opaque_tid();
-            const int c0 = t & 15;
-            float* xr = L.X + (t >> 4) * L.px + c0;
-            constexpr int HB = kRowRegs / 2;
+            const int c0 = t & 31;
+            float* xr = L.X + (t >> 5) * L.px + c0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float m[HB], sd[HB], ee[HB];
-#pragma unroll
-                for (int i = 0; i < HB; ++i) {
-                    const int c = c0 + 16 * (h * HB + i);
-                    const int ci = min(c, ob - 1);
-                    m[i] = 0.f; sd[i] = 1.f; ee[i] = 0.f;
-                    if (norm) { m[i] = ms[ci]; sd[i] = ms[kMaxIn + ci]; }   // uniform branch
-                    if (a.eps_ob) {                                       // injected randoms (uniform branch)
-                        const bool isob = c < ob;
-                        const int ca = min(max(c - ob, 0), ac - 1);
-                        ee[i] = isob ? a.eps_ob[g * ob + ci] : a.eps_ac[g * ac + ca];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < HB; ++i) {
-                    const int u = h * HB + i, c = c0 + 16 * u;
-                    float pv = xp.v[u], ev = xe.v[u];
-                    if (norm) {
-                        const float pn = fminf(fmaxf((pv - m[i]) / sd[i], -5.f), 5.f);
-                        const float en = fminf(fmaxf((ev - m[i]) / sd[i], -5.f), 5.f);
-                        pv = c < ob ? pn : pv;
-                        ev = c < ob ? en : ev;
-                    }
-                    float eps = ee[i];
-                    if (!a.eps_ob)   // drawn above (columns >= in read a valid word; their value is dropped below)
-                        eps = c < ob ? E[r * ob + c] : E[R * ob + r * ac + min(c - ob, ac - 1)];
-                    const float v = eps * pv + (1.f - eps) * ev;
-                    xr[16 * u] = c < in ? v : 0.f;
-                    xp.v[u] = v;
-                }
+            for (int u = 0; u < kRowRegs; ++u) {
+                const int c = c0 + 32 * u;
+                const float pv = row_norm(L, xp.v[u], c, ob, ac, norm), ev = row_norm(L, xe.v[u], c, ob, ac, norm);
+                // (columns >= in read a valid word; pv = ev = 0 there)
+                const float eps = c < ob ? E[r * ob + c] : E[R * ob + r * ac + min(c - ob, ac - 1)];
+                const float v = eps * pv + (1.f - eps) * ev;
+                xr[32 * u] = v;
+                xp.v[u] = v;
             }
+            PTR(4);
             if constexpr (LN) {   // the primal stream's layer input (x^T P_z1 of the weight gradient)
-                float* hr = a.X + (hrow0 + (t >> 4)) * in + c0;
+                float* hr = a.X + (hrow0 + (t >> 5)) * in + c0;
 #pragma unroll
                 for (int u = 0; u < kRowRegs; ++u)
-                    if (c0 + 16 * u < in) hr[16 * u] = xp.v[u];
+                    if (c0 + 32 * u < in) hr[32 * u] = xp.v[u];
             }
         }
     }

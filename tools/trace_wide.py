@@ -38,6 +38,7 @@ print('actor role workgroup 0 (start end):', f(ra))
 print('D role first tiles (interpolate start end | policy start end | expert start end):', f(rd))
 print('D interpolate tile 0 phases (fwd1 start, fwd2 start, fwd2 end, head bwd done, gz1 done, g0 done, g done, '
       'sums done, V done, tangent 1 done):', f(acc[5:, 70:80]))
+print('D interpolate tile 0 prologue (rows issued, weights drawn, statistics staged, barrier passed, half 0, half 1):', f(acc[5:, 80:86]))
 st = acc[5:, 128:]
 n = int((st[0] > 0).sum())
 d = np.median(np.diff(st[:, :n], axis=1), axis=0) / 100.0
