@@ -119,7 +119,11 @@ struct ApplySeg {
     // 256-wide path (samx_step_apply mode bit 6): the k-interleaved images of W1 / W2 that the role kernels' forward
     // products read (fused_wide.h: element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3)) follow the update, for the
     // segment's network and, with Polyak, its target network.  W1 = [0, img_n1), W2 = [img_o2, img_o2 + 256 * 256).
-    float *img1 = nullptr, *img2 = nullptr, *timg1 = nullptr, *timg2 = nullptr;
+    // tr1 / tr2: the images of the TRANSPOSE the backward products read, element (row, column) at
+    // ((column >> 2) * J + row - r0) * 4 + (column & 3): tr2 = all of W2 (J = 256, r0 = 0); tr1 = rows >= tr1_r0 of W1
+    // with tr1_J column slots (null: none)
+    float *img1 = nullptr, *img2 = nullptr, *timg1 = nullptr, *timg2 = nullptr, *tr1 = nullptr, *tr2 = nullptr;
+    int tr1_r0 = 0, tr1_J = 0;
     int64_t img_n1 = 0, img_o2 = 0;
 };
 

@@ -968,6 +968,8 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
                     const int64_t q = in1 ? i : i - s.img_o2, k = q >> 8, j = q & 255;
                     const int64_t at = (((k >> 2) << 8) + j) * 4 + (k & 3);
                     (in1 ? s.img1 : s.img2)[at] = pi;
+                    if (!in1) s.tr2[(((j >> 2) << 8) + k) * 4 + (j & 3)] = pi;
+                    else if (s.tr1 && k >= s.tr1_r0) s.tr1[((j >> 2) * (int64_t)s.tr1_J + k - s.tr1_r0) * 4 + (j & 3)] = pi;
                     if (s.targ) (in1 ? s.timg1 : s.timg2)[at] = ti;
                 }
             }

@@ -12,6 +12,8 @@ namespace wide {
 constexpr int kH = 256;     // hidden width (both layers)
 constexpr int kRows = 16;   // batch rows per workgroup
 constexpr int kMaxIn = 416; // widest network input (a multiple of 32)
+// floats of a transposed image with J column slots per k-group (Net::W1t / W2t)
+inline size_t timage_floats(int J) { return (size_t)(kH / 4) * J * 4; }
 
 struct Net {   // leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat parameter vector)
     const float *W1, *b1, *W2, *b2, *W3, *b3;
@@ -19,6 +21,13 @@ struct Net {   // leaky-ReLU net, h1 = h2 = 256 (device pointers into a flat par
     // k-interleaved images of W1 / W2 for the forward products (launch_pack writes them from W1 / W2 at the head of
     // every launch sequence: element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3), packed_rows(in) / 256 rows)
     const float *W1p = nullptr, *W2p = nullptr;
+    // images for the backward products (B[k][j] = W[j][k]): the k-interleaved image of the TRANSPOSE, element
+    // (row j, column k) of W at ((k >> 2) * J + j) * 4 + (k & 3) — the same loader as the forward products, 16 lanes
+    // reading 256 contiguous bytes.  (Straight from the parameter vector the 16 lanes of a quarter wave read 16
+    // different rows: one cache line per lane, 64 tag lookups per wave-wide load instead of 16 — 1.0 us per stage
+    // against 0.65.)  W2t: J = 256, all of W2.  W1t: what the role needs — reward net: J = 512, all rows of W1
+    // (the input gradient of the gradient penalty); critic: J = 256, rows ob .. ob + ac - 1 (dQ/da); actor: none.
+    const float *W1t = nullptr, *W2t = nullptr;
     // LayerNorm behind each hidden activation (networks.py:53-70, network_util.py:32-39), null without it; all
     // networks of a learner carry it or none does (hps.with_layernorm)
     const float *be1 = nullptr, *ga1 = nullptr, *be2 = nullptr, *ga2 = nullptr;
@@ -102,8 +111,10 @@ bool supported(const samx_mlp* actor, const samx_mlp* critic, const samx_mlp* re
 int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t st);
 // rows of the k-interleaved image of a [K][256] matrix (whole 32-deep stages; the rows beyond K are zero)
 inline int packed_rows(int K) { return (K + 31) / 32 * 32; }
-// k-interleaved images of up to 10 matrices in ONE launch: dst[i] (packed_rows(K[i]) * 256 floats) from W[i] ([K[i]][256])
-int launch_pack(const float* const* W, float* const* dst, const int* K, int n, hipStream_t st);
+// images of up to 16 matrices in ONE launch, from W[i] ([K[i]][256]): J[i] = 0: the k-interleaved image
+// (dst[i]: packed_rows(K[i]) * 256 floats); J[i] > 0: the transposed image with J[i] column slots (dst[i]:
+// timage_floats(J[i]) floats, slots 0 .. K[i] - 1 written)
+int launch_pack(const float* const* W, float* const* dst, const int* K, const int* J, int n, hipStream_t st);
 // TD targets only: the 1-step targets of the sampled rows into a->targ_q and, with a->n_idx, the n-step targets
 // into a->targ_qn (de-normalised with the CURRENT return statistics, sam_agent.py:196-205)
 int launch_targets(const AgentArgs* a, hipStream_t st);

@@ -106,9 +106,10 @@ __device__ __forceinline__ int64_t ring_row(const int64_t* idx, int64_t start, i
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte-aligned address
 
 // one layer product's weight operand:
-//   nt = false: B[k][j] = W[k][jg0 + j] of a [K][256] matrix, read from its K-INTERLEAVED IMAGE (pack_kernel):
-//               element (k, j) at ((k >> 2) * 256 + j) * 4 + (k & 3), rows up to 32 ceil(K / 32) present (zero)
-//   nt = true : B[k][j] = W[(jg0 + j) * ldw + k], rows jg0 + j < N (clamped), straight from the parameter vector
+//   B[k][j] = the element at ((k >> 2) * ldw + jg0 + j) * 4 + (k & 3) of a K-INTERLEAVED IMAGE (pack_kernel):
+//   forward products (w_nn): the image of a [K][256] matrix, ldw = 256, rows up to 32 ceil(K / 32) present (zero);
+//   backward products (w_t): the image of the TRANSPOSE, ldw = its column slots (Net::W1t / W2t), K = 256; slots
+//   beyond the matrix hold anything — what they produce is never stored
 // nvalid: number of valid output columns (16-column blocks that start beyond it are skipped)
 struct WDesc {
     const float* W;
@@ -143,8 +144,7 @@ __device__ __forceinline__ int opaque_lane() {
 // shared ring bought nothing and cost a 32 KB LDS write burst, 32 KB of fragment reads and a workgroup barrier per
 // 32-deep stage.  Each wave loads ITS fragments straight from L2 into registers, in MFMA layout, with 16-byte loads:
 // lane (r = lane & 15, kq = lane >> 4) needs B[32 t + 16 g + 4 kq + m][64 w + 16 nb + r] for m = 0..3 —
-//   NT products (backward): four consecutive floats of row (jg0 + 64 w + 16 nb + r) of W as it lies in the
-//       parameter vector;
+//   NT products (backward): the same, from the k-interleaved image of the transpose (Net::W1t / W2t);
 //   NN products (forward): four consecutive floats of the k-interleaved image of W that pack_kernel writes at the
 //       head of the launch sequence (a transposition inside blocks of 4 rows: 3.3 MB for the five networks).
 // Eight loads per wave and stage, NSET - 1 stages in flight; the only barriers left are the two around a product
@@ -174,21 +174,12 @@ __device__ __forceinline__ void wpipe_init(WPipe& p) { p.s = 0; p.primed = false
 __device__ __forceinline__ void bstage_load(BFrag& f, const WDesc& d, int t) {
     const int lane = opaque_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
-    if (!d.nt) {
-        const unsigned off = (unsigned)((kq * H + 16 * NB * wv + r) * 4);
+    const unsigned off = (unsigned)((kq * d.ldw + 16 * NB * wv + r) * 4);   // (ldw: a constant at every call site)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            glb_float* base = uniform_ptr(d.W + ((int64_t)(8 * t + 4 * g) * H + d.jg0) * 4);
+    for (int g = 0; g < 2; ++g) {
+        glb_float* base = uniform_ptr(d.W + ((int64_t)(8 * t + 4 * g) * d.ldw + d.jg0) * 4);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) f.b[g][nb] = load16(base + nb * 64, off);
-        }
-    } else {
-        const unsigned off = (unsigned)((16 * NB * wv + r) * H + 4 * kq);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                f.b[g][nb] = load16(uniform_ptr(d.W + (int64_t)(d.jg0 + 16 * nb) * H + 32 * t + 16 * g), off);
+        for (int nb = 0; nb < NB; ++nb) f.b[g][nb] = load16(base + nb * 64, off);
     }
 }
 
@@ -291,11 +282,9 @@ __device__ __forceinline__ void for_acc(const f32x4 (&acc)[NB], F f) {
             f((lane >> 4) * 4 + j, 16 * NB * wv + 16 * nb + (lane & 15), acc[nb][j], nb * 4 + j);
 }
 
-// (ldw is H for every product: the loaders use it as a compile-time constant)
 __device__ __forceinline__ WDesc w_nn(const float* W, int K) { return WDesc{W, H, K, H, 0, H, false}; }
-__device__ __forceinline__ WDesc w_nt(const float* W, int N, int jg0, int nvalid) {
-    return WDesc{W, H, H, N, jg0, nvalid, true};
-}
+// backward product through an image of the transpose with J column slots: output columns jg0 .. jg0 + 255
+__device__ __forceinline__ WDesc w_t(const float* Wt, int J, int jg0) { return WDesc{Wt, J, H, H, jg0, H, false}; }
 
 // this lane's bias values in the for_acc mapping (column 16 NB wv + 16 nb + (lane & 15) -> b[nb])
 struct BiasRegs { float b[NB]; };
@@ -875,7 +864,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     wpipe_init(pipe);
     const WDesc ta1 = w_nn(a.targ_actor.W1p, ob), ta2 = w_nn(a.targ_actor.W2p, H);
     const WDesc tc1 = w_nn(a.targ_critic.W1p, in_c), tc2 = w_nn(a.targ_critic.W2p, H);
-    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_nt(a.critic.W2, H, 0, H);
+    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_t(a.critic.W2t, H, 0);
     const bool ext = a.ext_tq != nullptr;   // the targets were computed ahead (launch_targets)
     if (cw && tid < R) {
         L.iw[tid] = a.iws ? a.iws[row0 + tid] : 1.f;
@@ -1026,9 +1015,9 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     const int64_t pr = ring_row(a.idx, a.ring_start, a.ring_len, row0 + (tid >> 5));
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc a1 = w_nn(a.actor.W1p, ob), a2 = w_nn(a.actor.W2p, H), a3 = w_nt(a.actor.W2, H, 0, H);
-    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_nt(a.critic.W2, H, 0, H);
-    const WDesc c4 = w_nt(a.critic.W1 + (int64_t)ob * H, ac, 0, ac);   // rows ob .. ob+ac of W1c: dQ/da
+    const WDesc a1 = w_nn(a.actor.W1p, ob), a2 = w_nn(a.actor.W2p, H), a3 = w_t(a.actor.W2t, H, 0);
+    const WDesc c1 = w_nn(a.critic.W1p, in_c), c2 = w_nn(a.critic.W2p, H), c3 = w_t(a.critic.W2t, H, 0);
+    const WDesc c4 = w_t(a.critic.W1t, H, 0);   // rows ob .. ob+ac of W1c: dQ/da
     if (cw) WTRACE(wg, 1, 0);
     load_rows_first(L, k32c, a.obs0, nullptr, a.mean, a.stdv, ob, ac, 0, pr, a.Xa, row0 + (tid >> 5), in_c);
     for (int t = tid; t < R * PP; t += NT) L.PRE[t] = 0.f;
@@ -1174,7 +1163,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     const int k32 = ((in + 31) / 32) * 32;
     WPipe pipe;
     wpipe_init(pipe);
-    const WDesc d1 = w_nn(n.W1p, in), d2 = w_nn(n.W2p, H), d3 = w_nt(n.W2, H, 0, H);
+    const WDesc d1 = w_nn(n.W1p, in), d2 = w_nn(n.W2p, H), d3 = w_t(n.W2t, H, 0);
     const int tsec = sect == 2 ? 0 : (sect == 0 ? 2 : 4);
     (void)tsec;   // only the SAMX_TRACE build reads it
     if (cw) WTRACE(wg % tiles_b, 2, tsec);
@@ -1335,7 +1324,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         // two tangent LayerNorms.  HBM rows: hP = [2B, 3B) the primal stream (X = x, A1 = n1,
         // DZ* = P_z*), hT = [3B, 4B) the tangent stream (X = V, A1 = ndot1, DZ* = T_z*).
         const int64_t hP = hrow0, hT = hrow0 + a.B;
-        const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
+        const WDesc g0 = w_t(n.W1t, 2 * H, 0), g1 = w_t(n.W1t, 2 * H, H);
         const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
         const unsigned m1 = hidden_fwd_ln<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, n.be1, n.ga1, L.ring, L.T1, a.XH1,
                                               a.A1, hP, rs1);
@@ -1479,7 +1468,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     // ---- interpolate rows: g = d score / d input, sum g^2, V = g / (B dim), tangent forward along V.
     // The scalar k = 10 * 2 (N - 1) / N needs every tile's sums: it is applied to these rows' share of the
     // weight gradients after this launch, not here.
-    const WDesc g0 = w_nt(n.W1, in, 0, in < H ? in : H), g1 = w_nt(n.W1, in, H, in - H);
+    const WDesc g0 = w_t(n.W1t, 2 * H, 0), g1 = w_t(n.W1t, 2 * H, H);
     const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
 #define DTR(i) do { if (cw) WTRACE(wg, 2, 6 + (i)); } while (0)   // interpolate tile 0: phase stamps 6 ..
     DTR(0);
@@ -1656,11 +1645,12 @@ __global__ __launch_bounds__(NT, 1) void targets_kernel(AgentArgs a, int tiles) 
 }
 
 // k-interleaved image of a [K][256] matrix (see WDesc); rows beyond K are zero.
-constexpr int kPackMax = 10;
+constexpr int kPackMax = 16;
 struct PackArgs {
     const float* W[kPackMax];
     float* dst[kPackMax];
     int K[kPackMax];
+    int J[kPackMax];      // 0: k-interleaved image; > 0: transposed image with J column slots
     int first[kPackMax + 1];
     int n;
 };
@@ -1677,6 +1667,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     for (int m = 0; m < 4; ++m) {
         const int k = 4 * kg + m;
         r[m] = k < K ? *(const f32x4u*)(W + (int64_t)k * H + j0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.J[p]) {   // transposed image: (row, columns j0 .. j0 + 3) is one 16-byte element, the four rows contiguous
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (4 * kg + m < K) *(f32x4*)(a.dst[p] + ((int64_t)(j0 >> 2) * a.J[p] + 4 * kg + m) * 4) = r[m];
+        return;
     }
     float* o = a.dst[p] + ((int64_t)kg * H + j0) * 4;
 #pragma unroll
@@ -1747,7 +1743,7 @@ int launch_roles(const AgentArgs* a, const DiscArgs* d, int roles, hipStream_t s
     return SAMX_OK;
 }
 
-int launch_pack(const float* const* W, float* const* dst, const int* K, int n, hipStream_t st) {
+int launch_pack(const float* const* W, float* const* dst, const int* K, const int* J, int n, hipStream_t st) {
     SAMX_REQUIRE(n >= 0 && n <= kPackMax, "wide::launch_pack: 0..%d matrices", kPackMax);
     if (n == 0) return SAMX_OK;
     PackArgs a;
@@ -1755,7 +1751,7 @@ int launch_pack(const float* const* W, float* const* dst, const int* K, int n, h
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         SAMX_REQUIRE(W[i] && dst[i] && K[i] > 0, "wide::launch_pack: matrix %d", i);
-        a.W[i] = W[i]; a.dst[i] = dst[i]; a.K[i] = K[i];
+        a.W[i] = W[i]; a.dst[i] = dst[i]; a.K[i] = K[i]; a.J[i] = J[i];
         a.first[i] = blocks;
         blocks += packed_rows(K[i]) / 16;   // one 256-thread block per 16 rows
     }

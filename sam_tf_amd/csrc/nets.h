@@ -48,7 +48,8 @@ struct WideExt {
 size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B);
 // the weight images inside the reduction workspace: img[n][0 / 1] = W1 / W2 of n = actor, critic, reward net, target
 // actor, target critic (for the optimiser pass that keeps them current)
-int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2]);
+// row[n][0 / 1]: the transposed images (wide::Net::W1t / W2t) of W1 / W2 of n = actor (W2 only), critic, reward net
+int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2], float* row[3][2]);
 // Fills learner.grads, the per-segment sums of squares (sumsq, fused::kMaxSegBlocks per optimiser) and the
 // losses, and ticks the step counters of the roles it ran.  part bit 0: the role launch and the grouped
 // products (with the head-gradient slot sums); bit 1: the reduction that finishes the gradients, with the

@@ -1562,6 +1562,8 @@ struct WideRed {
     // k-interleaved images of W1 / W2 (fused_wide.h: Net::W1p / W2p) of actor, critic, reward net, target actor,
     // target critic — scratch, rewritten from the parameter vectors at the head of every launch sequence
     float* pk[5][2];
+    // transposed images (Net::W1t / W2t) of actor (W2 only), critic, reward net for the backward products
+    float* pt[3][2];
     int ns[9];
     int64_t cnt[9];
     int sw;
@@ -1592,6 +1594,10 @@ WideRed carve_wide_red(Arena& ar, int ob, int ac, int64_t B, bool ln) {
         w.pk[n][0] = ar.take<float>((size_t)wide::packed_rows(kin[n]) * H);
         w.pk[n][1] = ar.take<float>((size_t)H * H);
     }
+    for (int n = 0; n < 3; ++n) {
+        w.pt[n][0] = ar.take<float>(n == 0 ? 1 : wide::timage_floats(n == 2 ? 2 * (int)H : (int)H));
+        w.pt[n][1] = ar.take<float>(wide::timage_floats((int)H));
+    }
     return w;
 }
 }  // namespace
@@ -1602,11 +1608,12 @@ size_t wide_reduce_ws_bytes(const samx_learner* L, int64_t B) {
     return align_up(ar.off, 256) + 256;
 }
 
-int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2]) {
+int wide_images(const samx_learner* L, int64_t B, void* ws_red, size_t red_bytes, float* img[5][2], float* row[3][2]) {
     Arena ar(ws_red, red_bytes);
     WideRed wr = carve_wide_red(ar, L->ob_dim, L->ac_dim, B, L->critic.layernorm != 0);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "wide_images: reduction workspace too small");
     for (int n = 0; n < 5; ++n) { img[n][0] = wr.pk[n][0]; img[n][1] = wr.pk[n][1]; }
+    for (int n = 0; n < 3; ++n) { row[n][0] = wr.pt[n][0]; row[n][1] = wr.pt[n][1]; }
     return SAMX_OK;
 }
 
@@ -1665,16 +1672,24 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
     auto pack = [&](int mask) -> int {   // bit n: network n of [actor, critic, reward, target actor, target critic]
         if (ext && ext->images_current) return SAMX_OK;
         if (ext && ext->pack_all) mask = 0x1F;
-        const float* W[10];
-        float* dst[10];
-        int K[10], n = 0;
+        const float* W[16];
+        float* dst[16];
+        int K[16], J[16], n = 0;
         const int kin[5] = {ob, in, in, ob, in};
         for (int q = 0; q < 5; ++q)
             if (mask & (1 << q)) {
-                W[n] = pk_src[q][0]; dst[n] = wr.pk[q][0]; K[n++] = kin[q];
-                W[n] = pk_src[q][1]; dst[n] = wr.pk[q][1]; K[n++] = H;
+                W[n] = pk_src[q][0]; dst[n] = wr.pk[q][0]; J[n] = 0; K[n++] = kin[q];
+                W[n] = pk_src[q][1]; dst[n] = wr.pk[q][1]; J[n] = 0; K[n++] = H;
+                if (q < 3) {   // transposed images of the networks that run backward (the targets only run forward)
+                    W[n] = pk_src[q][1]; dst[n] = wr.pt[q][1]; J[n] = H; K[n++] = H;
+                    if (q == 1) {   // critic: rows ob .. ob + ac - 1 of W1 (dQ/da)
+                        W[n] = pk_src[q][0] + (int64_t)ob * H; dst[n] = wr.pt[q][0]; J[n] = H; K[n++] = ac;
+                    } else if (q == 2) {   // reward net: all of W1 (the gradient penalty's input gradient)
+                        W[n] = pk_src[q][0]; dst[n] = wr.pt[q][0]; J[n] = 2 * H; K[n++] = in;
+                    }
+                }
             }
-        return wide::launch_pack(W, dst, K, n, st);
+        return wide::launch_pack(W, dst, K, J, n, st);
     };
     wide::AgentArgs a;
     a.wd_part = nullptr; a.wd_blocks = 0;
@@ -1713,6 +1728,8 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         a.critic.W1p = wr.pk[1][0]; a.critic.W2p = wr.pk[1][1];
         a.targ_actor.W1p = wr.pk[3][0]; a.targ_actor.W2p = wr.pk[3][1];
         a.targ_critic.W1p = wr.pk[4][0]; a.targ_critic.W2p = wr.pk[4][1];
+        a.actor.W1t = wr.pt[0][0]; a.actor.W2t = wr.pt[0][1];
+        a.critic.W1t = wr.pt[1][0]; a.critic.W2t = wr.pt[1][1];
         a.ob = ob; a.ac = ac; a.B = B;
         a.high = L->ac_high; a.gamma = L->gamma; a.td_scale = L->td_loss_scale; a.q_scale = L->q_actor_loss_scale;
         a.targ_q = o->targ_q; a.td_out = o->td;
@@ -1788,6 +1805,7 @@ int wide_step_roles(const samx_learner* L, const samx_batch* b, const samx_step_
         d.rng_seed = b->rng_seed; d.rng_step = L->steps + 2; d.label_smoothing = b->label_smoothing;
         d.net = net(nd); d.ob = ob; d.ac = ac; d.B = B; d.ent_scale = L->ent_reg_scale;
         d.net.W1p = wr.pk[2][0]; d.net.W2p = wr.pk[2][1];
+        d.net.W1t = wr.pt[2][0]; d.net.W2t = wr.pt[2][1];
         d.X = w.X; d.A1 = w.h.N1; d.A2 = w.h.N2; d.DZ1 = w.k.DZ1; d.DZ2 = w.k.DZ2;
         d.DS = w.DS; d.ce = w.ce; d.ent = w.ent; d.sg = w.sg; d.gp_part = w.gp_part; d.w3_part = wr.w3d;
         if (ln) { d.XH1 = w.h.XH1; d.XH2 = w.h.XH2; d.TN1 = w.TA1; d.PA1 = w.TA2; }

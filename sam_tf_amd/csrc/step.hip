@@ -5,6 +5,7 @@
 #include "samx_common.h"
 #include "fused_small.h"
 #include "nets.h"
+#include "fused_wide.h"
 #include "tree_dev.h"
 #include "rng.h"
 #include <stdlib.h>
@@ -137,7 +138,7 @@ int check_learner(const samx_learner* L, const char* who) {
 
 // segs: bit k set = optimiser segment k (0 actor, 1 critic, 2 reward net) takes part
 fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, float grad_scale, int segs = 7,
-                            bool polyak = true, float* (*img)[2] = nullptr) {
+                            bool polyak = true, float* (*img)[2] = nullptr, float* (*row)[2] = nullptr) {
     const int64_t Pa = samx_mlp_param_count(&L->actor), Pc = samx_mlp_param_count(&L->critic),
                   Pd = samx_mlp_param_count(&L->reward);
     const int64_t off[3] = {0, Pa, Pa + Pc}, n[3] = {Pa, Pc, Pd};
@@ -167,6 +168,9 @@ fused::ApplyArgs make_apply(const samx_learner* L, const StepWs& w, int mode, fl
             const samx_mlp* dn = k == 0 ? &L->actor : (k == 1 ? &L->critic : &L->reward);
             s.img1 = img[k][0]; s.img2 = img[k][1];
             s.timg1 = k < 2 ? img[3 + k][0] : nullptr; s.timg2 = k < 2 ? img[3 + k][1] : nullptr;
+            s.tr2 = row[k][1];
+            s.tr1 = k == 0 ? nullptr : row[k][0];
+            s.tr1_r0 = k == 1 ? L->ob_dim : 0; s.tr1_J = k == 2 ? 2 * samx::wide::kH : samx::wide::kH;
             s.img_n1 = (int64_t)dn->in_dim * dn->h1;
             s.img_o2 = s.img_n1 + dn->h1 + (dn->layernorm ? 2 * dn->h1 : 0);
         }
@@ -1211,13 +1215,14 @@ int samx_step_apply(const samx_learner* L, int64_t B, int mode, float grad_scale
     StepWs w = carve(ar, L, B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_step_apply: workspace %zu < %zu", ws_bytes, ar.off);
     float* img[5][2];
+    float* row[3][2];
     const bool keep = (mode & 64) && (mode & 2) && use_wide(L, B);   // (bit 6 means nothing on the other paths)
     if (keep) {
         SAMX_REQUIRE(!(mode & 32), "samx_step_apply: mode bit 6 needs the Polyak step in the same pass (no bit 5)");
-        rc = samx::wide_images(L, B, w.wide_red, w.wide_red_bytes, img);
+        rc = samx::wide_images(L, B, w.wide_red, w.wide_red_bytes, img, row);
         if (rc != SAMX_OK) return rc;
     }
-    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs, !(mode & 32), keep ? img : nullptr);
+    fused::ApplyArgs f = make_apply(L, w, mode & 3, grad_scale, segs, !(mode & 32), keep ? img : nullptr, keep ? row : nullptr);
     if (mode & 4) {  // gradients changed since samx_step_grads (all-reduce): recompute the norms
         rc = fused::launch_seg_sumsq(f, st);
         if (rc != SAMX_OK) return rc;
