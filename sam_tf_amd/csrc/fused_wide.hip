@@ -235,6 +235,8 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
                 if (t + i + NSET - 1 < T) bstage_load(f[(i + NSET - 1) % NSET], cur, t + i + NSET - 1);
                 if (t + i + 1 < T) rda(t + i + 1, a[(i + 1) & 1]);
                 if (t + i > 0) WTRACE_STAGE(pipe.s + t + i);
+                // (a sched_barrier here, to keep the stages-ahead requests in front of this stage's MFMAs — the compiler
+                // sinks the activation-fragment reads behind them — measured 8.26 -> 8.22 k steps/s at C4: not kept)
                 mm(a[i & 1], f[i]);
             }
         }
@@ -769,35 +771,63 @@ __device__ __forceinline__ void prod_to_tile(WPipe& pipe, const WDesc cur, const
 }
 
 // actor head on T2: acs = clip(high * tanh(T2 W3 + b3)) into X[:, ob:ob+ac] (and to hbm rows, ld = ob + ac);
-// called by all waves
+// called by all waves.  The 256-deep reduction is split over the eight waves (one or two 16-column blocks x eight or
+// four k ranges), each wave reads its operands in one batch, the partial tiles meet in `part` (2048 floats of LDS
+// that nobody else uses meanwhile: the callers pass T1) and are added in a fixed order.  (Two waves running 64
+// dependent [two LDS reads -> MFMA] steps took 2.6 us.)
+template <int KQ>   // MFMAs per wave: the wave's k range is 4 KQ deep, lane group kq owns KQ consecutive k
+__device__ __forceinline__ f32x4 actor_head_part(const float* T2, const float* slot, int ac, int k0, int jc) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const int kb = k0 + kq * KQ;
+    float av[KQ], bv[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; i += 4) {
+        const f32x4 q = *(const f32x4*)(T2 + r * LDT + kb + i);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[i + m] = q[m];
+    }
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) bv[i] = slot[(kb + i) * ac + jc];
+    f32x4 a4[4];   // four independent chains (a dependent 16x16x4 pair costs 40 cycles), summed at the end
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) a4[i & 3] = mfma4(av[i], bv[i], a4[i & 3]);
+    return (a4[0] + a4[1]) + (a4[2] + a4[3]);
+}
 template <bool CW>
 __device__ __forceinline__ void actor_head(const Lds& L, const Net& n, int ob, int ac, float high,
                                            float* __restrict__ hbm, int64_t row0, float* slot,
-                                           const HeadStage& hs) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-    const float b3v = n.b3[min(16 * wv + r, ac - 1)];   // (ahead of the barrier: its round trip hides behind the head)
+                                           const HeadStage& hs, float* part) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
+    // epilogue mapping: thread t < 256 nblk owns (block t >> 8, row (t >> 4) & 15, column t & 15)
+    const int ecb = tid >> 8, erow = (tid >> 4) & 15, ec = 16 * ecb + (tid & 15);
+    const float b3v = n.b3[min(ec, ac - 1)];   // (ahead of the barrier: its round trip hides behind the head)
     stage_head_commit(hs, ac, slot);
-    if (CW && 16 * wv < ac) {
-        const int jc = min(16 * wv + r, ac - 1);
-        f32x4 a4[4];   // four independent chains (a dependent 16x16x4 pair costs 40 cycles), summed at the end
+    const int nblk = ac > 16 ? 2 : 1;
+    {
+        const int cb = wv & (nblk - 1), kp = nblk == 2 ? wv >> 1 : wv;
+        const int jc = min(16 * cb + r, ac - 1);
+        const f32x4 acc = nblk == 2 ? actor_head_part<16>(L.T2, slot, ac, 64 * kp, jc)
+                                    : actor_head_part<8>(L.T2, slot, ac, 32 * kp, jc);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < H; k += 16)
+        for (int j = 0; j < 4; ++j) part[wv * 256 + ((lane >> 4) * 4 + j) * 16 + r] = acc[j];
+    }
+    bar();
+    if (ecb < nblk && ec < ac) {
+        float sum = 0.f;
+        const int e = erow * 16 + (tid & 15);
+        if (nblk == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a4[i] = mfma4(L.T2[r * LDT + k + 4 * i + kq], slot[(k + 4 * i + kq) * ac + jc], a4[i]);
-        const f32x4 acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        const int c = 16 * wv + (lane & 15);
-        if (c < ac) {
+            for (int kp = 0; kp < 4; ++kp) sum += part[(2 * kp + ecb) * 256 + e];
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = (lane >> 4) * 4 + j;
-                float v = high * tanhf(acc[j] + b3v);
-                v = fminf(fmaxf(v, -high), high);
-                L.X[row * L.px + ob + c] = v;
-                if (hbm) hbm[(row0 + row) * (ob + ac) + ob + c] = v;
-            }
+            for (int kp = 0; kp < 8; ++kp) sum += part[kp * 256 + e];
         }
+        float v = high * tanhf(sum + b3v);
+        v = fminf(fmaxf(v, -high), high);
+        L.X[erow * L.px + ob + ec] = v;
+        if (hbm) hbm[(row0 + erow) * (ob + ac) + ob + ec] = v;
     }
     bar();
 }
@@ -835,7 +865,7 @@ __device__ inline void role_t(const AgentArgs& a, int wg, float* lds, int pass) 
     HeadStage hs;
     stage_head_issue(hs, a.targ_actor.W3, ac);
     hfwd<CW, LN>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
-    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
+    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs, L.T1);
     hfwd<CW, LN>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     HeadRegs hd;
     if (cw) head_issue(hd, a.targ_critic.W3, a.targ_critic.b3);
@@ -899,7 +929,7 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
     stage_head_issue(hs, a.targ_actor.W3, ac);
     hfwd<CW, LN>(pipe, ta2, tc1, true, L.T1, LDT, a.targ_actor, 2, L.ring, L.T2, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 3);
-    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs);
+    actor_head<CW>(L, a.targ_actor, ob, ac, a.high, nullptr, 0, free_slot(L.ring, pipe), hs, L.T1);
     WTRACE(wg, 0, 4);
     hfwd<CW, LN>(pipe, tc1, tc2, true, L.X, L.px, a.targ_critic, 1, L.ring, L.T1, nullptr, nullptr, 0, nullptr);
     WTRACE(wg, 0, 5);
@@ -1028,7 +1058,7 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     HeadStage hs;
     stage_head_issue(hs, a.actor.W3, ac);
     const unsigned m2a = hfwd<CW, LN>(pipe, a2, c1, true, L.T1, LDT, a.actor, 2, L.ring, L.T2, a.A2a, a.XH2a, row0, rs + 16);
-    actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0, free_slot(L.ring, pipe), hs);
+    actor_head<CW>(L, a.actor, ob, ac, a.high, a.Xa, row0, free_slot(L.ring, pipe), hs, L.T1);
     // Q branch: -q_scale * mean Q(obz0, mu(obz0))   (sam_agent.py:412-413)
     const unsigned m1c = hfwd<CW, LN>(pipe, c1, c2, true, L.X, L.px, a.critic, 1, L.ring, L.T1, nullptr, a.XH1q, row0, rs + 32);
     HeadRegs hd;
