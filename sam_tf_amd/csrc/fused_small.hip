@@ -951,6 +951,53 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     }
     __syncthreads();
     const float scale = sh_scale * f.grad_scale, lr_t = sh_lr;
+    if (s.img1) {
+        // 256-wide path with weight images to keep (samx_step_apply mode bit 6): a work item is a QUAD of W1 or W2 —
+        // rows 4 kg .. 4 kg + 3 of one column j, one 16-byte element of the k-interleaved image and of the target's,
+        // four neighbours of the transposed image — or a single element of the rest (biases, LayerNorm, head).
+        // Every element is updated by the same arithmetic as below; only which thread takes it differs.
+        const int64_t K1 = s.img_n1 >> 8, Q1 = ((K1 + 3) >> 2) << 8, Q2 = 64 << 8;
+        const int64_t rest1 = s.img_o2 - s.img_n1, nw = Q1 + Q2 + (s.n - s.img_n1 - 65536);
+        auto upd = [&](int64_t e, float& pnew, float& tnew) {
+            const float gi = s.grad[e] * scale;
+            if (f.mode & 1) s.clipped[e] = gi;
+            float mi = s.m[e], vi = s.v[e];
+            mi = mi + (gi - mi) * (1.f - f.beta1);
+            vi = vi + (gi * gi - vi) * (1.f - f.beta2);
+            pnew = s.param[e] - (mi * lr_t) / (sqrtf(vi) + f.eps);
+            s.m[e] = mi; s.v[e] = vi; s.param[e] = pnew;
+            tnew = 0.f;
+            if (s.targ) { tnew = (1.f - f.tau) * s.targ[e] + f.tau * pnew; s.targ[e] = tnew; }
+        };
+        for (int64_t w = (int64_t)b * 256 + tid; w < nw; w += step) {
+            if (w >= Q1 + Q2) {   // a single element outside the two matrices
+                const int64_t r = w - Q1 - Q2;
+                float pn, tn;
+                upd(r < rest1 ? s.img_n1 + r : s.img_o2 + 65536 + (r - rest1), pn, tn);
+                continue;
+            }
+            const bool in1 = w < Q1;
+            const int64_t q = in1 ? w : w - Q1, kg = q >> 8, j = q & 255;
+            const int64_t base = in1 ? 0 : s.img_o2, rows = in1 ? K1 : 256;
+            float pn[4] = {0.f, 0.f, 0.f, 0.f}, tn[4] = {0.f, 0.f, 0.f, 0.f};
+            // (the four updates are independent: their loads are in flight together)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (4 * kg + m < rows) upd(base + ((4 * kg + m) << 8) + j, pn[m], tn[m]);
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const int64_t at = ((kg << 8) + j) * 4;
+            *(f4*)((in1 ? s.img1 : s.img2) + at) = f4{pn[0], pn[1], pn[2], pn[3]};
+            if (s.targ) *(f4*)((in1 ? s.timg1 : s.timg2) + at) = f4{tn[0], tn[1], tn[2], tn[3]};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int64_t k = 4 * kg + m;
+                if (k >= rows) continue;
+                if (!in1) s.tr2[(((j >> 2) << 8) + k) * 4 + (j & 3)] = pn[m];
+                else if (s.tr1 && k >= s.tr1_r0) s.tr1[((j >> 2) * (int64_t)s.tr1_J + k - s.tr1_r0) * 4 + (j & 3)] = pn[m];
+            }
+        }
+        return;
+    }
     for (; i < s.n; i += step) {
         const float gi = g0 * scale;
         if (f.mode & 1) s.clipped[i] = gi;
@@ -960,19 +1007,7 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
             vi = vi + (gi * gi - vi) * (1.f - f.beta2);
             const float pi = p0 - (mi * lr_t) / (sqrtf(vi) + f.eps);
             s.m[i] = mi; s.v[i] = vi; s.param[i] = pi;
-            const float ti = (1.f - f.tau) * t0 + f.tau * pi;
-            if (s.targ) s.targ[i] = ti;
-            if (s.img1) {   // 256-wide path: the forward products' weight images follow the update
-                const bool in1 = i < s.img_n1, in2 = i >= s.img_o2 && i < s.img_o2 + 65536;
-                if (in1 || in2) {
-                    const int64_t q = in1 ? i : i - s.img_o2, k = q >> 8, j = q & 255;
-                    const int64_t at = (((k >> 2) << 8) + j) * 4 + (k & 3);
-                    (in1 ? s.img1 : s.img2)[at] = pi;
-                    if (!in1) s.tr2[(((j >> 2) << 8) + k) * 4 + (j & 3)] = pi;
-                    else if (s.tr1 && k >= s.tr1_r0) s.tr1[((j >> 2) * (int64_t)s.tr1_J + k - s.tr1_r0) * 4 + (j & 3)] = pi;
-                    if (s.targ) (in1 ? s.timg1 : s.timg2)[at] = ti;
-                }
-            }
+            if (s.targ) s.targ[i] = (1.f - f.tau) * t0 + f.tau * pi;
         }
         const int64_t nx = i + step;
         if (nx < s.n) {
