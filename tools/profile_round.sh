@@ -35,6 +35,10 @@ python3 profiles/summarize_rocpd.py $DB4 > $O/${R}_c4_bench_kernel_stats.txt || 
 python3 profiles/timeline_rocpd.py $DB4 roles_kernel 100 > $O/${R}_c4_step_timeline.txt || exit 1
 grep "^{\"metric\"" $O/c4_bench.log | tail -1 > $O/${R}_bench_c4_under_rocprof.json
 rm -f $DB4
+DB4L=$(prof c4l --config C4 --launcher --steps 300 --warmup 50 --no-training-step) || exit 1
+python3 profiles/summarize_rocpd.py $DB4L > $O/${R}_c4_launcher_kernel_stats.txt || exit 1
+python3 profiles/timeline_rocpd.py $DB4L targets_kernel 100 > $O/${R}_c4_launcher_step_timeline.txt || exit 1
+rm -f $DB4L
 for C in C3 C5; do
   c=$(echo $C | tr A-Z a-z)
   N=$([ $C = C5 ] && echo 60 || echo 500)
