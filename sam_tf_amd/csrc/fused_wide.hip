@@ -223,7 +223,9 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
         for (int u = 0; u < NSET - 1; ++u)
             if (u < T) bstage_load(f[u], cur, u);
     }
-    bar();   // the activation tile is complete
+    // (No barrier here: every caller has one between the last write of the activation tile and this call — the
+    // epilogue of the product in front, a row / LayerNorm mini-phase, the action head — and nothing but requests
+    // and register work in between.)
     WTRACE_STAGE(pipe.s);
     AFrag a[2];
     rda(0, a[0]);
@@ -252,7 +254,8 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
 
 // acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for wave w's four 16-column blocks; A in LDS with pitch lda (a
 // multiple of 4) and zeros in the columns [K, 32 ceil(K/32)).  Called by ALL waves.
-// Ends with a barrier: afterwards every wave is done with A.
+// Starts WITHOUT a barrier (the caller's last barrier must follow the last write of A) and ends with one: afterwards
+// every wave is done with A.
 template <bool CW>
 __device__ __forceinline__ void wprod(WPipe& pipe, const WDesc cur, const WDesc next, bool has_next, const float* A,
                                       int lda, float* ring, f32x4 (&acc)[NB]) {

@@ -1551,7 +1551,9 @@ __global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
 }
 
 int wide_nsplit(int64_t R) {   // reduction chunks of 512 rows: 16 stages per workgroup
-    int64_t n = (R + 511) / 512;
+    static int chunk = 0;   // SAMX_WIDE_CHUNK: rows per chunk (measurement aid)
+    if (!chunk) { const char* e = getenv("SAMX_WIDE_CHUNK"); chunk = e ? atoi(e) : 512; if (chunk < 32) chunk = 512; }
+    int64_t n = (R + chunk - 1) / chunk;
     return (int)(n < 2 ? 2 : n);
 }
 // float layout of the reduction workspace: head slots (critic, D), then one partials buffer per product
