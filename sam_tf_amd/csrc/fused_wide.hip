@@ -249,7 +249,9 @@ __device__ __forceinline__ void wcompute_run(WPipe& pipe, const WDesc cur, const
         for (int u = 0; u < PRE; ++u)
             if (u < Tn) bstage_load(pipe.pre[u], next, u);
     }
-    bar();   // every wave is done with the activation tile
+    // every wave is done with the activation tile.  (Needed only where the epilogue overwrites that tile; leaving it
+    // out everywhere else measured neutral — C4 8.46 -> 8.43 k, launcher options 5.14 -> 5.16 k — and is not done.)
+    bar();
 }
 
 // acc[nb] (+)= A[16][K] * B[K][64 w + 16 nb .. +16) for wave w's four 16-column blocks; A in LDS with pitch lda (a
