@@ -141,6 +141,62 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(
     for_rows_cols(tot, w, body);
 }
 
+// The same with the interpolation weights and the labels drawn here (src.draw): a work item is FOUR consecutive
+// elements of one of the two weight tensors — one Philox evaluation (rng.h: counter = element / 4) — or one row's
+// labels.  (One Philox per element was 9.6 M evaluations per step at C5.)
+__global__ __launch_bounds__(256) void disc_prep_draw_kernel(
+    const float* __restrict__ p_obs, const float* __restrict__ p_acs, const float* __restrict__ e_obs,
+    const float* __restrict__ e_acs, const float* __restrict__ mean, const float* __restrict__ stdv, int64_t B, int ob,
+    int ac, float* __restrict__ X, DiscSrc src) {
+    const int w = ob + ac;
+    const uint64_t st = (uint64_t)src.step_dev[0];
+    const int64_t e0 = src.e_start ? src.e_start[0] : 0;
+    const int64_t n_ob = B * ob, n_ac = B * ac, g_ob = (n_ob + 3) >> 2, g_ac = (n_ac + 3) >> 2;
+    const int64_t nw = g_ob + g_ac + B;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nw; t += (int64_t)gridDim.x * blockDim.x) {
+        if (t >= g_ob + g_ac) {
+            const int64_t row = t - g_ob - g_ac;
+            if (src.real_out) src.real_out[row] = real_label(philox_uniform(src.rng_seed, st, RNG_REAL, (uint64_t)row));
+            if (src.fake_out) src.fake_out[row] = fake_label(philox_uniform(src.rng_seed, st, RNG_FAKE, (uint64_t)row));
+            continue;
+        }
+        const bool isob = t < g_ob;
+        const int64_t grp = isob ? t : t - g_ob, n = isob ? n_ob : n_ac;
+        const int cw = isob ? ob : ac;
+        float u[4];
+        philox_uniform4(src.rng_seed, st, isob ? RNG_EPS_OB : RNG_EPS_AC, (uint64_t)grp, u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t el = 4 * grp + i;
+            if (el >= n) break;
+            const int64_t row = el / cw;
+            const int cc = (int)(el - row * cw);
+            int64_t pr = row;
+            if (src.p_idx) {
+                pr = src.ring_start + src.p_idx[row];
+                if (pr >= src.ring_len) pr -= src.ring_len;
+            }
+            const int64_t er = e0 + row;
+            float pv, ev;
+            if (isob) {
+                pv = p_obs[pr * ob + cc];
+                ev = e_obs[er * ob + cc];
+                if (mean) {
+                    pv = fminf(fmaxf((pv - mean[cc]) / stdv[cc], -5.f), 5.f);
+                    ev = fminf(fmaxf((ev - mean[cc]) / stdv[cc], -5.f), 5.f);
+                }
+            } else {
+                pv = p_acs[pr * ac + cc];
+                ev = e_acs[er * ac + cc];
+            }
+            const int c = isob ? cc : ob + cc;
+            X[row * w + c] = pv;
+            X[(B + row) * w + c] = ev;
+            X[(2 * B + row) * w + c] = u[i] * pv + (1.f - u[i]) * ev;
+        }
+    }
+}
+
 enum HeadMode { HEAD_Q, HEAD_TARG, HEAD_TD, HEAD_CRITIC, HEAD_ACTOR_Q, HEAD_DISC, HEAD_REWARD };
 
 struct HeadArgs {
@@ -1235,8 +1291,12 @@ int disc_grad_src(const samx_mlp* dd, const float* pd, const float* p_obs, const
     Net d = split(dd, pd);
     const int ob = ob_dim, ac = d.in - ob_dim;
     const float gp_coeff = 10.f;  // discriminator.py:154
-    disc_prep_kernel<<<grid1d(B * d.in), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, mean,
-                                                      stdv, B, ob, ac, w.X, src);
+    if (src.draw)
+        disc_prep_draw_kernel<<<grid1d((B * d.in + 3) / 4 + B + 2), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, mean, stdv, B,
+                                                                              ob, ac, w.X, src);
+    else
+        disc_prep_kernel<<<grid1d(B * d.in), 256, 0, st>>>(p_obs, p_acs, e_obs, e_acs, eps_ob, eps_ac, mean,
+                                                          stdv, B, ob, ac, w.X, src);
     SAMX_LAUNCH_CHECK();
     if (src.draw) { real_labels = src.real_out; fake_labels = src.fake_out; }
 
