@@ -1,7 +1,8 @@
 // Role-fused forward + input-gradient kernel for 256x256 networks (fused_wide.hip): one workgroup runs a
 // role's whole chain of layer products for 16 batch rows with the activations in LDS and the weights
-// streamed through an LDS-DMA ring; what the weight-gradient products need (layer inputs and
-// pre-activation cotangents) is written to HBM, where ONE grouped launch reduces it over the batch.
+// loaded by each wave straight from L2 into MFMA registers (k-interleaved images); what the weight-gradient
+// products need (layer inputs and pre-activation cotangents) is written to HBM, where ONE grouped launch
+// reduces it over the batch.
 #pragma once
 #include "samx_common.h"
 #include "../../include/samx.h"

@@ -1,10 +1,10 @@
 // Role-fused kernel for 256x256 leaky-ReLU networks (Humanoid-shaped configuration: ob 376, ac 17,
 // batch 1024).  One workgroup owns 16 batch rows and runs the ENTIRE chain of layer products of its role
-// for them.  It has 8 waves, two per SIMD: waves 0-3 COMPUTE (fragment reads, MFMAs, epilogues), waves 4-7
-// LOAD (they stream the weights global -> registers -> LDS ring and do nothing else), so a SIMD always has
-// a wave that can issue while the other waits for memory.  Both halves are instantiated from the SAME role
-// source (template parameter CW) and therefore meet at the same barriers; everything that is not the weight
-// stream is compiled only into the compute half (`if (cw)`), which also keeps the two halves' registers apart.
+// for them.  It has 8 waves, two per SIMD, and every wave computes: wave w owns the output columns
+// [32 w, 32 w + 32) of every product (two 16x16 accumulator blocks), loads ITS weight fragments straight from L2
+// into registers in MFMA layout (the weights never touch LDS: each element is used by one wave, once per tile),
+// and runs its share of every epilogue.  The row code (input gather, normalisation) runs on all 512 threads, the
+// LayerNorm mini-phases and the 1-wide heads on the 256 "row threads" of waves 0-3.
 // Roles:
 //   TC  target actor + target critic on obs1 -> TD target, then the online critic on (obs0, acs): forward,
 //       huber loss, backward to the first pre-activation            (sam_agent.py:196-205,457-520)
@@ -13,19 +13,17 @@
 //   D   policy / expert rows: forward, BCE terms, backward; interpolate rows: forward, input gradient g,
 //       its squared sums, V = g / (B dim) and the tangent forward along V (gradient penalty)
 //                                                                   (discriminator.py:77-161)
-// Activations stay in LDS ([16][260] tiles); the 256x256 weight matrices do not fit next to them, so every
-// product streams its weights through a ring of three 32-deep LDS stages filled through registers (16-byte
-// global loads issued two stages ahead, written to LDS behind the MFMAs of the current stage).  All matmuls
-// are v_mfma_f32_16x16x4_f32 (exact f32).  A layer's k index is visited in the order
-// k = 32 t + 16 g + 4 (lane >> 4) + m so that the activation fragment is ONE ds_read_b128 per four MFMAs.
+// Activations stay in LDS ([16][260] tiles).  All matmuls are v_mfma_f32_16x16x4_f32 (exact f32).  A layer's k
+// index is visited in the order k = 32 t + 16 g + 4 (lane >> 4) + m so that the activation fragment is ONE
+// ds_read_b128 per four MFMAs and the weight fragment ONE 16-byte global load per four MFMAs — from a
+// k-interleaved image of the matrix (forward products) or of its transpose (backward products), element (k, j) at
+// ((k >> 2) * J + j) * 4 + (k & 3): pack_kernel writes the images from the parameter vectors, the optimiser pass
+// keeps them current inside a multi-row launch (fused_small.hip apply_kernel, samx_step_apply mode bit 6).
 // What the weight-gradient products need — layer inputs and pre-activation cotangents — is written to
-// HBM; they are batch reductions and run as ONE grouped MFMA launch afterwards (wgrad_group.hip).
-//
-// LDS images of a weight stage:
-//   NN (forward, B[k][j] = W[k][j]):  S[32][260]: rows 4 apart shift 16 banks, so the ds_read_b32 of lanes
-//       (j, kq) and (j, kq+1) never meet.
-//   NT (backward, B[k][j] = W[j][k]): S[256][32]: the eight 16-byte chunks of row j are XOR-permuted by
-//       (j >> 1) & 7 on the write and again on the read: one conflict-free ds_read_b128 per four MFMAs.
+// HBM; they are batch reductions and run as ONE grouped MFMA launch afterwards (nets.hip: gemm_group).
+// (History: round 2 streamed the weights through a ring of three 32-deep LDS stages filled by four loader waves;
+// what is left of it here is the name `ring` of the LDS area that now holds the staged action-head matrix, the
+// LayerNorm column-sum scratch and the interpolation weights — free_slot.)
 #include "fused_wide.h"
 #include "rng.h"
 #include <math.h>
@@ -65,13 +63,6 @@ __device__ __forceinline__ float lrelu(float z) { return fmaxf(z, 0.2f * z); }
 __device__ __forceinline__ float dlrelu(float a) { return a >= 0.f ? 1.f : 0.2f; }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ void dma16(const float* g, float* s) {
-    __builtin_amdgcn_global_load_lds((glb_float*)g, (lds_float*)s, 16, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 // Barrier that does not drain the global loads in flight (a __syncthreads() would).  The wait is the BUILTIN
 // (vmcnt 63, expcnt 7, lgkmcnt 0) so that the compiler's wait-count bookkeeping sees it: behind an inline-asm

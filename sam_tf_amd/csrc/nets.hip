@@ -105,19 +105,14 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(
     int64_t B, int ob, int ac, float* __restrict__ X, DiscSrc src) {
     const int w = ob + ac;
     const int64_t tot = B * w;
-    const uint64_t st = src.draw ? (uint64_t)src.step_dev[0] : 0;
     const int64_t e0 = src.e_start ? src.e_start[0] : 0;
-    auto body = [&](int64_t row, int c) {
+    auto body = [&](int64_t row, int c) {   // (injected weights; drawn ones: disc_prep_draw_kernel)
         int64_t pr = row;
         if (src.p_idx) {
             pr = src.ring_start + src.p_idx[row];
             if (pr >= src.ring_len) pr -= src.ring_len;
         }
         const int64_t er = e0 + row;
-        if (src.draw && c == 0) {
-            if (src.real_out) src.real_out[row] = real_label(philox_uniform(src.rng_seed, st, RNG_REAL, (uint64_t)row));
-            if (src.fake_out) src.fake_out[row] = fake_label(philox_uniform(src.rng_seed, st, RNG_FAKE, (uint64_t)row));
-        }
         float p, e, eps;
         if (c < ob) {
             p = p_obs[pr * ob + c];
@@ -126,13 +121,11 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(
                 p = fminf(fmaxf((p - mean[c]) / stdv[c], -5.f), 5.f);
                 e = fminf(fmaxf((e - mean[c]) / stdv[c], -5.f), 5.f);
             }
-            eps = src.draw ? philox_uniform(src.rng_seed, st, RNG_EPS_OB, (uint64_t)(row * ob + c))
-                           : eps_ob[row * ob + c];
+            eps = eps_ob[row * ob + c];
         } else {
             p = p_acs[pr * ac + (c - ob)];
             e = e_acs[er * ac + (c - ob)];
-            eps = src.draw ? philox_uniform(src.rng_seed, st, RNG_EPS_AC, (uint64_t)(row * ac + (c - ob)))
-                           : eps_ac[row * ac + (c - ob)];
+            eps = eps_ac[row * ac + (c - ob)];
         }
         X[row * w + c] = p;
         X[(B + row) * w + c] = e;
