@@ -930,10 +930,41 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     const int64_t step = (int64_t)s.nblocks * 256;
     const bool adam = f.mode & 2;
     float g0 = 0.f, m0 = 0.f, v0 = 0.f, p0 = 0.f, t0 = 0.f;
-    if (i < s.n) {
+    if (!s.img1 && i < s.n) {
         g0 = s.grad[i];
         if (adam) { m0 = s.m[i]; v0 = s.v[i]; p0 = s.param[i]; if (s.targ) t0 = s.targ[i]; }
     }
+    // 256-wide path with weight images to keep (samx_step_apply mode bit 6): a work item is a QUAD of W1 or W2 —
+    // rows 4 kg .. 4 kg + 3 of one column j, one 16-byte element of the k-interleaved image and of the target's,
+    // four neighbours of the transposed image — or a single element of the rest (biases, LayerNorm, head).
+    // Every element is updated by the same arithmetic as on the plain path; only which thread takes it differs.
+    // As there, the first item's loads go out before the norm / step-size chain.
+    struct Quad { int64_t e[4]; float g[4], m[4], v[4], p[4], t[4]; int n; int64_t kg, j; bool in1, quad; };
+    const int64_t K1 = s.img_n1 >> 8, Q1 = ((K1 + 3) >> 2) << 8, Q2 = 64 << 8;
+    const int64_t rest1 = s.img_o2 - s.img_n1, nw = s.img1 ? Q1 + Q2 + (s.n - s.img_n1 - 65536) : 0;
+    auto fetch = [&](int64_t w, Quad& q) {
+        q.quad = w < Q1 + Q2;
+        q.in1 = w < Q1;
+        if (q.quad) {
+            const int64_t x = q.in1 ? w : w - Q1, base = q.in1 ? 0 : s.img_o2, rows = q.in1 ? K1 : 256;
+            q.kg = x >> 8; q.j = x & 255;
+            q.n = (int)(rows - 4 * q.kg < 4 ? rows - 4 * q.kg : 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) q.e[m] = base + ((4 * q.kg + (m < q.n ? m : 0)) << 8) + q.j;
+        } else {
+            const int64_t r = w - Q1 - Q2;
+            q.n = 1; q.kg = q.j = 0;
+            q.e[0] = q.e[1] = q.e[2] = q.e[3] = r < rest1 ? s.img_n1 + r : s.img_o2 + 65536 + (r - rest1);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {   // (rows beyond the matrix re-read its row 4 kg: never stored)
+            q.g[m] = s.grad[q.e[m]]; q.m[m] = s.m[q.e[m]]; q.v[m] = s.v[q.e[m]]; q.p[m] = s.param[q.e[m]];
+            q.t[m] = s.targ ? s.targ[q.e[m]] : 0.f;
+        }
+    };
+    Quad q0;
+    int64_t w0 = (int64_t)b * 256 + tid;
+    if (s.img1 && w0 < nw) fetch(w0, q0);
     double acc = 0.0;
     for (int k = tid; k < s.nsumsq; k += 256) acc += (double)s.sumsq[k];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -952,49 +983,37 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     __syncthreads();
     const float scale = sh_scale * f.grad_scale, lr_t = sh_lr;
     if (s.img1) {
-        // 256-wide path with weight images to keep (samx_step_apply mode bit 6): a work item is a QUAD of W1 or W2 —
-        // rows 4 kg .. 4 kg + 3 of one column j, one 16-byte element of the k-interleaved image and of the target's,
-        // four neighbours of the transposed image — or a single element of the rest (biases, LayerNorm, head).
-        // Every element is updated by the same arithmetic as below; only which thread takes it differs.
-        const int64_t K1 = s.img_n1 >> 8, Q1 = ((K1 + 3) >> 2) << 8, Q2 = 64 << 8;
-        const int64_t rest1 = s.img_o2 - s.img_n1, nw = Q1 + Q2 + (s.n - s.img_n1 - 65536);
-        auto upd = [&](int64_t e, float& pnew, float& tnew) {
-            const float gi = s.grad[e] * scale;
-            if (f.mode & 1) s.clipped[e] = gi;
-            float mi = s.m[e], vi = s.v[e];
-            mi = mi + (gi - mi) * (1.f - f.beta1);
-            vi = vi + (gi * gi - vi) * (1.f - f.beta2);
-            pnew = s.param[e] - (mi * lr_t) / (sqrtf(vi) + f.eps);
-            s.m[e] = mi; s.v[e] = vi; s.param[e] = pnew;
-            tnew = 0.f;
-            if (s.targ) { tnew = (1.f - f.tau) * s.targ[e] + f.tau * pnew; s.targ[e] = tnew; }
-        };
-        for (int64_t w = (int64_t)b * 256 + tid; w < nw; w += step) {
-            if (w >= Q1 + Q2) {   // a single element outside the two matrices
-                const int64_t r = w - Q1 - Q2;
-                float pn, tn;
-                upd(r < rest1 ? s.img_n1 + r : s.img_o2 + 65536 + (r - rest1), pn, tn);
-                continue;
-            }
-            const bool in1 = w < Q1;
-            const int64_t q = in1 ? w : w - Q1, kg = q >> 8, j = q & 255;
-            const int64_t base = in1 ? 0 : s.img_o2, rows = in1 ? K1 : 256;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int64_t w = w0; w < nw;) {
             float pn[4] = {0.f, 0.f, 0.f, 0.f}, tn[4] = {0.f, 0.f, 0.f, 0.f};
-            // (the four updates are independent: their loads are in flight together)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (4 * kg + m < rows) upd(base + ((4 * kg + m) << 8) + j, pn[m], tn[m]);
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const int64_t at = ((kg << 8) + j) * 4;
-            *(f4*)((in1 ? s.img1 : s.img2) + at) = f4{pn[0], pn[1], pn[2], pn[3]};
-            if (s.targ) *(f4*)((in1 ? s.timg1 : s.timg2) + at) = f4{tn[0], tn[1], tn[2], tn[3]};
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int64_t k = 4 * kg + m;
-                if (k >= rows) continue;
-                if (!in1) s.tr2[(((j >> 2) << 8) + k) * 4 + (j & 3)] = pn[m];
-                else if (s.tr1 && k >= s.tr1_r0) s.tr1[((j >> 2) * (int64_t)s.tr1_J + k - s.tr1_r0) * 4 + (j & 3)] = pn[m];
+                if (m >= q0.n) continue;
+                const int64_t e = q0.e[m];
+                const float gi = q0.g[m] * scale;
+                if (f.mode & 1) s.clipped[e] = gi;
+                float mi = q0.m[m], vi = q0.v[m];
+                mi = mi + (gi - mi) * (1.f - f.beta1);
+                vi = vi + (gi * gi - vi) * (1.f - f.beta2);
+                pn[m] = q0.p[m] - (mi * lr_t) / (sqrtf(vi) + f.eps);
+                s.m[e] = mi; s.v[e] = vi; s.param[e] = pn[m];
+                if (s.targ) { tn[m] = (1.f - f.tau) * q0.t[m] + f.tau * pn[m]; s.targ[e] = tn[m]; }
             }
+            if (q0.quad) {
+                const int64_t at = ((q0.kg << 8) + q0.j) * 4, j = q0.j;
+                *(f4*)((q0.in1 ? s.img1 : s.img2) + at) = f4{pn[0], pn[1], pn[2], pn[3]};
+                if (s.targ) *(f4*)((q0.in1 ? s.timg1 : s.timg2) + at) = f4{tn[0], tn[1], tn[2], tn[3]};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int64_t k = 4 * q0.kg + m;
+                    if (m >= q0.n) continue;
+                    if (!q0.in1) s.tr2[(((j >> 2) << 8) + k) * 4 + (j & 3)] = pn[m];
+                    else if (s.tr1 && k >= s.tr1_r0)
+                        s.tr1[((j >> 2) * (int64_t)s.tr1_J + k - s.tr1_r0) * 4 + (j & 3)] = pn[m];
+                }
+            }
+            w += step;
+            if (w < nw) fetch(w, q0);
         }
         return;
     }
