@@ -1516,30 +1516,25 @@ __global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
     if (b >= f.main_blocks) { wide_losses(f.loss, b - f.main_blocks, shd); return; }
     while (k < f.nseg - 1 && b >= f.seg[k].nblocks) { b -= f.seg[k].nblocks; ++k; }
     const WFinishSeg& s = f.seg[k];
+    // The gradient penalty's scalar k: every wave derives it itself (same loads, same fixed tree).  Its loads go out
+    // here; the shuffles and the float64 arithmetic wait until the first round's partial sums have been requested
+    // (below) — they used to stand in front of those requests, on the segment with the most of them.
     float kgp = 0.f;
-    if (k == f.gp_seg && f.gp_part) {   // every wave derives the scalar itself (same loads, same fixed tree)
-        double so = 0.0, sa = 0.0;
-        for (int i = tid & 63; i < f.gp_tiles; i += 64) { so += f.gp_part[2 * i]; sa += f.gp_part[2 * i + 1]; }
+    const bool want_kgp = k == f.gp_seg && f.gp_part;
+    double gso = 0.0, gsa = 0.0;
+    if (want_kgp)
+        for (int i = tid & 63; i < f.gp_tiles; i += 64) { gso += f.gp_part[2 * i]; gsa += f.gp_part[2 * i + 1]; }
+    auto finish_kgp = [&]() {   // (called where every lane of the wave is active)
+        double so = gso, sa = gsa;
         for (int o = 32; o > 0; o >>= 1) { so += __shfl_xor(so, o, 64); sa += __shfl_xor(sa, o, 64); }
         const double N = sqrt(so / ((double)f.B * f.ob) + sa / ((double)f.B * f.ac));
         kgp = (float)((double)f.gp_coeff * 2.0 * (N - 1.0) / N);
-    }
+    };
+    // every thread of the block runs the first round (uniform): then k can be finished inside it
+    const bool kgp_late = want_kgp && (int64_t)(b + 1) * 256 <= s.n;
+    if (want_kgp && !kgp_late) finish_kgp();
+    bool kgp_pending = kgp_late;
     if (b == 0 && tid == 0 && s.step_dev) s.step_dev[0] += 1;
-    if (k == f.gp_seg && b == 0 && f.rms_sums) {   // same arithmetic as the role kernel's loader
-        const int dim = f.ob;
-        const double cnt = f.rms_sums[2 * dim] + f.rms_addvec[2 * dim];   // every thread reads the old count first
-        __syncthreads();
-        for (int c = tid; c < dim; c += 256) {
-            const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
-                         s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
-            f.rms_sums[c] = s1;
-            f.rms_sums[dim + c] = s2;
-            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
-            f.rms_mean[c] = mean;
-            f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
-        }
-        if (tid == 0) f.rms_sums[2 * dim] = cnt;
-    }
     double acc = 0.0;
     const int64_t stride = (int64_t)s.nblocks * 256;
     constexpr int E = 4;   // elements per thread and round: their partial-sum loads are in flight together
@@ -1585,6 +1580,7 @@ __global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
 #pragma unroll
             for (int e = 0; e < E; ++e) { if (z < n2[e]) u[e] += t0[e]; if (z + 1 < n2[e]) u[e] += t1[e]; }
         }
+        if (kgp_pending) { finish_kgp(); kgp_pending = false; }   // (first round: all lanes are here)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int64_t i = i0 + e * stride;
@@ -1601,6 +1597,23 @@ __global__ __launch_bounds__(256) void wide_finish_kernel(WFinishArgs f) {
     if ((tid & 63) == 0) shd[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) s.sumsq[b] = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
+    // the commit of d.obs_rms (one block; nothing in this launch reads what it writes, so it comes last: its float64
+    // divisions used to delay that block's gradient elements)
+    if (k == f.gp_seg && b == 0 && f.rms_sums) {   // same arithmetic as the role kernel's loader
+        const int dim = f.ob;
+        const double cnt = f.rms_sums[2 * dim] + f.rms_addvec[2 * dim];   // every thread reads the old count first
+        __syncthreads();
+        for (int c = tid; c < dim; c += 256) {
+            const double s1 = __dadd_rn(f.rms_sums[c], f.rms_addvec[c]),
+                         s2 = __dadd_rn(f.rms_sums[dim + c], f.rms_addvec[dim + c]);
+            f.rms_sums[c] = s1;
+            f.rms_sums[dim + c] = s2;
+            const float mean = (float)(s1 / cnt), msq = (float)(s2 / cnt);
+            f.rms_mean[c] = mean;
+            f.rms_std[c] = sqrtf(fmaxf(__fsub_rn(msq, __fmul_rn(mean, mean)), 1e-2f));
+        }
+        if (tid == 0) f.rms_sums[2 * dim] = cnt;
+    }
 }
 
 int wide_nsplit(int64_t R) {   // reduction chunks of 512 rows: 16 stages per workgroup
