@@ -350,11 +350,13 @@ __device__ __forceinline__ void head_grad_slot(const float* T, const float* dq, 
 }
 
 // T[r][c] = dq[r] * w3[c] * lrelu'(T[r][c]) in place, and to hbm
-// (w3c = w3[threadIdx.x], loaded ahead by the caller: thread t only meets column t)
+// (w3c = w3[threadIdx.x & 255], loaded ahead by the caller: thread t only meets column t & 255); called by the
+// first NTH threads of the workgroup (the 256 row threads where head_grad_slot reads the same column first, else all)
+template <int NTH>
 __device__ __forceinline__ void head_bwd(float* T, const float* dq, const float w3c,
                                          float* __restrict__ hbm, int64_t row0) {
-    static_assert(NC == H, "one column per row thread");
-    for (int t = threadIdx.x; t < R * H; t += NC) {
+    static_assert(NTH % H == 0, "one column per thread");
+    for (int t = threadIdx.x; t < R * H; t += NTH) {
         const int r = t >> 8, c = t & 255;
         const float v = dq[r] * w3c * dlrelu(T[r * LDT + c]);
         T[r * LDT + c] = v;
@@ -1008,9 +1010,9 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         return;
     }
     (void)m1; (void)m2; (void)w3c;
-    if (cw) {
+    if (cw) {   // (the same thread reads column t for the head's gradient, then overwrites it: no barrier between)
         head_grad_slot(L.T2, L.dq, a.w3c_part + (int64_t)wg * (H + 1));
-        head_bwd(L.T2, L.dq, w3c, a.DZ2c, row0);
+        head_bwd<NC>(L.T2, L.dq, w3c, a.DZ2c, row0);
     }
     bar();
     WTRACE(wg, 0, 11);
@@ -1387,13 +1389,14 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             }
         }
         bar();
-        if (cw) {
-            const int r = tid >> 4, q = tid & 15;
+        {   // (all threads: 32 per row)
+            const int r = tid >> 5, q = tid & 31;
             float so = 0.f, sa = 0.f;
-            for (int c = q; c < in; c += 16) {
+            for (int c = q; c < in; c += 32) {
                 const float g = L.X[r * L.px + c];
                 if (c < ob) so = fmaf(g, g, so); else sa = fmaf(g, g, sa);
             }
+            so += __shfl_xor(so, 16, 64); sa += __shfl_xor(sa, 16, 64);
             so = sum16(so); sa = sum16(sa);
             if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
         }
@@ -1404,10 +1407,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             a.gp_part[2 * (wg % tiles_b)] = o;
             a.gp_part[2 * (wg % tiles_b) + 1] = c;
         }
-        if (cw) {
+        {   // (all threads: 32 per row)
             const float co = 1.f / ((float)a.B * (float)ob), ca = 1.f / ((float)a.B * (float)ac);
-            const int r = tid >> 4, c0 = tid & 15;
-            for (int c = c0; c < in; c += 16) {
+            const int r = tid >> 5, c0 = tid & 31;
+            for (int c = c0; c < in; c += 32) {
                 const float v = L.X[r * L.px + c] * (c < ob ? co : ca);
                 L.X[r * L.px + c] = v;
                 a.X[(hT + r) * in + c] = v;   // V: the tangent stream's layer input
@@ -1478,7 +1481,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         bar();
         if (cw) {
             head_grad_slot(L.T2, L.dq, a.w3_part + (int64_t)wg * (H + 1));
-            head_bwd(L.T2, L.dq, w3c, a.DZ2, hrow0);
+            head_bwd<NC>(L.T2, L.dq, w3c, a.DZ2, hrow0);
         }
         bar();
         f32x4 acc[NB];
@@ -1505,7 +1508,7 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     DTR(2);
     if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
     bar();
-    if (cw) head_bwd(L.T2, L.dq, w3c, a.DZ2, hrow0);                                             // gz2
+    head_bwd<NT>(L.T2, L.dq, w3c, a.DZ2, hrow0);                                                 // gz2 (all threads)
     bar();
     DTR(3);
     {   // gz1 = (gz2 W2^T) .* m1, in place over gz2
@@ -1544,13 +1547,14 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
     }
     bar();
     DTR(6);
-    if (cw) {
-        const int r = tid >> 4, q = tid & 15;
+    {   // (all threads: 32 per row)
+        const int r = tid >> 5, q = tid & 31;
         float so = 0.f, sa = 0.f;
-        for (int c = q; c < in; c += 16) {
+        for (int c = q; c < in; c += 32) {
             const float g = L.X[r * L.px + c];
             if (c < ob) so = fmaf(g, g, so); else sa = fmaf(g, g, sa);
         }
+        so += __shfl_xor(so, 16, 64); sa += __shfl_xor(sa, 16, 64);
         so = sum16(so); sa = sum16(sa);
         if (q == 0) { L.red[r] = so; L.red[16 + r] = sa; }
     }
@@ -1562,10 +1566,10 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         a.gp_part[2 * (wg % tiles_b)] = o;
         a.gp_part[2 * (wg % tiles_b) + 1] = c;
     }
-    if (cw) {
+    {   // (all threads: 32 per row)
         const float co = 1.f / ((float)a.B * (float)ob), ca = 1.f / ((float)a.B * (float)ac);
-        const int r = tid >> 4, c0 = tid & 15;
-        for (int c = c0; c < in; c += 16) {
+        const int r = tid >> 5, c0 = tid & 31;
+        for (int c = c0; c < in; c += 32) {
             const float v = L.X[r * L.px + c] * (c < ob ? co : ca);
             L.X[r * L.px + c] = v;
             a.X[(hrow0 + r) * in + c] = v;   // V takes the interpolates' place among the layer inputs
