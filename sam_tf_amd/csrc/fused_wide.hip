@@ -723,6 +723,9 @@ __device__ __forceinline__ void ln_tan_rows(float* T, const float* __restrict__ 
     }
 }
 
+// (Measured and dropped: the LayerNorm parameters and 1-wide head weights of a role's networks staged in an LDS
+// table at the start of the role, so that no mini-phase reads them from global memory behind a barrier — launcher
+// options at C4 5242 against 5242 steps/s on one box, alternating: those reads are not what a mini-phase waits for.)
 // hidden layer with LayerNorm: T <- n = LN(lrelu(A W + b)); two barriers more than hidden_fwd.  Called by all
 // waves; returns the mask bits of this (compute) thread's elements IN THE ROWS MAPPING.
 template <bool CW>
@@ -1354,20 +1357,27 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         const int64_t hP = hrow0, hT = hrow0 + a.B;
         const WDesc g0 = w_t(n.W1t, 2 * H, 0), g1 = w_t(n.W1t, 2 * H, H);
         const WDesc t1 = w_nn(n.W1p, in), t2 = w_nn(n.W2p, H);
+#define LTR(i) do { if (cw) WTRACE(wg, 2, 6 + (i)); } while (0)   // interpolate tile 0 with LayerNorm: phase stamps 6 ..
+        LTR(0);
         const unsigned m1 = hidden_fwd_ln<CW>(pipe, d1, d2, true, L.X, L.px, n.b1, n.be1, n.ga1, L.ring, L.T1, a.XH1,
                                               a.A1, hP, rs1);
+        LTR(1);
         const unsigned m2 = hidden_fwd_ln<CW>(pipe, d2, d3, true, L.T1, LDT, n.b2, n.be2, n.ga2, L.ring, L.T2, a.XH2,
                                               nullptr, hP, rs2);
+        LTR(2);
         if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
         bar();
         if (cw)   // T_z2: the head's cotangent is w3 (d score = 1)
             ln_bwd_rows<true, false>(L.T2, L.dq, n.W3, n.ga2, a.XH2, hP, rs2, m2, nullptr, a.DZ2, hT, nullptr, 0, nullptr);
         bar();
+        LTR(3);
         prod_to_tile<CW>(pipe, d3, g0, true, L.T2, LDT, L.ring, L.T1);   // T_n1
+        LTR(4);
         if (cw)   // T_z1 in place; T_n1 kept for the tangent LayerNorm of layer 1 (same-thread read-back)
             ln_bwd_rows<false, false>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, nullptr, a.DZ1, hT, a.TN1, row0,
                                       nullptr);
         bar();
+        LTR(5);
         {   // g = T_z1 W1^T, 256 input columns at a time, over X (x is in HBM by now)
             auto put = [&](const f32x4 (&acc)[NB], int j0) {
                 
@@ -1417,13 +1427,17 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             }
         }
         bar();
+        LTR(6);
         prod_to_tile<CW>(pipe, t1, t2, true, L.X, L.px, L.ring, L.T1);   // zdot1 = V W1
+        LTR(7);
         float* scratch = free_slot(L.ring, pipe);
         if (cw)   // ndot1 -> T1 and A1[hT]; PA1 (unmasked) -> HBM; column sums of tn1 u1 (part of dgamma1)
             ln_tan_rows<false>(L.T1, n.ga1, a.XH1, hP, rs1, m1, a.TN1, nullptr, row0, a.A1, hT, a.PA1, scratch);
         bar();
+        LTR(8);
         if (cw) slot[(H + 1) + H + tid] = ln_col4(scratch, 256 + tid);
         prod_to_tile<CW>(pipe, t2, d3, true, L.T1, LDT, L.ring, L.T2);   // zdot2 = ndot1 W2
+        LTR(9);
         scratch = free_slot(L.ring, pipe);
         if (cw)   // P_z2 -> T2 and DZ2[hP]; column sums of ndot2 (-> dW3) and of tn2 u2 (-> dgamma2)
             ln_tan_rows<true>(L.T2, n.ga2, a.XH2, hP, rs2, m2, nullptr, n.W3, row0, a.DZ2, hP, nullptr, scratch);
@@ -1434,7 +1448,9 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             slot[(H + 1) + 3 * H + tid] = ln_col4(scratch, 256 + tid);     // dgamma2
             if (tid == 0) slot[H] = 0.f;
         }
+        LTR(10);
         prod_to_tile<CW>(pipe, d3, d3, false, L.T2, LDT, L.ring, L.T1);   // P_n1 = P_z2 W2^T
+        LTR(11);
         scratch = free_slot(L.ring, pipe);
         if (cw)   // P_z1 = J1(gamma1 P_n1) + PA1, masked -> DZ1[hP]; dbeta1, dgamma1 (P part)
             ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, a.PA1, a.DZ1, hP, nullptr, row0,
@@ -1444,6 +1460,8 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             slot[(H + 1) + tid] = ln_col4(scratch, tid);
             slot[(H + 1) + H + tid] += ln_col4(scratch, 256 + tid);   // (this thread stored the tangent part above)
         }
+        LTR(12);
+        if (cw) WTRACE(wg, 2, 1);
         return;
     }
     if (sect != 2) {

@@ -16,6 +16,8 @@ from sam_tf_amd.comm import TorchComm  # noqa: E402
 
 dev = torch.device('cuda', 0)
 cfg = dict(bench.CONFIGS['C4'])
+if os.environ.get('SAMX_TRACE_LN') == '1':   # with_layernorm nets (D interpolate phases: LTR stamps)
+    cfg['ln'] = True
 mu, d, pool, drv = bench.build_learner(cfg, TorchComm(dev), dev, 0, True)
 drv.prepare(1)
 drv.run(8)
@@ -38,6 +40,9 @@ print('actor role workgroup 0 (start end):', f(ra))
 print('D role first tiles (interpolate start end | policy start end | expert start end):', f(rd))
 print('D interpolate tile 0 phases (fwd1 start, fwd2 start, fwd2 end, head bwd done, gz1 done, g0 done, g done, '
       'sums done, V done, tangent 1 done):', f(acc[5:, 70:80]))
+if os.environ.get('SAMX_TRACE_LN') == '1':
+    print('D interpolate tile 0 with LayerNorm (fwd1 start, fwd2 start, fwd2 end, T_z2 done, T_n1 product done, T_z1 done, '
+          'V done, zdot1 done, tan1 done, zdot2 done, tan2 done, P_n1 done, end):', f(acc[5:, 70:83]))
 print('D interpolate tile 0 prologue (rows issued, weights drawn, statistics staged, barrier passed, half 0, half 1):', f(acc[5:, 80:86]))
 st = acc[5:, 128:]
 n = int((st[0] > 0).sum())
