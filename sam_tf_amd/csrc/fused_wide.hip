@@ -79,6 +79,10 @@ __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
 }
+__device__ __forceinline__ float sum32(float v) {   // over the 32 lanes of a row in the rows mapping
+    v += __shfl_xor(v, 16, 64);
+    return sum16(v);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float sig_ce(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
 
@@ -521,9 +525,9 @@ __device__ __forceinline__ void load_rows_first(const Lds& L, int k32, const flo
 // the ring slot the weight stream leaves free between two products (free_slot) and one more barrier.
 constexpr float kLnEps = 1e-8f;
 constexpr float kInvH = 1.f / (float)H;
-constexpr int LNU = H / 16;
-__device__ __forceinline__ float sum_rows4(float v) {   // over the 4 rows a wave holds in the rows mapping
-    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+constexpr int LNU = H / 32;   // columns per thread: 32 threads per row on all 512 threads (first form: 16 per row on 256)
+__device__ __forceinline__ float sum_rows2(float v) {   // over the 2 rows a wave holds in the rows mapping
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -532,40 +536,40 @@ __device__ __forceinline__ float sum_rows4(float v) {   // over the 4 rows a wav
 __device__ __forceinline__ unsigned ln_fwd_rows(float* T, const float* __restrict__ be, const float* __restrict__ ga,
                                                 float* __restrict__ xh_hbm, float* __restrict__ n_hbm, int64_t grow0,
                                                 float* rs_strip) {
-    const int t = opaque_tid(), r = t >> 4, c0 = t & 15;
+    const int t = opaque_tid(), r = t >> 5, c0 = t & 31;
     float a[LNU], g[LNU], b[LNU];
     float s = 0.f;
     unsigned bits = 0;
 #pragma unroll
-    for (int u = 0; u < LNU; ++u) { g[u] = ga[c0 + 16 * u]; b[u] = be[c0 + 16 * u]; }
+    for (int u = 0; u < LNU; ++u) { g[u] = ga[c0 + 32 * u]; b[u] = be[c0 + 32 * u]; }
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
-        a[u] = T[r * LDT + c0 + 16 * u];
+        a[u] = T[r * LDT + c0 + 32 * u];
         s += a[u];
         bits |= (a[u] >= 0.f ? 1u : 0u) << u;
     }
-    const float mu = sum16(s) * kInvH;
+    const float mu = sum32(s) * kInvH;
     float q = 0.f;
 #pragma unroll
     for (int u = 0; u < LNU; ++u) { const float d = a[u] - mu; q = fmaf(d, d, q); }
-    const float rs = 1.f / sqrtf(sum16(q) * kInvH + kLnEps);
+    const float rs = 1.f / sqrtf(sum32(q) * kInvH + kLnEps);
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
         const float xh = (a[u] - mu) * rs;
         a[u] = xh;
-        T[r * LDT + c0 + 16 * u] = fmaf(g[u], xh, b[u]);
+        T[r * LDT + c0 + 32 * u] = fmaf(g[u], xh, b[u]);
     }
     if (rs_strip && c0 == 0) rs_strip[r] = rs;
     // the HBM copies last (stores count in vmcnt like loads)
     if (xh_hbm) {
         float* o = xh_hbm + (grow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = a[u];
+        for (int u = 0; u < LNU; ++u) o[32 * u] = a[u];
     }
     if (n_hbm) {
         float* o = n_hbm + (grow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = fmaf(g[u], a[u], b[u]);
+        for (int u = 0; u < LNU; ++u) o[32 * u] = fmaf(g[u], a[u], b[u]);
     }
     return bits;
 }
@@ -583,65 +587,65 @@ __device__ __forceinline__ void ln_bwd_rows(float* T, const float* dq, const flo
                                             const float* __restrict__ add_hbm, float* __restrict__ dz_hbm,
                                             int64_t drow0, float* __restrict__ tn_hbm, int64_t trow0,
                                             float* scratch) {
-    const int t = opaque_tid(), r = t >> 4, c0 = t & 15, lane = t & 63, wv = t >> 6;
+    const int t = opaque_tid(), r = t >> 5, c0 = t & 31, lane = t & 63, wv = t >> 6;
     float xh[LNU], dn[LNU], dx[LNU];
     {
         const float* xi = xh_hbm + (grow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) xh[u] = xi[16 * u];
+        for (int u = 0; u < LNU; ++u) xh[u] = xi[32 * u];
     }
     const float rs = rs_strip[r];
     float s1 = 0.f, s2 = 0.f;
     const float dqr = HEAD ? dq[r] : 0.f;
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
-        const int c = c0 + 16 * u;
+        const int c = c0 + 32 * u;
         dn[u] = HEAD ? dqr * w3[c] : T[r * LDT + c];
         dx[u] = dn[u] * ga[c];
         s1 += dx[u];
         s2 = fmaf(dx[u], xh[u], s2);
     }
-    const float m1 = sum16(s1) * kInvH, m2 = sum16(s2) * kInvH;
+    const float m1 = sum32(s1) * kInvH, m2 = sum32(s2) * kInvH;
     float ad[LNU];
     if (add_hbm) {
         const float* ai = add_hbm + (trow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) ad[u] = ai[16 * u];
+        for (int u = 0; u < LNU; ++u) ad[u] = ai[32 * u];
     }
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
         float da = rs * (dx[u] - m1 - xh[u] * m2);
         if (add_hbm) da += ad[u];
         dx[u] = da * ((bits >> u) & 1u ? 1.f : 0.2f);
-        T[r * LDT + c0 + 16 * u] = dx[u];
+        T[r * LDT + c0 + 32 * u] = dx[u];
     }
     if (SLOTS) {
 #pragma unroll
         for (int u = 0; u < LNU; ++u) {
-            const float b = sum_rows4(dn[u]), g = sum_rows4(dn[u] * xh[u]);
-            if (lane < 16) { scratch[wv * 512 + c0 + 16 * u] = b; scratch[wv * 512 + 256 + c0 + 16 * u] = g; }
+            const float b = sum_rows2(dn[u]), g = sum_rows2(dn[u] * xh[u]);
+            if (lane < 32) { scratch[wv * 512 + c0 + 32 * u] = b; scratch[wv * 512 + 256 + c0 + 32 * u] = g; }
         }
     }
     if (dz_hbm) {
         float* o = dz_hbm + (drow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = dx[u];
+        for (int u = 0; u < LNU; ++u) o[32 * u] = dx[u];
     }
     if (tn_hbm) {
         float* o = tn_hbm + (trow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = dn[u];
+        for (int u = 0; u < LNU; ++u) o[32 * u] = dn[u];
     }
 }
-// the four waves' column sums in a fixed order: thread c < 256
-__device__ __forceinline__ float ln_col4(const float* scratch, int o) {
-    return (scratch[o] + scratch[512 + o]) + (scratch[1024 + o] + scratch[1536 + o]);
+// the eight waves' column sums in a fixed order
+__device__ __forceinline__ float ln_col8(const float* scratch, int o) {
+    return ((scratch[o] + scratch[512 + o]) + (scratch[1024 + o] + scratch[1536 + o])) +
+           ((scratch[2048 + o] + scratch[2560 + o]) + (scratch[3072 + o] + scratch[3584 + o]));
 }
 // dst[0..256) = dbeta, dst[256..512) = dgamma (contiguous in the flat layout)
-__device__ __forceinline__ void ln_cols_commit(const float* scratch, float* __restrict__ dst) {
+__device__ __forceinline__ void ln_cols_commit(const float* scratch, float* __restrict__ dst) {   // all threads
     const int t = threadIdx.x;
-    dst[t] = ln_col4(scratch, t);
-    dst[256 + t] = ln_col4(scratch, 256 + t);
+    dst[t] = ln_col8(scratch, t);
 }
 
 // Tangent of lrelu -> LayerNorm along zdot (T holds the raw tangent pre-activation) and the primal cotangent the
@@ -660,26 +664,26 @@ __device__ __forceinline__ void ln_tan_rows(float* T, const float* __restrict__ 
                                             const float* __restrict__ tn_hbm, const float* __restrict__ w3,
                                             int64_t trow0, float* __restrict__ out_hbm, int64_t drow0,
                                             float* __restrict__ pa_hbm, float* scratch) {
-    const int t = opaque_tid(), r = t >> 4, c0 = t & 15, lane = t & 63, wv = t >> 6;
+    const int t = opaque_tid(), r = t >> 5, c0 = t & 31, lane = t & 63, wv = t >> 6;
     float xh[LNU], ad[LNU], ub[LNU], tn[LNU];
     {
         const float* xi = xh_hbm + (grow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) xh[u] = xi[16 * u];
+        for (int u = 0; u < LNU; ++u) xh[u] = xi[32 * u];
         if (!LAYER2) {
             const float* ti = tn_hbm + (trow0 + r) * H + c0;
 #pragma unroll
-            for (int u = 0; u < LNU; ++u) tn[u] = ti[16 * u];
+            for (int u = 0; u < LNU; ++u) tn[u] = ti[32 * u];
         } else {
 #pragma unroll
-            for (int u = 0; u < LNU; ++u) tn[u] = w3[c0 + 16 * u];
+            for (int u = 0; u < LNU; ++u) tn[u] = w3[c0 + 32 * u];
         }
     }
     const float rs = rs_strip[r];
     float s1 = 0.f, s2 = 0.f, sa = 0.f, su = 0.f, sb = 0.f;
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
-        const int c = c0 + 16 * u;
+        const int c = c0 + 32 * u;
         ad[u] = T[r * LDT + c] * ((bits >> u) & 1u ? 1.f : 0.2f);
         ub[u] = ga[c] * tn[u];
         s1 += ad[u];
@@ -688,14 +692,14 @@ __device__ __forceinline__ void ln_tan_rows(float* T, const float* __restrict__ 
         su += ub[u];
         sb = fmaf(ub[u], xh[u], sb);
     }
-    const float mean_ad = sum16(s1) * kInvH, cc = sum16(s2) * kInvH;
-    const float su_ = sum16(su), Aq = sum16(sa) - mean_ad * su_, Bq = sum16(sb);
+    const float mean_ad = sum32(s1) * kInvH, cc = sum32(s2) * kInvH;
+    const float su_ = sum32(su), Aq = sum32(sa) - mean_ad * su_, Bq = sum32(sb);
     const float k1 = -(rs * rs * (Aq - cc * Bq) * kInvH), k2 = -(rs * Bq * kInvH), k3 = -(rs * cc);
     const float mub = su_ * kInvH, mbx = Bq * kInvH;
     float o1[LNU], o2[LNU];
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
-        const int c = c0 + 16 * u;
+        const int c = c0 + 32 * u;
         const float uu = rs * ((ad[u] - mean_ad) - cc * xh[u]);
         const float nd = ga[c] * uu;
         const float ta = rs * (ub[u] - mub - xh[u] * mbx);
@@ -704,22 +708,22 @@ __device__ __forceinline__ void ln_tan_rows(float* T, const float* __restrict__ 
         T[r * LDT + c] = LAYER2 ? pz : nd;
         o1[u] = LAYER2 ? pz : nd;
         o2[u] = pa;
-        const float sg = sum_rows4(tn[u] * uu);
-        if (lane < 16) scratch[wv * 512 + 256 + c] = sg;
+        const float sg = sum_rows2(tn[u] * uu);
+        if (lane < 32) scratch[wv * 512 + 256 + c] = sg;
         if (LAYER2) {
-            const float sn = sum_rows4(nd);
-            if (lane < 16) scratch[wv * 512 + c] = sn;
+            const float sn = sum_rows2(nd);
+            if (lane < 32) scratch[wv * 512 + c] = sn;
         }
     }
     {
         float* o = out_hbm + (drow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = o1[u];
+        for (int u = 0; u < LNU; ++u) o[32 * u] = o1[u];
     }
     if (!LAYER2) {
         float* o = pa_hbm + (trow0 + r) * H + c0;
 #pragma unroll
-        for (int u = 0; u < LNU; ++u) o[16 * u] = o2[u];
+        for (int u = 0; u < LNU; ++u) o[32 * u] = o2[u];
     }
 }
 
@@ -742,7 +746,7 @@ __device__ __forceinline__ unsigned hidden_fwd_ln(WPipe& pipe, const WDesc cur, 
     for_acc(acc, [&](int r, int c, float v, int bi) { T[r * LDT + c] = lrelu(v + bb.b[bi >> 2]); });
     bar();
     unsigned bits = 0;
-    if (is_row()) bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
+    bits = ln_fwd_rows(T, be, ga, xh_hbm, n_hbm, grow0, rs_strip);
     bar();
     return bits;
 }
@@ -998,18 +1002,16 @@ __device__ inline void role_tc(const AgentArgs& a, int wg, float* lds) {
         if (cw) head_grad_slot(L.T2, L.dq, slot);   // T2 = n2: the head's input
         bar();
         float* scratch = free_slot(L.ring, pipe);
-        if (cw)
             ln_bwd_rows<true, true>(L.T2, L.dq, a.critic.W3, a.critic.ga2, a.XH2c, row0, rs2, m2, nullptr, a.DZ2c,
                                     row0, nullptr, 0, scratch);
         bar();
-        if (cw) ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
+        ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
         prod_to_tile<CW>(pipe, c3, c3, false, L.T2, LDT, L.ring, L.T1);   // cotangent of n1
         scratch = free_slot(L.ring, pipe);
-        if (cw)
             ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, a.critic.ga1, a.XH1c, row0, rs1, m1, nullptr, a.DZ1c,
                                      row0, nullptr, 0, scratch);
         bar();
-        if (cw) ln_cols_commit(scratch, slot + (H + 1));
+        ln_cols_commit(scratch, slot + (H + 1));
         return;
     }
     (void)m1; (void)m2; (void)w3c;
@@ -1075,14 +1077,11 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
     }
     bar();
     if constexpr (LN) {
-        if (cw) {
-            if (tid < R) a.row_q[row0 + tid] = L.s_[tid];
-            ln_bwd_rows<true, false>(L.T2, L.dq, a.critic.W3, a.critic.ga2, a.XH2q, row0, rs + 48, m2c, nullptr, nullptr,
-                                     0, nullptr, 0, nullptr);   // dZ2c in place
-        }
+        if (cw && tid < R) a.row_q[row0 + tid] = L.s_[tid];
+        ln_bwd_rows<true, false>(L.T2, L.dq, a.critic.W3, a.critic.ga2, a.XH2q, row0, rs + 48, m2c, nullptr, nullptr,
+                                 0, nullptr, 0, nullptr);   // dZ2c in place
         bar();
         prod_to_tile<CW>(pipe, c3, c4, true, L.T2, LDT, L.ring, L.T1);   // cotangent of the critic's n1
-        if (cw)
             ln_bwd_rows<false, false>(L.T1, nullptr, nullptr, a.critic.ga1, a.XH1q, row0, rs + 32, m1c, nullptr, nullptr,
                                       0, nullptr, 0, nullptr);   // dZ1c in place
         bar();
@@ -1145,18 +1144,16 @@ __device__ inline void role_a(const AgentArgs& a, int wg, float* lds) {
             for_acc(acc, [&](int r_, int c, float v, int) { L.T2[r_ * LDT + c] = v; });
             bar();
             float* lslot = a.lna_part + (int64_t)wg * kLnSlot;
-            if (cw)
                 ln_bwd_rows<false, true>(L.T2, nullptr, nullptr, a.actor.ga2, a.XH2a, row0, rs + 16, m2a, nullptr,
                                          a.DZ2a, row0, nullptr, 0, slot);   // (the head matrix in `slot` is dead)
             bar();
-            if (cw) ln_cols_commit(slot, lslot + 2 * H);
+            ln_cols_commit(slot, lslot + 2 * H);
             prod_to_tile<CW>(pipe, a3, a3, false, L.T2, LDT, L.ring, L.T1);
             float* scratch = free_slot(L.ring, pipe);
-            if (cw)
                 ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, a.actor.ga1, a.XH1a, row0, rs, m1a, nullptr, a.DZ1a,
                                          row0, nullptr, 0, scratch);
             bar();
-            if (cw) ln_cols_commit(scratch, lslot);
+            ln_cols_commit(scratch, lslot);
             return;
         }
         
@@ -1336,18 +1333,16 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
             if (cw) head_grad_slot(L.T2, L.dq, slot);   // T2 = n2: the head's input
             bar();
             float* scratch = free_slot(L.ring, pipe);
-            if (cw)
                 ln_bwd_rows<true, true>(L.T2, L.dq, n.W3, n.ga2, a.XH2, hrow0, rs2, m2, nullptr, a.DZ2, hrow0, nullptr, 0,
                                         scratch);
             bar();
-            if (cw) ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
+            ln_cols_commit(scratch, slot + (H + 1) + 2 * H);
             prod_to_tile<CW>(pipe, d3, d3, false, L.T2, LDT, L.ring, L.T1);   // cotangent of n1
             scratch = free_slot(L.ring, pipe);
-            if (cw)
                 ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hrow0, rs1, m1, nullptr, a.DZ1, hrow0,
                                          nullptr, 0, scratch);
             bar();
-            if (cw) ln_cols_commit(scratch, slot + (H + 1));
+            ln_cols_commit(scratch, slot + (H + 1));
             return;
         }
         // ---- interpolate rows.  The gradient penalty is no longer piecewise linear: next to the tangent stream T
@@ -1367,13 +1362,13 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         LTR(2);
         if (cw && tid < R) { L.dq[tid] = 1.f; a.DS[hrow0 + tid] = 1.f; }
         bar();
-        if (cw)   // T_z2: the head's cotangent is w3 (d score = 1)
+        // T_z2: the head's cotangent is w3 (d score = 1)
             ln_bwd_rows<true, false>(L.T2, L.dq, n.W3, n.ga2, a.XH2, hP, rs2, m2, nullptr, a.DZ2, hT, nullptr, 0, nullptr);
         bar();
         LTR(3);
         prod_to_tile<CW>(pipe, d3, g0, true, L.T2, LDT, L.ring, L.T1);   // T_n1
         LTR(4);
-        if (cw)   // T_z1 in place; T_n1 kept for the tangent LayerNorm of layer 1 (same-thread read-back)
+        // T_z1 in place; T_n1 kept for the tangent LayerNorm of layer 1 (same-thread read-back)
             ln_bwd_rows<false, false>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, nullptr, a.DZ1, hT, a.TN1, row0,
                                       nullptr);
         bar();
@@ -1431,34 +1426,34 @@ __device__ inline void role_d(const DiscArgs& a, int wg, float* lds) {
         prod_to_tile<CW>(pipe, t1, t2, true, L.X, L.px, L.ring, L.T1);   // zdot1 = V W1
         LTR(7);
         float* scratch = free_slot(L.ring, pipe);
-        if (cw)   // ndot1 -> T1 and A1[hT]; PA1 (unmasked) -> HBM; column sums of tn1 u1 (part of dgamma1)
+        // ndot1 -> T1 and A1[hT]; PA1 (unmasked) -> HBM; column sums of tn1 u1 (part of dgamma1)
             ln_tan_rows<false>(L.T1, n.ga1, a.XH1, hP, rs1, m1, a.TN1, nullptr, row0, a.A1, hT, a.PA1, scratch);
         bar();
         LTR(8);
-        if (cw) slot[(H + 1) + H + tid] = ln_col4(scratch, 256 + tid);
+        if (cw) slot[(H + 1) + H + tid] = ln_col8(scratch, 256 + tid);
         prod_to_tile<CW>(pipe, t2, d3, true, L.T1, LDT, L.ring, L.T2);   // zdot2 = ndot1 W2
         LTR(9);
         scratch = free_slot(L.ring, pipe);
-        if (cw)   // P_z2 -> T2 and DZ2[hP]; column sums of ndot2 (-> dW3) and of tn2 u2 (-> dgamma2)
+        // P_z2 -> T2 and DZ2[hP]; column sums of ndot2 (-> dW3) and of tn2 u2 (-> dgamma2)
             ln_tan_rows<true>(L.T2, n.ga2, a.XH2, hP, rs2, m2, nullptr, n.W3, row0, a.DZ2, hP, nullptr, scratch);
         bar();
         if (cw) {
-            slot[tid] = ln_col4(scratch, tid);                              // sum ndot2 (without k)
+            slot[tid] = ln_col8(scratch, tid);                              // sum ndot2 (without k)
             slot[(H + 1) + 2 * H + tid] = 0.f;                               // dbeta2
-            slot[(H + 1) + 3 * H + tid] = ln_col4(scratch, 256 + tid);     // dgamma2
+            slot[(H + 1) + 3 * H + tid] = ln_col8(scratch, 256 + tid);     // dgamma2
             if (tid == 0) slot[H] = 0.f;
         }
         LTR(10);
         prod_to_tile<CW>(pipe, d3, d3, false, L.T2, LDT, L.ring, L.T1);   // P_n1 = P_z2 W2^T
         LTR(11);
         scratch = free_slot(L.ring, pipe);
-        if (cw)   // P_z1 = J1(gamma1 P_n1) + PA1, masked -> DZ1[hP]; dbeta1, dgamma1 (P part)
+        // P_z1 = J1(gamma1 P_n1) + PA1, masked -> DZ1[hP]; dbeta1, dgamma1 (P part)
             ln_bwd_rows<false, true>(L.T1, nullptr, nullptr, n.ga1, a.XH1, hP, rs1, m1, a.PA1, a.DZ1, hP, nullptr, row0,
                                      scratch);
         bar();
         if (cw) {
-            slot[(H + 1) + tid] = ln_col4(scratch, tid);
-            slot[(H + 1) + H + tid] += ln_col4(scratch, 256 + tid);   // (this thread stored the tangent part above)
+            slot[(H + 1) + tid] = ln_col8(scratch, tid);
+            slot[(H + 1) + H + tid] += ln_col8(scratch, 256 + tid);   // (this thread stored the tangent part above)
         }
         LTR(12);
         if (cw) WTRACE(wg, 2, 1);
