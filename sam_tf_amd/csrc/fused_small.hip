@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
 // copy that the reference logs, (b) Adam (+Polyak).  mode bit 0: write clipped, bit 1: Adam.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
-    __shared__ double shd[4];
+    __shared__ double shd[4], sh_pow[2];
     __shared__ float sh_scale, sh_lr;
     const int tid = threadIdx.x;
     int seg = 0, b = blockIdx.x;
@@ -965,21 +965,23 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     Quad q0;
     int64_t w0 = (int64_t)b * 256 + tid;
     if (s.img1 && w0 < nw) fetch(w0, q0);
+    // The step counter was advanced by finalize (or the host-enqueued tick kernel); here it is only read — blocks
+    // of one launch may run in any order.  Its load goes out with the others, and the two float64 powers of the
+    // step size run on two waves, ahead of the first barrier (they used to follow it, behind a bare load).
+    double tstep = 0.0;
+    if (tid == 64 || tid == 128) tstep = (double)s.step_dev[0];
     double acc = 0.0;
     for (int k = tid; k < s.nsumsq; k += 256) acc += (double)s.sumsq[k];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    if (tid == 64) sh_pow[0] = pow((double)f.beta2, tstep);
+    if (tid == 128) sh_pow[1] = pow((double)f.beta1, tstep);
     __syncthreads();
     if (tid == 0) {
         const float nrm = (float)sqrt(shd[0] + shd[1] + shd[2] + shd[3]) * f.grad_scale;
         sh_scale = s.clip > 0.f ? s.clip / fmaxf(nrm, s.clip) : 1.f;
     }
-    if (tid == 64) {
-        // the step counter was advanced by finalize (or the host-enqueued tick kernel); here it is
-        // only read — blocks of one launch may run in any order
-        const double t = (double)s.step_dev[0];
-        sh_lr = (float)((double)s.lr * sqrt(1.0 - pow((double)f.beta2, t)) / (1.0 - pow((double)f.beta1, t)));
-    }
+    if (tid == 64) sh_lr = (float)((double)s.lr * sqrt(1.0 - sh_pow[0]) / (1.0 - sh_pow[1]));
     __syncthreads();
     const float scale = sh_scale * f.grad_scale, lr_t = sh_lr;
     if (s.img1) {
