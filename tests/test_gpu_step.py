@@ -288,3 +288,74 @@ def test_weight_images_kept_by_the_optimiser_pass(name, ln):
                           grads=L.grads.clone(), **{k: v.clone() for k, v in out.t.items()})
     for k in runs[False]:
         assert torch.equal(runs[False][k], runs[True][k]), k
+
+
+@pytest.mark.parametrize('name', ['C2', 'C4'])
+def test_masks_without_kink_redraw_actor_and_disc(name):
+    """test_masks_without_kink_redraw for the other two roles.  Neither the actor's loss nor the discriminator's takes
+    importance weights, so one row is selected by REPLICATING it over the batch (every row of the batch is row r: the
+    mean gradient is r's own; the gradient penalty's scalar is then that row's too, in the oracle as on the device).
+    Nothing is redrawn.  Rows whose pre-activations — the actor's on obz0 and the critic's on [obz0 | mu(obz0)]; the
+    reward net's on the policy pair, the expert pair and their interpolate — come within 1e-4 of the leaky-ReLU kink
+    may carry another mask than the fp64 oracle (a handful at most); rows away from it must agree to 1e-5."""
+    from oracle import nets_oracle as NO
+    from sam_tf_amd import ops
+    c = make_case(name, off_kink=False)
+    P, D, B = c['P'], c['D'], c['B']
+    t64 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    obz = lambda o: NO.obz(t64(o), t64(c['mean']), t64(c['std'])).numpy()
+    ob0 = obz(D['obs0'])
+    mu = NO.actor_act(NO._params(P['pa'], c['da'], torch.float64)[1], t64(ob0), c['da'], 0.4).detach().numpy()
+    m_actor = np.minimum(NO.min_abs_preact(P['pa'], c['da'], ob0),
+                         NO.min_abs_preact(P['pc'], c['dc'], np.concatenate([ob0, mu], axis=1)))
+    xp = np.concatenate([ob0, D['acs']], axis=1)
+    xe = np.concatenate([obz(D['e_obs']), D['e_acs']], axis=1)
+    eps = np.concatenate([D['eps_ob'], D['eps_ac']], axis=1)
+    m_disc = np.minimum(np.minimum(NO.min_abs_preact(P['pd'], c['dd'], xp), NO.min_abs_preact(P['pd'], c['dd'], xe)),
+                        NO.min_abs_preact(P['pd'], c['dd'], eps * xp + (1.0 - eps) * xe))
+    mk = lambda d: ops.mlp_desc(d.in_dim, d.h1, d.h2, d.out_dim, d.layernorm)
+    L = ops.LearnerState(mk(c['da']), mk(c['dc']), mk(c['dd']), c['ob'], c['ac'], dict(HP, wd_scale=0.0))
+    L.params.copy_(_dev(np.concatenate([P['pa'], P['pc'], P['pd']])))
+    L.targets.copy_(_dev(np.concatenate([P['pa_t'], P['pc_t']])))
+    for k in ('mu_mean', 'd_mean'):
+        L.set_ptr(k, _dev(c['mean']))
+    for k in ('mu_std', 'd_std'):
+        L.set_ptr(k, _dev(c['std']))
+    out = ops.make_step_out(B)
+    rs = np.random.RandomState(7)
+    rep = lambda a, r: np.ascontiguousarray(np.broadcast_to(a[r], a.shape))
+    for role, margin in (('actor', m_actor), ('disc', m_disc)):
+        near = np.where(margin < 1e-4)[0]
+        assert near.size <= B // 8, '%s: implausibly many near-kink rows: %d' % (role, near.size)
+        near = near[:12]   # (each row costs a device step and an fp64 autograd pass over the whole batch)
+        far = rs.choice(np.where(margin >= 1e-4)[0], size=4, replace=False)
+        differs = []
+        for r in list(near) + list(far):
+            Dr = dict(D)
+            if role == 'actor':
+                Dr['obs0'] = rep(D['obs0'], r)
+            else:
+                for k in ('obs0', 'acs', 'e_obs', 'e_acs', 'eps_ob', 'eps_ac', 'real', 'fake'):
+                    Dr[k] = rep(D[k], r)
+            batch = ops.make_batch(B, p_obs=_dev(Dr['obs0'] if role == 'disc' else D['obs0']),
+                                   p_acs=_dev(Dr['acs']), e_obs=_dev(Dr['e_obs']), e_acs=_dev(Dr['e_acs']),
+                                   eps_ob=_dev(Dr['eps_ob']), eps_ac=_dev(Dr['eps_ac']), real_labels=_dev(Dr['real']),
+                                   fake_labels=_dev(Dr['fake']), obs0=_dev(Dr['obs0'] if role == 'actor' else D['obs0']),
+                                   acs=_dev(D['acs']), rews=_dev(D['rews']), dones1=_dev(D['dones1']),
+                                   obs1=_dev(D['obs1']))
+            ops.step_grads(L, batch, out)
+            torch.cuda.synchronize()
+            if role == 'actor':
+                got = L.seg(L.grads, 0).cpu().numpy()
+                _, exp = NO.actor_loss_grad(P['pa'], c['da'], P['pc'], c['dc'], None, c['dd'], Dr['obs0'], c['mean'],
+                                            c['std'], 0.4, 1.0, 0.0)
+            else:
+                got = L.seg(L.grads, 2).cpu().numpy()
+                _, exp = NO.disc_loss_grad(P['pd'], c['dd'], Dr['obs0'], Dr['acs'], Dr['e_obs'], Dr['e_acs'], Dr['eps_ob'],
+                                           Dr['eps_ac'], Dr['real'], Dr['fake'], c['mean'], c['std'], ent_reg_scale=0.0)
+            if relerr(got, exp) >= 1e-5:
+                differs.append(int(r))
+        assert not set(differs) & set(int(r) for r in far), '%s: rows away from the kink differ: %r' % (role, differs)
+        assert len(differs) <= 3, '%s: near-kink rows with a different mask: %r of %d' % (role, differs, near.size)
+        record_margin('masks_without_redraw/%s' % name, '%s_near_kink_rows' % role, int(near.size))
+        record_margin('masks_without_redraw/%s' % name, '%s_rows_with_other_mask' % role, len(differs))
