@@ -916,6 +916,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
         g0 += __shfl_xor(g0, 1, 64); g0 += __shfl_xor(g0, 2, 64);
         g1 += __shfl_xor(g1, 1, 64); g1 += __shfl_xor(g1, 2, 64);
         float g = g0 + kgp * g1;
+        // (requesting the decayed kernel's value with the slots, ahead of the sums, measured slower at C2:
+        // 36.24 -> 35.98 k steps/s alternating on one box)
         if (s.wd > 0.f && ((i >= s.wd0_lo && i < s.wd0_hi) || (i >= s.wd1_lo && i < s.wd1_hi)))
             g += s.wd * s.param[i];
         if (q == 0) {
