@@ -1,5 +1,6 @@
 // Internal interface of the whole-network fused kernels (fused_small.hip) used by step.hip.
 #pragma once
+#include "ret_tail.h"
 #include "samx_common.h"
 #include "../../include/samx.h"
 
