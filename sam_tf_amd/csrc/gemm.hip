@@ -34,6 +34,8 @@
 // by the wave that issued the DMA, after its own vmcnt wait and before the barrier.
 #include "gemm.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
 
 namespace samx {
 namespace {
@@ -58,8 +60,12 @@ typedef const __attribute__((address_space(1))) float glb_float;
 __device__ unsigned long long g_gemm_trace[64];
 #define GTRACE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (i) < 64) \
                          g_gemm_trace[(i)] = wall_clock64(); } while (0)
+// register-direct weight-gradient kernel: per workgroup (wave 0) [entry, first batch landed, loop done, stored, where]
+__device__ unsigned long long g_wd_trace[10 * 1024];
+#define WDTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_wd_trace[10 * blockIdx.x + (i)] = wall_clock64(); } while (0)
 #else
 #define GTRACE(i) do { } while (0)
+#define WDTRACE(i) do { } while (0)
 #endif
 
 struct EpiCtx {
@@ -506,6 +512,266 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup G) {
     gemm_tile<false, false, 1, true, true>(G.g[p], bx, by, bz);
 }
 
+// ---- Register-direct weight-gradient products ---------------------------------------------------------------
+// dW = X^T dZ has BOTH operands free-contiguous, so the MFMA fragment of a k-step (two batch rows) is 32 consecutive
+// floats of a row: a coalesced global load, nothing has to pass through LDS.  Lane (m, hi) loads NE consecutive
+// columns of X row r + hi (ONE 16-byte load for NE = 4) and two of dZ; register e of the first is the A operand of
+// the 32-row block {i0 + NE ii + e}, register f of the second the B operand of the columns {j0 + 2 jj + f}: 2 NE
+// MFMAs per pair of loads, a 32 NE x 64 output tile per WAVE in 2 NE accumulators (NE = 4: 128 x 64, 21 flop per
+// byte from L2).  No barrier and no LDS traffic in the loop; the four waves of a workgroup take a quarter of the
+// reduction chunk each and add their accumulators through LDS at the end, (q0 + q2) + (q1 + q3) — a fixed order.
+// The bias gradient (the virtual ones row of the staged kernel, a whole extra row of tiles when M % 64 == 0) is
+// the column sum of dZ: two adds per k-step on registers the first M tile holds anyway.
+// Workgroups that share operands — the tiles of one (product, chunk) — are placed on ONE XCD (blockIdx % 8), the
+// groups dealt to the XCDs longest first by the host.
+struct WProb {
+    const float *A, *B;
+    float* P;          // [nsplit][Mo][N]
+    int lda, ldb, M, N, R, ones, chunk, Mo;
+    int tmn, tnn;      // M tiles (128 wide; the last one narrower: NE of 1, 2 or 4), N tiles (64 wide)
+};
+constexpr int kWGroupMax = 384;
+#ifndef SAMX_WGRAD_TILE_NE
+#define SAMX_WGRAD_TILE_NE 2
+#endif
+constexpr int kWTileNE = SAMX_WGRAD_TILE_NE;   // full M tiles are 32 kWTileNE wide
+static_assert(kWTileNE == 2 || kWTileNE == 4, "M tiles of 64 or 128");
+struct WDirect {
+    WProb g[kGemmGroupMax];
+    SlotSum sums[kSlotSumMax];
+    int sum_first[kSlotSumMax + 1];
+    int nsums;
+    int slots;                    // workgroup slots per XCD: blocks [0, 8 slots) are product tiles
+    int xfirst[9];                // groups of XCD x: grp[xfirst[x] .. xfirst[x + 1])
+    uint32_t grp[kWGroupMax];     // product | chunk << 8 | first slot << 16
+};
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NE>
+__device__ __forceinline__ void load_rows(const __amdgpu_buffer_rsrc_t r, const int lane_off, const int row_off,
+                                          float (&o)[NE]) {
+    if constexpr (NE == 4) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, row_off, 0));
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    } else if constexpr (NE == 2) {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, row_off, 0));
+        o[0] = v[0]; o[1] = v[1];
+    } else {
+        o[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
+    }
+}
+
+template <int NE>
+__device__ __forceinline__ void wdirect_tile(const WProb& g, const int i0, const int j0, const int z, float* red) {
+    constexpr int KD = kWTileNE == 2 ? 8 : 16;   // k-steps (row pairs) in flight
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the row addresses below stay on the SALU)
+    const int r_begin = z * g.chunk, r_end = min(g.R, r_begin + g.chunk);
+    const int q = g.chunk >> 2;    // rows per wave (the chunk is a multiple of 32, R is even)
+    const int w_begin = r_begin + wave * q, w_end = min(r_end, w_begin + q);
+    const bool colsum = g.ones >= 0 && i0 == 0;
+    const int ones_lim = colsum ? g.ones : 0;   // rows below it count for the bias gradient
+    // lanes past the edge read a clamped (valid) address: they feed rows / columns that are never stored
+    const int ia = min(i0 + NE * m, (g.M - 1) & ~(NE - 1)), jb = min(j0 + 2 * m, (g.N - 1) & ~1);
+    // Buffer loads: resource (scalar) + a fixed 32-bit lane offset + the row's byte offset as the SCALAR offset
+    // operand.  With one wave per SIMD every VALU instruction between two MFMAs is time the matrix pipe idles
+    // (tools/exp/mfma_mix.hip: one 64-bit multiply-add per load costs 10 of 64 clocks per MFMA), so the loop keeps
+    // its address arithmetic on the SALU.  (The host checks that the byte offsets fit 31 bits.)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+    const int sa = g.lda * 4, sb = g.ldb * 4;
+    const int oa = (hi * g.lda + ia) * 4, ob = (hi * g.ldb + jb) * 4;
+    auto row_a = [&](const int r, float (&o)[NE]) { load_rows<NE>(ra, oa, r * sa, o); };
+    auto row_b = [&](const int r, float (&o)[2]) { load_rows<2>(rb, ob, r * sb, o); };
+    f32x16 acc[NE][2];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[e][f][v] = 0.f;
+    float cs[2] = {0.f, 0.f};
+
+    // Main loop over groups of KD k-steps (2 KD rows), branch-free: the registers of a k-step are refilled with the
+    // rows of the NEXT group right after its MFMAs have been issued (KD - 1 k-steps = 2 x KD - 2 loads stay in
+    // flight: the counted waits are the compiler's); the refills of the last group re-read it (discarded).  Then
+    // the rows that do not fill a group, one k-step at a time.
+    const int rows = w_end > w_begin ? w_end - w_begin : 0;
+    const int nd = rows / (2 * KD);
+    WDTRACE(0);
+#ifdef SAMX_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wd_trace[10 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
+        g_wd_trace[10 * blockIdx.x + 8] = clock64();
+    }
+#endif
+    if (nd > 0) {
+        float a[KD][NE], b[KD][2];
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            // (in the loop's own order: the counted waits come out of the merge of this state with the back edge's —
+            // with the loads reordered here the loop head gets a vmcnt(0))
+            __builtin_amdgcn_sched_barrier(0);
+            row_a(w_begin + 2 * s, a[s]);
+            row_b(w_begin + 2 * s, b[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int last = w_begin + (nd - 1) * 2 * KD;
+        // one group; MODE (compile time) is how the bias row counts its rows: 0 not at all (no bias row, or not
+        // this tile's job), 1 all of them, 2 those below ones_lim
+        auto group = [&](const int r0, const int rn, auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink every load to just before its use)
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], b[s][f], acc[e][f], 0, 0, 0);
+                if (MODE == 1) {
+                    cs[0] += b[s][0];
+                    cs[1] += b[s][1];
+                } else if (MODE == 2) {
+                    const bool in = r0 + 2 * s + hi < ones_lim;
+                    cs[0] += in ? b[s][0] : 0.f;
+                    cs[1] += in ? b[s][1] : 0.f;
+                }
+                row_a(rn + 2 * s, a[s]);
+                row_b(rn + 2 * s, b[s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int n = 0; n < nd; ++n) {
+            const int r0 = w_begin + n * 2 * KD, rn = min(r0 + 2 * KD, last);
+            if (r0 >= ones_lim) group(r0, rn, std::integral_constant<int, 0>());
+            else if (r0 + 2 * KD <= ones_lim) group(r0, rn, std::integral_constant<int, 1>());
+            else group(r0, rn, std::integral_constant<int, 2>());
+            if (n == 0) WDTRACE(1);
+        }
+    }
+    for (int r = w_begin + nd * 2 * KD; r < w_end; r += 2) {
+        float a[NE], b[2];
+        row_a(r, a);
+        row_b(r, b);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[f], acc[e][f], 0, 0, 0);
+        const bool in = r + hi < ones_lim;
+        cs[0] += in ? b[0] : 0.f;
+        cs[1] += in ? b[1] : 0.f;
+    }
+
+    WDTRACE(2);
+#ifdef SAMX_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wd_trace[10 * blockIdx.x + 9] = clock64();
+#endif
+    // The four partial tiles are added through LDS, ((q0 + q1) + q2) + q3: wave u finishes accumulator registers
+    // 4u .. 4u + 3 of every accumulator (output rows NE (k + 8u + 4 hi) + e) and takes the other waves' from LDS
+    // [wave][accumulator][register][lane].
+    constexpr int NA = 2 * NE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u == wave) continue;   // (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < NA; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                red[((wave * NA + c) * 16 + 4 * u + k) * 64 + lane] = acc[c >> 1][c & 1][4 * u + k];
+    }
+    float* red_cs = red + 4 * NA * 16 * 64;
+    if (colsum && wave > 0) { red_cs[(wave * 2) * 64 + lane] = cs[0]; red_cs[(wave * 2 + 1) * 64 + lane] = cs[1]; }
+    __syncthreads();
+    WDTRACE(5);
+    float* P = g.P + (int64_t)z * g.Mo * g.N;
+    const int j = j0 + 2 * m;
+    const bool fast = i0 + 32 * NE <= g.M && (g.N & 1) == 0;   // every row of the tile exists, pairs are aligned
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u != wave) continue;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            float x[2][4];
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = e * 2 + f, v = 4 * u + k;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float term = t == u ? acc[e][f][v] : red[((t * NA + c) * 16 + v) * 64 + lane];
+                        sum = t == 0 ? term : sum + term;
+                    }
+                    x[f][k] = sum;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + NE * (k + 8 * u + 4 * hi) + e;
+                float* dst = P + (int64_t)i * g.N + j;
+                if (fast) {
+                    if (j < g.N) *(f32x2u*)dst = f32x2u{x[0][k], x[1][k]};
+                } else if (i < g.M) {
+                    if (j < g.N) dst[0] = x[0][k];
+                    if (j + 1 < g.N) dst[1] = x[1][k];
+                }
+            }
+        }
+    }
+    WDTRACE(3);
+    if (colsum && wave == 0) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float x = cs[f];
+#pragma unroll
+            for (int t = 1; t < 4; ++t) x += red_cs[(t * 2 + f) * 64 + lane];
+            x += __shfl_down(x, 32);
+            if (hi == 0 && j + f < g.N) P[(int64_t)g.M * g.N + j + f] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, kWTileNE == 2 ? 2 : 1) void wgrad_direct_kernel(WDirect G) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    if (b >= 8 * G.slots) {   // slot sums (as in gemm_group_kernel)
+        const int g = ((b - 8 * G.slots) * 256 + (int)threadIdx.x) >> 4, l = threadIdx.x & 15;
+        int q = 0;
+        while (q < G.nsums && g >= G.sum_first[q + 1]) ++q;
+        if (q >= G.nsums) return;
+        const SlotSum& s = G.sums[q];
+        const int c = g - G.sum_first[q];
+        float sm = 0.f;
+        for (int z = l; z < s.n; z += 16) sm += s.slots[(int64_t)z * s.width + c];
+        for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+        if (l == 0) s.out[c] = sm;
+        return;
+    }
+    const int xcd = b & 7, slot = b >> 3;
+    for (int k = G.xfirst[xcd]; k < G.xfirst[xcd + 1]; ++k) {
+        const uint32_t e = G.grp[k];
+        const int p = e & 255, z = (e >> 8) & 255, first = (int)(e >> 16);
+        const WProb& g = G.g[p];
+        const int t = slot - first;
+        if (t < 0 || t >= g.tmn * g.tnn) continue;
+        const int tm = t / g.tnn, tn = t - tm * g.tnn;
+        const int i0 = tm * 32 * kWTileNE, rem = g.M - i0;
+        if constexpr (kWTileNE == 4) {
+            if (rem > 64) { wdirect_tile<4>(g, i0, tn * 64, z, lds); return; }
+        }
+        if (rem > 32) wdirect_tile<2>(g, i0, tn * 64, z, lds);
+        else wdirect_tile<1>(g, i0, tn * 64, z, lds);
+        return;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmArgs g, int Mo) {
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Mo * g.N) return;
@@ -588,6 +854,64 @@ int launch(const GemmArgs& g_in, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+// SAMX_ERR_UNSUPPORTED (silently: the caller falls back to the staged kernel) when a product does not fit
+int wgrad_direct(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums) {
+    WDirect G;
+    struct Grp { int tiles, p, z; };
+    Grp grp[kWGroupMax];
+    int ngrp = 0;
+    for (int p = 0; p < n; ++p) {
+        const GemmArgs& g = list[p];
+        if (!(g.a_si == 1 && g.b_sj == 1 && g.overread_ok && (g.R & 1) == 0 && g.M >= 4 && g.N >= 2 &&
+              g.nsplit <= 255 && ngrp + g.nsplit <= kWGroupMax &&
+              ((int64_t)g.R + 1) * g.a_sr * 4 < (1ll << 31) && ((int64_t)g.R + 1) * g.b_sr * 4 < (1ll << 31)))
+            return SAMX_ERR_UNSUPPORTED;
+        WProb& w = G.g[p];
+        w.A = g.A; w.B = g.B; w.P = g.partials;
+        w.lda = (int)g.a_sr; w.ldb = (int)g.b_sr; w.M = g.M; w.N = g.N; w.R = g.R; w.ones = g.a_ones_rows;
+        w.chunk = gemm_split_chunk(g.R, g.nsplit);
+        w.Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
+        w.tmn = cdiv(g.M, 32 * kWTileNE); w.tnn = cdiv(g.N, 64);
+        for (int z = 0; z < g.nsplit; ++z) grp[ngrp++] = Grp{w.tmn * w.tnn, p, z};
+    }
+    // longest group first onto the XCD with the fewest workgroups so far
+    std::stable_sort(grp, grp + ngrp, [](const Grp& a, const Grp& b) { return a.tiles > b.tiles; });
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xcd_of[kWGroupMax], first[kWGroupMax];
+    for (int k = 0; k < ngrp; ++k) {
+        int x = 0;
+        for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
+        xcd_of[k] = x; first[k] = load[x]; load[x] += grp[k].tiles;
+    }
+    G.slots = 0;
+    for (int x = 0; x < 8; ++x) G.slots = load[x] > G.slots ? load[x] : G.slots;
+    if (G.slots > 65535) return SAMX_ERR_UNSUPPORTED;
+    int e = 0;
+    for (int x = 0; x < 8; ++x) {
+        G.xfirst[x] = e;
+        for (int k = 0; k < ngrp; ++k)
+            if (xcd_of[k] == x) G.grp[e++] = (uint32_t)grp[k].p | ((uint32_t)grp[k].z << 8) | ((uint32_t)first[k] << 16);
+    }
+    G.xfirst[8] = e;
+    G.nsums = nsums;
+    int groups = 0;
+    for (int q = 0; q < nsums; ++q) {
+        G.sums[q] = sums[q];
+        G.sum_first[q] = groups;
+        groups += sums[q].width;
+    }
+    G.sum_first[nsums] = groups;
+    const int blocks = 8 * G.slots + (groups * 16 + 255) / 256;
+    // [wave][accumulator][register][lane] of the widest tile + the column sums
+    constexpr size_t lds = (size_t)(4 * 2 * kWTileNE * 16 + 8) * 64 * sizeof(float);
+    static LdsGrant grant;
+    if (int rc = grant.ensure((const void*)wgrad_direct_kernel, lds, 64 * 1024)) return rc;
+    wgrad_direct_kernel<<<blocks, 256, lds, stream>>>(G);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+}  // namespace
+
 int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums) {
     SAMX_REQUIRE(list && n > 0 && n <= kGemmGroupMax, "gemm_group_partials: 1..%d problems", kGemmGroupMax);
     SAMX_REQUIRE(nsums >= 0 && nsums <= kSlotSumMax && (nsums == 0 || sums), "gemm_group_partials: 0..%d slot sums",
@@ -611,6 +935,14 @@ int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const S
         blocks += G.gx[p] * G.gy[p] * g.nsplit;
     }
     G.first[n] = blocks;
+    {   // the register-direct kernel takes the call when every product fits its form (SAMX_WGRAD_DIRECT=0: never)
+        static int direct = -1;
+        if (direct < 0) { const char* e = getenv("SAMX_WGRAD_DIRECT"); direct = e ? atoi(e) : 1; }
+        if (direct) {
+            const int rc = wgrad_direct(list, n, stream, sums, nsums);
+            if (rc != SAMX_ERR_UNSUPPORTED) return rc;
+        }
+    }
     G.nsums = nsums;
     int groups = 0;
     for (int q = 0; q < nsums; ++q) {
@@ -661,6 +993,9 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
 }  // namespace samx
 
 #ifdef SAMX_TRACE
+extern "C" int samx_debug_wd_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::g_wd_trace), sizeof(unsigned long long) * 10 * 1024);
+}
 extern "C" int samx_debug_gemm_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::g_gemm_trace), sizeof(unsigned long long) * 64);
 }
