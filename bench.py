@@ -428,7 +428,7 @@ def main():
             'roofline': {'bound': 'latency' if drv.fused else 'mfma',
                          'kernel': ('samx::fused::step_kernel (whole-network fused, all three roles)' if drv.fused
                                     else ('samx::wide::roles_kernel (the layer chains of every role, one launch) + '
-                                          'samx::gemm_group_kernel (all weight-gradient products, one launch)')
+                                          'samx::wgrad_direct_kernel (all weight-gradient products, one launch)')
                                     if drv.wide
                                     else 'layer-wise fp32 MFMA GEMM chains (samx::gemm_kernel), three roles '
                                          'on three streams'),
@@ -438,7 +438,8 @@ def main():
                          'kernel_us': dom * 1e6, 'flops_per_launch': flops_per_step(cfg),
                          'note': ('latency-bound: %.1f MFLOP and < 1 MB per launch; neither the MFMA nor the HBM '
                                   'roofline binds (DESIGN.md 3.1)' % (flops_per_step(cfg) / 1e6)) if drv.fused
-                                 else 'fp32 MFMA (exact f32) peak 157.3 TFLOP/s',
+                                 else 'fp32 MFMA (exact f32) peak 157.3 TFLOP/s at 2.4 GHz; with every CU on MFMAs the chip holds 2.1 GHz: '
+                                      '138 TFLOP/s measured with nothing but MFMAs (profiles/r03_mfma_rate.txt)',
                          'pass_us': {k: v * 1e6 for k, v in passes.items()}},
         }
 

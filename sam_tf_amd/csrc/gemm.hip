@@ -535,7 +535,8 @@ constexpr int kWGroupMax = 384;
 #define SAMX_WGRAD_TILE_NE 2
 #endif
 constexpr int kWTileNE = SAMX_WGRAD_TILE_NE;   // full M tiles are 32 kWTileNE wide
-static_assert(kWTileNE == 2 || kWTileNE == 4, "M tiles of 64 or 128");
+static_assert(kWTileNE == 1 || kWTileNE == 2 || kWTileNE == 4, "M tiles of 32, 64 or 128");
+constexpr int kWOcc = kWTileNE == 1 ? 4 : kWTileNE == 2 ? 2 : 1;   // workgroups per CU the register budget is set for
 struct WDirect {
     WProb g[kGemmGroupMax];
     SlotSum sums[kSlotSumMax];
@@ -545,6 +546,7 @@ struct WDirect {
     int xfirst[9];                // groups of XCD x: grp[xfirst[x] .. xfirst[x + 1])
     uint32_t grp[kWGroupMax];     // product | chunk << 8 | first slot << 16
 };
+int wgrad_direct(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums);
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -565,7 +567,7 @@ __device__ __forceinline__ void load_rows(const __amdgpu_buffer_rsrc_t r, const 
 
 template <int NE>
 __device__ __forceinline__ void wdirect_tile(const WProb& g, const int i0, const int j0, const int z, float* red) {
-    constexpr int KD = kWTileNE == 2 ? 8 : 16;   // k-steps (row pairs) in flight
+    constexpr int KD = kWTileNE == 4 ? 16 : 8;   // k-steps (row pairs) in flight
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the row addresses below stay on the SALU)
     const int r_begin = z * g.chunk, r_end = min(g.R, r_begin + g.chunk);
@@ -738,7 +740,7 @@ __device__ __forceinline__ void wdirect_tile(const WProb& g, const int i0, const
     }
 }
 
-__global__ __launch_bounds__(256, kWTileNE == 2 ? 2 : 1) void wgrad_direct_kernel(WDirect G) {
+__global__ __launch_bounds__(256, kWOcc) void wgrad_direct_kernel(WDirect G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
     if (b >= 8 * G.slots) {   // slot sums (as in gemm_group_kernel)
@@ -766,8 +768,10 @@ __global__ __launch_bounds__(256, kWTileNE == 2 ? 2 : 1) void wgrad_direct_kerne
         if constexpr (kWTileNE == 4) {
             if (rem > 64) { wdirect_tile<4>(g, i0, tn * 64, z, lds); return; }
         }
-        if (rem > 32) wdirect_tile<2>(g, i0, tn * 64, z, lds);
-        else wdirect_tile<1>(g, i0, tn * 64, z, lds);
+        if constexpr (kWTileNE >= 2) {
+            if (rem > 32) { wdirect_tile<2>(g, i0, tn * 64, z, lds); return; }
+        }
+        wdirect_tile<1>(g, i0, tn * 64, z, lds);
         return;
     }
 }
@@ -838,8 +842,18 @@ int launch(const GemmArgs& g_in, hipStream_t stream) {
     // fewer than two 4-wave workgroups per CU: spread each tile's reduction over 16 waves instead
     const bool few = (int64_t)grid.x * grid.y * grid.z < 512;
     const bool a_rc = g.a_sr == 1 && !(g.a_ones_rows >= 0), b_rc = g.b_sr == 1 && g.b_sj != 1;
-    int rc;
-    if (a_rc && !b_rc) rc = launch_layout<true, false>(g, grid, few, stream);
+    int rc = SAMX_ERR_UNSUPPORTED;
+    if (!a_rc && !b_rc && g.nsplit > 1) {
+        // SAMX_WGRAD_DIRECT_SPLIT=1: split weight-gradient products of the layer-wise path on the register-direct
+        // kernel too.  Off: at C5, where three role chains run side by side, it measured 705 against 709 steps/s
+        // (686..707 over 384..1536 split slots) — three staged workgroups per CU mix better with the other chains'
+        // launches than two 67 KB ones.
+        static int direct = -1;
+        if (direct < 0) { const char* e = getenv("SAMX_WGRAD_DIRECT_SPLIT"); direct = e ? atoi(e) : 0; }
+        if (direct) rc = wgrad_direct(&g, 1, stream, nullptr, 0);
+    }
+    if (rc != SAMX_ERR_UNSUPPORTED) { if (rc != SAMX_OK) return rc; }
+    else if (a_rc && !b_rc) rc = launch_layout<true, false>(g, grid, few, stream);
     else if (a_rc && b_rc) rc = launch_layout<true, true>(g, grid, few, stream);
     else if (!a_rc && !b_rc) rc = launch_layout<false, false>(g, grid, few, stream);
     else return fail(SAMX_ERR_UNSUPPORTED, "gemm: operand layout (A free-contiguous, B reduction-contiguous)");
@@ -863,7 +877,8 @@ int wgrad_direct(const GemmArgs* list, int n, hipStream_t stream, const SlotSum*
     int ngrp = 0;
     for (int p = 0; p < n; ++p) {
         const GemmArgs& g = list[p];
-        if (!(g.a_si == 1 && g.b_sj == 1 && g.overread_ok && (g.R & 1) == 0 && g.M >= 4 && g.N >= 2 &&
+        if (!(g.a_si == 1 && g.b_sj == 1 && (g.overread_ok || (g.M % kWTileNE == 0 && g.N % 2 == 0)) &&
+              (g.R & 1) == 0 && g.M >= 4 && g.N >= 2 &&
               g.nsplit <= 255 && ngrp + g.nsplit <= kWGroupMax &&
               ((int64_t)g.R + 1) * g.a_sr * 4 < (1ll << 31) && ((int64_t)g.R + 1) * g.b_sr * 4 < (1ll << 31)))
             return SAMX_ERR_UNSUPPORTED;
