@@ -229,6 +229,17 @@ int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, in
                   const float* bias, const float* aux, int64_t ld_aux, const float* add, int64_t ld_add,
                   float alpha, int32_t nsplit, float* partials, int32_t overread_ok, void* stream);
 
+/* The split weight-gradient product of the 256-wide path on its own, for parity tests: partials[z][i][j] =
+ * sum over the rows r of chunk z (gemm_split_chunk(R, nsplit) = ceil(R / nsplit) rounded up to 32 rows each) of
+ * A[r*lda + i] * B[r*ldb + j], i < M, j < N, plus row i == M = sum of B[r*ldb + j] over r < a_ones_rows when
+ * a_ones_rows >= 0 (the bias gradient) — dW, db = X^T dZ of tf.gradients (tf_util.py:141) before the fixed-order sum
+ * over the chunks.  kernel 1: the register-direct kernel (operands straight from L2 into MFMA registers; needs R even
+ * and readable bytes behind odd extents as for samx_gemm_f32, else SAMX_ERR_UNSUPPORTED); kernel 0: the staged
+ * (LDS ring) kernel it replaced.  partials: nsplit * (M + (a_ones_rows >= 0)) * N floats. */
+int samx_wgrad_partials_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* partials, int32_t M,
+                            int32_t N, int32_t R, int32_t a_ones_rows, int32_t nsplit, int32_t kernel,
+                            int32_t overread_ok, void* stream);
+
 /* ---- network passes ------------------------------------------------------------------------ */
 /* ob_mean/ob_std: float[ob] from samx_rms_commit, or NULL when rmsify_obs is off
  * (sam_agent.py:150-159).  Observations are normalised and clipped to [-5, 5] inside.

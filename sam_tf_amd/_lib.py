@@ -107,6 +107,8 @@ SIGNATURES = {
     'samx_rms_distance': (C.c_int, [_P, _P, _I64, _P, _P]),
     'samx_gemm_f32': (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, _P, _P, _I64, _P, _I64, C.c_float, C.c_int32, _P, C.c_int32, _P]),
+    'samx_wgrad_partials_f32': (C.c_int, [_P, _I64, _P, _I64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, _P]),
     'samx_nets_ws_bytes': (_SZ, [_MP, _MP, _MP, _I64]),
     'samx_act_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _I64, _F, _P, _P, _RP, _P, _SZ, _P]),
     'samx_targ_q': (C.c_int, [_MP, _P, _MP, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _P, _RP, _P, _SZ,

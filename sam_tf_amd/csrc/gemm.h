@@ -58,8 +58,10 @@ int gemm(const GemmArgs& g, hipStream_t stream);
 // then a fixed xor tree).
 constexpr int kGemmGroupMax = 10, kSlotSumMax = 4;
 struct SlotSum { const float* slots; int n, width; float* out; };
+// kernel: -1 the register-direct kernel when every product fits it (SAMX_WGRAD_DIRECT=0: never), 0 the staged
+// (LDS ring) kernel, 1 the register-direct kernel or SAMX_ERR_UNSUPPORTED.
 int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums = nullptr,
-                        int nsums = 0);
+                        int nsums = 0, int kernel = -1);
 inline int gemm_split_chunk(int R, int nsplit) { return ((R + nsplit - 1) / nsplit + 31) / 32 * 32; }
 
 // number of r-splits that fills the chip for a weight-gradient GEMM

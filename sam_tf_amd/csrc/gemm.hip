@@ -927,21 +927,37 @@ int wgrad_direct(const GemmArgs* list, int n, hipStream_t stream, const SlotSum*
 }
 }  // namespace
 
-int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums) {
+int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const SlotSum* sums, int nsums, int kernel) {
     SAMX_REQUIRE(list && n > 0 && n <= kGemmGroupMax, "gemm_group_partials: 1..%d problems", kGemmGroupMax);
     SAMX_REQUIRE(nsums >= 0 && nsums <= kSlotSumMax && (nsums == 0 || sums), "gemm_group_partials: 0..%d slot sums",
                  kSlotSumMax);
+    for (int p = 0; p < n; ++p) {
+        const GemmArgs& g = list[p];
+        SAMX_REQUIRE(g.A && g.B && g.partials && g.M > 0 && g.N > 0 && g.R > 0 && g.nsplit >= 2,
+                     "gemm_group_partials: problem %d needs operands, a partials buffer and nsplit >= 2", p);
+        SAMX_REQUIRE(g.a_si == 1 && g.b_sj == 1, "gemm_group_partials: problem %d is not a free-contiguous product", p);
+    }
+    for (int q = 0; q < nsums; ++q)
+        SAMX_REQUIRE(sums[q].slots && sums[q].out && sums[q].n > 0 && sums[q].width > 0,
+                     "gemm_group_partials: slot sum %d", q);
+    {   // the register-direct kernel takes the call when every product fits its form (SAMX_WGRAD_DIRECT=0: never)
+        static int direct = -1;
+        if (direct < 0) { const char* e = getenv("SAMX_WGRAD_DIRECT"); direct = e ? atoi(e) : 1; }
+        if (kernel == 1 || (kernel < 0 && direct)) {
+            const int rc = wgrad_direct(list, n, stream, sums, nsums);
+            if (rc != SAMX_ERR_UNSUPPORTED) return rc;
+            if (kernel == 1)
+                return fail(SAMX_ERR_UNSUPPORTED, "gemm_group_partials: a product does not fit the register-direct kernel");
+        }
+    }
     GemmGroup G;
     G.n = n;
     int blocks = 0;
     for (int p = 0; p < n; ++p) {
         const GemmArgs& g = list[p];
-        SAMX_REQUIRE(g.A && g.B && g.partials && g.M > 0 && g.N > 0 && g.R > 0 && g.nsplit >= 2,
-                     "gemm_group_partials: problem %d needs operands, a partials buffer and nsplit >= 2", p);
         const int ea = g.M, eb = g.N;
-        SAMX_REQUIRE(g.a_si == 1 && g.b_sj == 1 && ea >= 4 && eb >= 4 && (ea % 4 == 0 || g.overread_ok) &&
-                         (eb % 4 == 0 || g.overread_ok),
-                     "gemm_group_partials: problem %d is not a free-contiguous product with 16-byte staging", p);
+        SAMX_REQUIRE(ea >= 4 && eb >= 4 && (ea % 4 == 0 || g.overread_ok) && (eb % 4 == 0 || g.overread_ok),
+                     "gemm_group_partials: problem %d does not fit the 16-byte staging of the staged kernel", p);
         const int Mo = g.M + (g.a_ones_rows >= 0 ? 1 : 0);
         G.g[p] = g;
         G.gx[p] = cdiv(g.N, BN);
@@ -950,19 +966,9 @@ int gemm_group_partials(const GemmArgs* list, int n, hipStream_t stream, const S
         blocks += G.gx[p] * G.gy[p] * g.nsplit;
     }
     G.first[n] = blocks;
-    {   // the register-direct kernel takes the call when every product fits its form (SAMX_WGRAD_DIRECT=0: never)
-        static int direct = -1;
-        if (direct < 0) { const char* e = getenv("SAMX_WGRAD_DIRECT"); direct = e ? atoi(e) : 1; }
-        if (direct) {
-            const int rc = wgrad_direct(list, n, stream, sums, nsums);
-            if (rc != SAMX_ERR_UNSUPPORTED) return rc;
-        }
-    }
     G.nsums = nsums;
     int groups = 0;
     for (int q = 0; q < nsums; ++q) {
-        SAMX_REQUIRE(sums[q].slots && sums[q].out && sums[q].n > 0 && sums[q].width > 0,
-                     "gemm_group_partials: slot sum %d", q);
         G.sums[q] = sums[q];
         G.sum_first[q] = groups;
         groups += sums[q].width;
@@ -1015,6 +1021,22 @@ extern "C" int samx_debug_gemm_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(samx::g_gemm_trace), sizeof(unsigned long long) * 64);
 }
 #endif
+
+extern "C" int samx_wgrad_partials_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* partials,
+                                       int32_t M, int32_t N, int32_t R, int32_t a_ones_rows, int32_t nsplit,
+                                       int32_t kernel, int32_t overread_ok, void* stream) {
+    SAMX_REQUIRE(A && B && partials && M > 0 && N > 0 && R > 0 && nsplit >= 2, "samx_wgrad_partials_f32: arguments");
+    SAMX_REQUIRE(kernel == 0 || kernel == 1, "samx_wgrad_partials_f32: kernel 0 (staged) or 1 (register-direct)");
+    samx::GemmArgs g;
+    g.A = A; g.a_si = 1; g.a_sr = lda;
+    g.B = B; g.b_sr = ldb; g.b_sj = 1;
+    g.C = partials; g.ldc = N;
+    g.M = M; g.N = N; g.R = R;
+    g.a_ones_rows = a_ones_rows;
+    g.nsplit = nsplit; g.partials = partials;
+    g.overread_ok = overread_ok != 0;
+    return samx::gemm_group_partials(&g, 1, (hipStream_t)stream, nullptr, 0, kernel);
+}
 
 extern "C" int samx_gemm_f32(const float* A, int64_t a_si, int64_t a_sr, const float* B, int64_t b_sr, int64_t b_sj,
                              float* C, int64_t ldc, int32_t M, int32_t N, int32_t R, int32_t a_ones_rows,

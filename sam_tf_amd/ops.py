@@ -833,6 +833,16 @@ def step_apply(L, B, mode, grad_scale=1.0):
                                stream_ptr()))
 
 
+def wgrad_partials_f32(A, B, M, N, R, nsplit, a_ones_rows=-1, kernel=1, overread_ok=False):
+    """partials[nsplit, M(+1), N] of the split weight-gradient product A[:R, :M]^T B[:R, :N] (row-major operands with
+    their own row strides), by the register-direct kernel (1) or the staged one (0) — samx_wgrad_partials_f32."""
+    Mo = M + (1 if a_ones_rows >= 0 else 0)
+    P = torch.empty(nsplit, Mo, N, dtype=torch.float32, device=A.device)
+    check(_L().samx_wgrad_partials_f32(ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(P), M, N, R, a_ones_rows, nsplit,
+                                       int(kernel), int(bool(overread_ok)), stream_ptr()))
+    return P
+
+
 def gemm_f32(A, a_strides, B, b_strides, M, N, R, epi=0, bias=None, aux=None, add=None, alpha=0.0,
              a_ones_rows=-1, nsplit=1, out=None, overread_ok=False):
     """C[M(+1), N] = epi(sum_r A(i,r) B(r,j)) with explicit (free, reduction) / (reduction, free) element

@@ -104,3 +104,57 @@ def test_gemm_rejects_bad_arguments():
         ops.gemm_f32(A, (8, 1), B, (8, 1), 8, 8, 8, epi=9)   # unknown epilogue
     with pytest.raises(_lib.SamxError):
         ops.gemm_f32(A, (8, 1), B, (8, 1), 8, 8, 8, epi=1)   # bias epilogue without bias
+
+
+def _split_chunk(R, nsplit):
+    return ((R + nsplit - 1) // nsplit + 31) // 32 * 32
+
+
+@pytest.mark.parametrize('kernel', [1, 0])
+@pytest.mark.parametrize('M,N,R,nsplit,ones', [
+    (256, 256, 1024, 2, 1024),    # C4's W2 products: main loop only, bias row over every row
+    (393, 256, 2048, 4, 1024),    # reward net W1 with LayerNorm: 2B rows, bias row over the primal half, 9-wide edge tile
+    (376, 256, 1024, 2, -1),      # no bias row
+    (256, 17, 1024, 2, 1024),     # action head: odd N (4-byte stores), one narrow column tile
+    (64, 64, 64, 2, 64),          # 8 rows per wave: the k-step-at-a-time loop only
+    (100, 70, 160, 2, 100),       # 24 rows per wave: one group + the remainder; bias limit inside a group; odd extents
+    (33, 2, 96, 3, 50),           # a second tile of one column of X, the narrowest B, a bias limit inside chunk 1
+    (20, 20, 32, 2, 32),          # chunk 1 has no rows: zeros
+    (130, 130, 2, 2, 2),          # one k-step in all
+    (4, 6, 1000, 5, 777),
+])
+def test_weight_gradient_partials(M, N, R, nsplit, ones, kernel):
+    """samx_wgrad_partials_f32: every chunk's partial sums and bias row of the register-direct kernel (and of the
+    staged one it replaced) against float64, on padded row strides; the two kernels agree to fp32 rounding."""
+    from sam_tf_amd import ops
+    if kernel == 0 and min(M, N) < 4:
+        pytest.skip('the staged kernel stages 16 bytes at a time')
+    rs = np.random.RandomState(M * 7 + N + R)
+    lda, ldb = M + 3, N + 5   # rows keep 4-byte alignment only; the tail of each row is readable (overread_ok)
+    a = rs.standard_normal((R + 1, lda)).astype(np.float32)
+    b = rs.standard_normal((R + 1, ldb)).astype(np.float32)
+    A = torch.from_numpy(a).cuda(); B = torch.from_numpy(b).cuda()
+    got = ops.wgrad_partials_f32(A, B, M, N, R, nsplit, a_ones_rows=ones, kernel=kernel, overread_ok=True).cpu().numpy()
+    chunk = _split_chunk(R, nsplit)
+    Mo = M + (1 if ones >= 0 else 0)
+    assert got.shape == (nsplit, Mo, N)
+    for z in range(nsplit):
+        r0, r1 = min(R, z * chunk), min(R, (z + 1) * chunk)
+        want = a[r0:r1, :M].astype(np.float64).T @ b[r0:r1, :N].astype(np.float64)
+        if ones >= 0:
+            lim = max(r0, min(r1, ones))
+            want = np.concatenate([want, b[r0:lim, :N].astype(np.float64).sum(0, keepdims=True)])
+        scale = max(1.0, np.max(np.abs(want)))
+        assert np.max(np.abs(got[z] - want)) <= 2e-5 * scale, (z, np.max(np.abs(got[z] - want)), scale)
+
+
+def test_weight_gradient_partials_rejects_what_does_not_fit():
+    from sam_tf_amd import ops, _lib
+    A = torch.zeros(65, 8, device='cuda'); B = torch.zeros(65, 8, device='cuda')
+    with pytest.raises(_lib.SamxError):
+        ops.wgrad_partials_f32(A, B, 8, 8, 63, 2, kernel=1, overread_ok=True)    # odd R: row pairs
+    with pytest.raises(_lib.SamxError):
+        ops.wgrad_partials_f32(A, B, 7, 8, 64, 2, kernel=1, overread_ok=False)   # odd M without readable bytes behind
+    with pytest.raises(_lib.SamxError):
+        ops.wgrad_partials_f32(A, B, 8, 8, 64, 1, kernel=1)                      # a split product has >= 2 chunks
+    ops.wgrad_partials_f32(A, B, 8, 8, 64, 2, kernel=1)                          # even extents need no overread
