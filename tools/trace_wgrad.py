@@ -50,3 +50,11 @@ print('%d distinct CUs hold them; workgroups per CU: %s' % (len(u), dict(zip(*np
 print('XCD of block b (b %% 8 -> XCC_ID):', {int(b % 8): int(x) for b, x in zip(blocks[:64], xcc[:64])})
 for b, row, w in list(zip(blocks, tt, where))[:: max(1, len(blocks) // 24)]:
     print('block %3d cu %4d: %s' % (b, w, ' '.join('%.2f' % ((x - t0) / 100.0) for x in row[:4])))
+# which workgroups share a CU: slot s and slot s + k of one XCD?
+by_cu = {}
+for b, w in zip(blocks, where):
+    by_cu.setdefault(int(w), []).append(int(b) >> 3)
+d = [max(v) - min(v) for v in by_cu.values() if len(v) == 2]
+if d:
+    u, c = np.unique(d, return_counts=True)
+    print('slot distance of the two workgroups of a CU (XCD-local slots): %s' % dict(zip(u.tolist(), c.tolist())))
