@@ -32,6 +32,12 @@
 // Out-of-range free indices read a clamped (valid) address: they only feed output rows/columns that
 // are never stored.  Out-of-range reduction indices (last stage) and the ones row are patched in LDS
 // by the wave that issued the DMA, after its own vmcnt wait and before the barrier.
+//
+// The split weight-gradient products of the 256-wide path do NOT take this kernel any more (round 3): both of their
+// operands are free-contiguous, every MFMA fragment is a coalesced global load, and wgrad_direct_kernel further down
+// runs them from registers alone ("Register-direct weight-gradient products").  gemm_group_kernel, the staged form
+// of that launch, stays for products that do not fit it (odd row counts, offsets beyond 31 bits) and as the second
+// implementation the parity tests compare against (samx_wgrad_partials_f32).
 #include "gemm.h"
 #include <stdlib.h>
 #include <algorithm>
