@@ -585,6 +585,13 @@ int samx_step_grads(const samx_learner* L, const samx_batch* batch, const samx_s
  * images in the workspace are current, write none.  Bit 7 is only valid if since the last call with bit 8 on this
  * workspace W1 / W2 of the learner's networks and targets were modified by nothing but samx_step_apply calls with
  * mode bit 6 (PopArt's rescale touches the heads only).
+ * Part bit 9 (value 512; with bit 1, samx_step_path 1 only — refused elsewhere; one process): the reduction launch
+ * also runs the optimiser pass, i.e. the call then includes samx_step_apply(mode 3 [| the same role subset],
+ * grad_scale 1) and the caller does not make that call: gradients stay in registers between the two halves and the
+ * blocks exchange nothing but their sums of squares (one tagged 64-bit word each, agent-scope atomics, bounded wait;
+ * fused_small.hip finalize_apply_kernel).  Same bits as the two calls.  Needs learner.clipped, the counter tick (no
+ * bit 6) and a workspace that was zero-filled before its first use; on a device that cannot make the launch's blocks
+ * resident within 2 s the parameters are poisoned with NaN instead of being updated wrongly.
  * Under HIP stream capture: on the layer-wise path (samx_step_path 0) the call forks two role streams from
  * `stream`; `stream` must then be the capture's ORIGIN stream.  A fork of a forked stream crashes
  * hipStreamEndCapture in the HIP runtime this was built against (torch 2.10.0+rocm7.0) — with plain torch streams

@@ -169,6 +169,10 @@ int launch_td(const samx_mlp* dc, const float* critic, const float* obs0, const 
               int64_t* idx_copy, hipStream_t st);
 int launch_finalize(const FinalizeArgs& f, hipStream_t st);
 int launch_apply(const ApplyArgs& f, hipStream_t st);
+// both in one launch (one process; fused_small.hip finalize_apply_kernel): slots [3 * kMaxSegBlocks] and epoch [2]
+// live in the step workspace, zero before their first use
+int launch_finalize_apply(const FinalizeArgs& f, const ApplyArgs& a, unsigned long long* slots, unsigned* epoch,
+                          hipStream_t st);
 int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st);
 int launch_tick(int64_t* a, int64_t* b, int64_t* c, hipStream_t st);
 

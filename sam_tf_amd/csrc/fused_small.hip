@@ -727,7 +727,7 @@ __device__ __forceinline__ void gp_scalars(const FinalizeArgs& f, int lane, floa
 
 // scalar losses, the commit of the inline d.obs_rms update and the step counters: one wave of the
 // EXTRA last block, so this serial chain runs beside the gradient blocks instead of after one of them
-__device__ inline void finalize_scalars(const FinalizeArgs& f, int tid) {
+__device__ inline void finalize_scalars(const FinalizeArgs& f, int tid, bool tick = true) {
     float kgp; double gp_loss;
     gp_scalars(f, tid, kgp, gp_loss);
     auto wsum = [](double x) {
@@ -796,7 +796,7 @@ __device__ inline void finalize_scalars(const FinalizeArgs& f, int tid) {
         }
         if (tid == 0) f.rms_sums[2 * dim] = cnt;
     }
-    if (tid == 0)
+    if (tid == 0 && tick)
         for (int k = 0; k < f.nseg; ++k)
             if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
 }
@@ -983,6 +983,169 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// finalize + apply in ONE launch (samx_step_grads_part bit 9; one process, whole-network path): every quad of lanes
+// reduces the tile slots of ONE element as finalize_kernel does and keeps the gradient in a register; the only thing a
+// block needs from the others is the clip norm, i.e. their per-block sums of squares — one float each.  A block
+// publishes its float as ONE 64-bit word {launch tag, float bits} with an agent-scope atomic store and reads the
+// words of its segment with agent-scope atomic loads until they carry this launch's tag: no fence, no second word
+// (a device-scope release fence writes the XCD's L2 back — measured at ~15 us per launch when the optimiser pass
+// hung behind tickets).  The arithmetic, and the order of every addition, is apply_kernel's: same bits.
+// Tags: the workspace keeps a launch counter (epoch[0]); a launch uses epoch + 1 and the extra block stores it back
+// once every slot carries it (so every block has read the counter, and the step counters, before they move).
+// Every block of the launch must be resident at once: the host refuses grids beyond 1024 blocks (an MI355X holds
+// 2048 of these), and the wait is bounded by the wall clock — on expiry the block poisons its parameters with NaN and
+// sets epoch[1] (loud, never silent; a healthy device does not get there).
+// ------------------------------------------------------------------------------------------------
+constexpr long long kSpinTicks = 200000000ll;   // wall_clock64() runs at 100 MHz: 2 s
+
+__device__ __forceinline__ bool wait_slot(const unsigned long long* slot, unsigned tag, float& value) {
+    long long t0 = 0;
+    for (unsigned it = 0;; ++it) {
+        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == tag) { value = __uint_as_float((unsigned)v); return true; }
+        if ((it & 63) == 63) {   // the clock is a scalar-memory round trip of its own: looked at every 64th miss
+            const long long now = wall_clock64();
+            if (it == 63) t0 = now;
+            else if (now - t0 > kSpinTicks) { value = 0.f; return false; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_apply_kernel(FinalizeArgs f, ApplyArgs a, unsigned long long* slots,
+                                                             unsigned* epoch) {
+    __shared__ double shd[4], shn[4], sh_pow[2];
+    __shared__ float sh_lr;
+    const int tid = threadIdx.x;
+    const unsigned tag = epoch[0] + 1u;
+    if (blockIdx.x == gridDim.x - 1) {  // the extra block: scalars, then the counters once everybody has read them
+        if (tid >= 64) return;
+        finalize_scalars(f, tid, false);
+        bool ok = true;
+        for (int k = 0; k < f.nseg; ++k)
+            for (int j = tid; j < f.seg[k].nblocks; j += 64) {
+                float unused;
+                ok = wait_slot(slots + k * kMaxSegBlocks + j, tag, unused) && ok;
+            }
+        const bool all_ok = __all(ok);
+        if (tid == 0) {
+            for (int k = 0; k < f.nseg; ++k)
+                if (f.seg[k].step_dev) f.seg[k].step_dev[0] += 1;
+            epoch[0] = tag;
+            if (!all_ok) epoch[1] = 1u;
+        }
+        return;
+    }
+    int seg = 0, b = blockIdx.x;
+    while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
+    const Segment& s = f.seg[seg];
+    const ApplySeg& p = a.seg[seg];
+    const int q = tid & 3;
+    const int64_t i = (int64_t)b * 64 + (tid >> 2);   // nblocks * 64 >= n (host-checked): one element per quad
+    // a lane's slots q, q + 4, ...: eight loads per batch as in finalize_kernel; a segment of 33..48 slots (the
+    // discriminator's at every batch size with 16 row tiles per stream) requests all twelve at once — its blocks
+    // are the last to publish, and the second batch was a second memory round trip ahead of everybody's wait.
+    // The additions run in the same order either way.
+    float t[12];
+    const bool wide12 = s.nslots > 32 && s.nslots <= 48;
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 4 * j;
+            t[j] = (i < s.n && k < s.nslots) ? s.partials[i + (int64_t)k * s.slot_stride] : 0.f;
+        }
+    };
+    issue(q);
+    if (wide12) {
+#pragma unroll
+        for (int j = 8; j < 12; ++j) {
+            const int k = q + 4 * j;
+            t[j] = (i < s.n && k < s.nslots) ? s.partials[i + (int64_t)k * s.slot_stride] : 0.f;
+        }
+    }
+    // the optimiser's operands of this element travel behind the slots
+    const bool own = q == 0 && i < s.n;
+    float m0 = 0.f, v0 = 0.f, p0 = 0.f, t0 = 0.f;
+    if (own) { m0 = p.m[i]; v0 = p.v[i]; p0 = p.param[i]; if (p.targ) t0 = p.targ[i]; }
+    double tstep = 0.0;   // the counter AFTER this update's tick (the extra block advances it behind everybody's read)
+    if (tid == 64 || tid == 128) tstep = (double)p.step_dev[0] + 1.0;
+    float kgp; double gp_loss;
+    gp_scalars(f, tid & 63, kgp, gp_loss);
+    float g = 0.f;
+    double acc = 0.0;
+    if (i < s.n) {
+        float g0 = 0.f, g1 = 0.f;
+        if (wide12) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {   // (two batches of eight there: the zeros are added too, -0 + 0 = +0)
+                const bool plain = q + 4 * j < s.scaled_from;
+                const float tj = j < 12 ? t[j] : 0.f;
+                g0 += plain ? tj : 0.f;
+                g1 += plain ? 0.f : tj;
+            }
+        } else {
+            for (int k0 = q; k0 < s.nslots; k0 += 32) {
+                if (k0 != q) issue(k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool plain = k0 + 4 * j < s.scaled_from;
+                    g0 += plain ? t[j] : 0.f;
+                    g1 += plain ? 0.f : t[j];
+                }
+            }
+        }
+        g0 += __shfl_xor(g0, 1, 64); g0 += __shfl_xor(g0, 2, 64);
+        g1 += __shfl_xor(g1, 1, 64); g1 += __shfl_xor(g1, 2, 64);
+        g = g0 + kgp * g1;
+        if (s.wd > 0.f && ((i >= s.wd0_lo && i < s.wd0_hi) || (i >= s.wd1_lo && i < s.wd1_hi)))
+            g += s.wd * s.param[i];
+        if (q == 0) {
+            s.grad[i] = g;
+            acc += (double)g * (double)g;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    if (tid == 64) sh_pow[0] = pow((double)a.beta2, tstep);
+    if (tid == 128) sh_pow[1] = pow((double)a.beta1, tstep);
+    __syncthreads();
+    unsigned long long* my = slots + seg * kMaxSegBlocks;
+    if (tid == 0) {
+        const float ss = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
+        s.sumsq[b] = ss;
+        __hip_atomic_store(my + b, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(ss),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the segment's norm: thread k fetches block k's sum (nblocks <= 256), added as apply_kernel adds them
+    double part = 0.0;
+    bool ok = true;
+    if (tid < s.nblocks) {
+        float x;
+        ok = wait_slot(my + tid, tag, x);
+        part += (double)x;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((tid & 63) == 0) shn[tid >> 6] = part;
+    // (the step size needs nothing from the other blocks: it is ready behind the same barrier as the norm's sums,
+    // and every lane that updates an element finishes norm and clip factor itself — apply_kernel's third barrier
+    // is not needed)
+    if (tid == 64) sh_lr = (float)((double)p.lr * sqrt(1.0 - sh_pow[0]) / (1.0 - sh_pow[1]));
+    const int bad = __syncthreads_or(!ok);
+    if (!own) return;
+    const float nrm = (float)sqrt(shn[0] + shn[1] + shn[2] + shn[3]) * a.grad_scale;
+    const float scale = (p.clip > 0.f ? p.clip / fmaxf(nrm, p.clip) : 1.f) * a.grad_scale, lr_t = sh_lr;
+    const float gi = g * scale;
+    if (a.mode & 1) p.clipped[i] = gi;
+    float mi = m0, vi = v0;
+    mi = mi + (gi - mi) * (1.f - a.beta1);
+    vi = vi + (gi * gi - vi) * (1.f - a.beta2);
+    float pi = p0 - (mi * lr_t) / (sqrtf(vi) + a.eps);
+    if (bad) pi = __uint_as_float(0x7fc00000u);   // the wait expired: never a silent wrong update
+    p.m[i] = mi; p.v[i] = vi; p.param[i] = pi;
+    if (p.targ) p.targ[i] = (1.f - a.tau) * t0 + a.tau * pi;
+}
+
 __global__ void tick_kernel(int64_t* a, int64_t* b, int64_t* c) {
     if (threadIdx.x == 0) {
         if (a) a[0] += 1;
@@ -1116,6 +1279,22 @@ int launch_finalize(const FinalizeArgs& f, hipStream_t st) {
     int blocks = 0;
     for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
     finalize_kernel<<<blocks + 1, 256, 0, st>>>(f);  // + the scalar block
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
+
+int launch_finalize_apply(const FinalizeArgs& f, const ApplyArgs& a, unsigned long long* slots, unsigned* epoch,
+                          hipStream_t st) {
+    SAMX_REQUIRE(slots && epoch && f.nseg == a.nseg && (a.mode & 2), "finalize+apply: bad arguments");
+    int blocks = 0;
+    for (int i = 0; i < f.nseg; ++i) {
+        SAMX_REQUIRE(f.seg[i].n == a.seg[i].n && f.seg[i].step_dev && !a.seg[i].img1 &&
+                         (int64_t)f.seg[i].nblocks * 64 >= f.seg[i].n && f.seg[i].nblocks <= kMaxSegBlocks,
+                     "finalize+apply: segment %d does not fit one element per lane quad", i);
+        blocks += f.seg[i].nblocks;
+    }
+    SAMX_REQUIRE(blocks + 1 <= 1024, "finalize+apply: %d blocks must all be resident at once", blocks + 1);
+    finalize_apply_kernel<<<blocks + 1, 256, 0, st>>>(f, a, slots, epoch);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

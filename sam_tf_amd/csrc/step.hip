@@ -34,6 +34,9 @@ struct StepWs {
     size_t stats_bytes;
     void* wide_red;  // 256x256 path: head slots + split partials of the grouped weight-gradient launch
     size_t wide_red_bytes;
+    // whole-network path, reduction + optimiser pass in one launch (part bit 9): {tag, sum of squares} words of the
+    // blocks and the launch counter behind them (fused_small.hip finalize_apply_kernel)
+    unsigned long long* fa_slots;
 };
 
 // Two side streams per device for the layer-wise path: the discriminator, target+critic and actor
@@ -112,6 +115,7 @@ StepWs carve(Arena& ar, const samx_learner* L, int64_t B) {
     w.stats_ws = ar.take<char>(w.stats_bytes);
     w.wide_red_bytes = (!f && samx::wide_step_supported(L, B)) ? samx::wide_reduce_ws_bytes(L, B) : 0;
     w.wide_red = ar.take<char>(w.wide_red_bytes);
+    w.fa_slots = ar.take<unsigned long long>(f ? 3 * fused::kMaxSegBlocks + 1 : 0);
     return w;
 }
 
@@ -851,9 +855,12 @@ int samx_step_grads(const samx_learner* L, const samx_batch* b, const samx_step_
 int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_step_out* o, void* ws,
                          size_t ws_bytes, int part, void* stream) {
     int rc = check_learner(L, "samx_step_grads");
-    SAMX_REQUIRE((part & ~511) == 0 && (part & 3) != 0 && (part & 12) != 12 && (part & 384) != 384,
-                 "samx_step_grads_part: part uses bits 0-8, needs bit 0 or 1, cannot skip both roles, and bits 7 and 8 "
+    SAMX_REQUIRE((part & ~1023) == 0 && (part & 3) != 0 && (part & 12) != 12 && (part & 384) != 384,
+                 "samx_step_grads_part: part uses bits 0-9, needs bit 0 or 1, cannot skip both roles, and bits 7 and 8 "
                  "exclude each other");
+    SAMX_REQUIRE(!(part & 512) || ((part & 2) && !(part & (16 | 64)) && L && L->clipped),
+                 "samx_step_grads_part: bit 9 (optimiser pass inside the reduction launch) needs bit 1, the counter "
+                 "tick (no bit 6), no bit 4 and learner.clipped");
     const bool tick = !(part & 64);   // bit 6: an evaluation that no update follows (d.get_grads / d.get_losses)
     const bool do_d = !(part & 4), do_a = !(part & 8);   // roles of this call
     const bool t_only = part & 16, t_done = part & 32;   // PopArt with N processes: the call split at the all-reduce
@@ -884,6 +891,8 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     Arena ar(ws, ws_bytes);
     StepWs w = carve(ar, L, b->B);
     if (!ar.ok()) return fail(SAMX_ERR_WORKSPACE, "samx_step_grads: workspace %zu < %zu", ws_bytes, ar.off);
+    SAMX_REQUIRE(!(part & 512) || use_fused(L, b->B),
+                 "samx_step_grads_part: bit 9 is for the whole-network path (samx_step_path 1)");
     const int64_t B = b->B;
     const int64_t Pa = samx_mlp_param_count(&L->actor), Pc = samx_mlp_param_count(&L->critic),
                   Pd = samx_mlp_param_count(&L->reward);
@@ -1198,6 +1207,11 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     f.gp_part = do_d ? w.gp_part : nullptr; f.gp_tiles = tiles; f.ob = L->ob_dim; f.ac = L->ac_dim;
     f.rms_sums = do_d ? b->d_rms_sums : nullptr; f.rms_addvec = do_d ? b->d_rms_addvec : nullptr;
     f.rms_mean = const_cast<float*>(L->d_mean); f.rms_std = const_cast<float*>(L->d_std);
+    if (part & 512) {   // = samx_step_apply(mode 3 [| 8 | 16 for the role subset], grad_scale 1) in the same launch
+        fused::ApplyArgs ap = make_apply(L, w, 3, 1.f, segs);
+        return fused::launch_finalize_apply(f, ap, w.fa_slots,
+                                            reinterpret_cast<unsigned*>(w.fa_slots + 3 * fused::kMaxSegBlocks), st);
+    }
     return fused::launch_finalize(f, st);
 }
 

@@ -122,6 +122,9 @@ class UpdateStepDriver(object):
         self.wide = self.L.path(B) == 2
         # (SAMX_KEEP_IMAGES=0: every row packs its weight images itself, see _img_bits)
         self.keep_images = os.environ.get('SAMX_KEEP_IMAGES', '1') != '0'
+        # whole-network path, one process: the optimiser pass rides in the reduction launch (samx_step_grads_part bit 9;
+        # SAMX_APPLY_IN_REDUCTION=0 restores the two launches for A/B runs — same bits either way)
+        self.apply_in_reduction = os.environ.get('SAMX_APPLY_IN_REDUCTION', '1') != '0'
         # PER on the layer-wise path, one process: the D chain beside the PER work + agent roles (see
         # _seg_grads_two_branches); SAMX_PER_TWO_BRANCHES=0 keeps every row on one chain
         self.per_two_branches = bool(self.per_dev and not self.fused and not self.wide and self.world == 1 and
@@ -366,9 +369,12 @@ class UpdateStepDriver(object):
             self._seg_trees(role, k)
         if split and img_part:
             img_part = 128   # (the target call of this row packed, or found, every image)
-        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0) | img_part)
-        # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass
-        ops.step_apply(self.L, self.B, (3 | img_mode if self.world == 1 else 1) | mode, 1.0)
+        # single GPU: the local norm IS the global one -> clipped copies + Adam + Polyak in one pass; on the
+        # whole-network path that pass runs inside the reduction launch (part bit 9, same bits: one launch less per row)
+        one = 512 if (self.world == 1 and self.fused and self.apply_in_reduction) else 0
+        ops.step_grads_part(self.L, self.batches[k], self.out, 3 | part | (32 if split else 0) | img_part | one)
+        if not one:
+            ops.step_apply(self.L, self.B, (3 | img_mode if self.world == 1 else 1) | mode, 1.0)
         if self.world == 1:
             self._seg_refresh(role, k)
 

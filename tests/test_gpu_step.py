@@ -290,6 +290,53 @@ def test_weight_images_kept_by_the_optimiser_pass(name, ln):
         assert torch.equal(runs[False][k], runs[True][k]), k
 
 
+@pytest.mark.parametrize('name,ln,d_scale', [('C2', False, 0.0), ('C3', False, 0.5), ('C1', False, 0.0), ('C2', True, 0.0),
+                                             ('C3', True, 0.5)])
+def test_optimiser_pass_inside_the_reduction_launch(name, ln, d_scale):
+    """Whole-network path: update steps whose optimiser pass runs inside the reduction launch (samx_step_grads_part
+    bit 9: gradients stay in registers, the blocks exchange their sums of squares as tagged words) == the same steps
+    with samx_step_grads + samx_step_apply(mode 3), bit for bit — parameters, targets, Adam moments, clipped copies,
+    gradients, losses, step counters.  Role subsets in between (an agents-only and a discriminator-only step), and
+    the two forms interleaved on one workspace (the tagged words of a two-launch step are stale, never current)."""
+    from sam_tf_amd import ops
+    runs = {}
+    seq = [(0, 0), (0, 0), (4, 8), (8, 16), (0, 0), (0, 0)]   # (part role bits, apply role bits)
+    for one in (0, 1, 2):   # two launches | one launch | alternating
+        c, L, batch, out = _setup(name, d_scale, 1e-3, True, ln=ln)
+        assert L.path(c['B']) == 1
+        for k, (pr, ar) in enumerate(seq):
+            if one == 1 or (one == 2 and k % 2 == 0):
+                ops.step_grads_part(L, batch, out, 3 | pr | 512)
+            else:
+                ops.step_grads_part(L, batch, out, 3 | pr)
+                ops.step_apply(L, c['B'], 3 | ar, 1.0)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(L.params).all())
+        runs[one] = dict(params=L.params.clone(), targets=L.targets.clone(), m=L.m.clone(), v=L.v.clone(),
+                         grads=L.grads.clone(), clipped=L.clipped.clone(), steps=L.steps.clone(),
+                         **{k: v.clone() for k, v in out.t.items()})
+    assert runs[0]['steps'].tolist() == [5, 5, 5]
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+        assert torch.equal(runs[0][k], runs[2][k]), k
+
+
+def test_optimiser_pass_inside_the_reduction_launch_is_refused_elsewhere():
+    """Bit 9 is for samx_step_path 1: the 256-wide and layer-wise paths refuse it, and so does an evaluation without the
+    counter tick (bit 6)."""
+    from sam_tf_amd import ops, _lib
+    for name in ('w_20x3', 'ragged'):
+        c, L, batch, out = _setup(name, 0.0, 0.0, True)
+        assert L.path(c['B']) != 1
+        with pytest.raises(_lib.SamxError):
+            ops.step_grads_part(L, batch, out, 3 | 512)
+    c, L, batch, out = _setup('C2', 0.0, 0.0, True)
+    with pytest.raises(_lib.SamxError):
+        ops.step_grads_part(L, batch, out, 3 | 64 | 512)
+    with pytest.raises(_lib.SamxError):
+        ops.step_grads_part(L, batch, out, 1 | 512)
+
+
 @pytest.mark.parametrize('name', ['C2', 'C4'])
 def test_masks_without_kink_redraw_actor_and_disc(name):
     """test_masks_without_kink_redraw for the other two roles.  Neither the actor's loss nor the discriminator's takes
