@@ -117,9 +117,12 @@ def build_learner(cfg, comm, device, seed, use_graph):
                            g_steps=int(cfg.get('g_steps', 1)), window=cfg.get('window'),
                            pn_adapt_frequency=cfg.get('pn_adapt_frequency'),
                            steps_per_launch=int(os.environ.get('SAMX_STEPS_PER_LAUNCH', 0)) or
-                           # about 100 kernel nodes per captured graph is the sweet spot measured on MI355X: 32 rows of the
-                           # 3-launch plain step, 16 rows of everything with more launches per row (C3: 6)
-                           (32 if not (cfg['per'] or cfg.get('ret') or cfg.get('nstep') or cfg.get('ln')) else 16))
+                           # measured on MI355X (tools/exp/rows_per_launch_sweep*.sh): 64 rows of the 2-launch plain step
+                           # (128 nodes; 32 -> 64 rows +3.8 %, 128 rows +1 % more), 32 rows of the 3..5-launch rows of the
+                           # option variants (+1.5..2.5 % over 16), 16 rows with prioritized replay (5-6 launches per row;
+                           # 24 / 32 measure the same)
+                           (16 if cfg['per'] else
+                            (64 if not (cfg.get('ret') or cfg.get('nstep') or cfg.get('ln')) else 32)))
     return mu, d, pool, drv
 
 
@@ -199,10 +202,14 @@ def time_passes(drv, cfg, iters=50):
     if drv.d.hps.rmsify_obs:
         keep += [drv.d.obs_rms.sums, drv.d.obs_rms.mean, drv.d.obs_rms.std]
     saved = [t.clone() for t in keep]
-    fns = (('network_passes', lambda: ops.step_grads_part(L, drv.batch, drv.out, 1)),
+    fns = [('network_passes', lambda: ops.step_grads_part(L, drv.batch, drv.out, 1)),
            ('reduce_losses', lambda: ops.step_grads_part(L, drv.batch, drv.out, 2)),
            ('step_apply', lambda: ops.step_apply(L, B, 3, 1.0)),
-           ('d_input_sums(K steps)', lambda: (drv._seg_sums(drv.K), drv._seg_inputs())))
+           ('d_input_sums(K steps)', lambda: (drv._seg_sums(drv.K), drv._seg_inputs()))]
+    if drv.fused and drv.world == 1 and drv.apply_in_reduction:
+        # what the driver's rows launch instead of the two passes above (samx_step_grads_part bit 9)
+        fns.insert(3, ('reduce_losses_and_step_apply_in_one_launch',
+                       lambda: ops.step_grads_part(L, drv.batch, drv.out, 2 | 512)))
     out = {}
     for name, fn in fns:
         fn(); fn()
