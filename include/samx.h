@@ -124,6 +124,16 @@ int samx_pow_host_f32_range(uint32_t first_bits, int64_t n, double bonus, double
 int samx_pow_host(const double* x_host, double y, int64_t n, double* out_host);   /* libm pow, HOST pointers */
 int64_t samx_pow_selfcheck(int64_t n);
 
+/* HOST: np.random.randint(low=0, high=high, size=(rows, row_len)) of numpy's legacy global generator — the replay
+ * index draws of RB.sample / sample_uniform (memory.py:90, called per batch from sam.py:372,424) for all rows of a
+ * multi-row launch at once — written as int64 into out[r * row_stride + c] (e.g. straight into pinned staging).
+ * mt_state = numpy's own MT19937 state (np.random.mtrand._rand._bit_generator.ctypes.state_address), advanced in
+ * place exactly as numpy's call would advance it (masked rejection on 32-bit words; 1 <= high <= 2^32); the caller
+ * holds no other reference to the generator meanwhile.  tests/test_host_rng.py compares it with numpy draw for draw,
+ * interleaved with numpy's own calls; sam_tf_amd/ops.py checks it once per process before using it. */
+int samx_host_mt19937_randint(void* mt_state, uint64_t high, int64_t rows, int64_t row_len, int64_t* out,
+                              int64_t row_stride);
+
 /* ---- replay storage ------------------------------------------------------------------------ */
 /* RingBuffer.get_batch for the five atoms at once (memory.py:33-34,74-84): row = (start+idx)%maxlen.
  * Any output may be NULL. */

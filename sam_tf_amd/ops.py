@@ -5,6 +5,7 @@ current stream), checks shapes/dtypes on the host — a wrong shape must never r
 enqueues the HIP work.  There is no CPU path here.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -125,6 +126,51 @@ def pow_matches_host(n=200000):
     if _POW_OK is None:
         _POW_OK = int(_L().samx_pow_selfcheck(int(n))) == 0
     return _POW_OK
+
+
+_HOST_RNG = None   # (bit generator object, address of its state) once checked; False when not usable
+
+
+def host_rng_ready():
+    """True when the library's restatement of numpy's legacy randint (samx_host_mt19937_randint, include/samx.h)
+    reproduces THIS numpy draw for draw on the global generator's own state — checked once per process, with the
+    generator put back exactly where it was.  SAMX_HOST_RNG=0 keeps numpy's call."""
+    global _HOST_RNG
+    if _HOST_RNG is None:
+        _HOST_RNG = False
+        try:
+            bg = np.random.mtrand._rand._bit_generator
+            if os.environ.get('SAMX_HOST_RNG', '1') != '0' and type(bg).__name__ == 'MT19937':
+                addr = int(bg.ctypes.state_address)
+                saved = np.random.get_state()
+                ok = True
+                try:
+                    for high in (1 << 20, 1000000, 100000, 7, 1, 1 << 32, 4097):
+                        np.random.set_state(saved)
+                        ref = np.random.randint(low=0, high=high, size=(3, 500))
+                        tail = np.random.randint(low=0, high=1 << 30, size=4)
+                        np.random.set_state(saved)
+                        got = np.full((3, 520), -1, dtype=np.int64)
+                        check(_L().samx_host_mt19937_randint(addr, high, 3, 500, got.ctypes.data, 520))
+                        ok = ok and np.array_equal(ref, got[:, :500]) and bool((got[:, 500:] == -1).all()) and \
+                            np.array_equal(tail, np.random.randint(low=0, high=1 << 30, size=4))
+                finally:
+                    np.random.set_state(saved)
+                if ok:
+                    _HOST_RNG = (bg, addr)
+        except Exception:  # noqa: BLE001 - any surprise in numpy's internals: numpy's own call stays
+            _HOST_RNG = False
+    return bool(_HOST_RNG) and np.random.mtrand._rand._bit_generator is _HOST_RNG[0]
+
+
+def host_randint_rows(words, rows, row_len, high):
+    """np.random.randint(low=0, high=high, size=(rows, row_len)) of the global generator, written into the first
+    row_len int64 words of the first `rows` rows of the 2-D int64 array `words` (its rows may be longer: pinned
+    staging).  Only after host_rng_ready()."""
+    assert words.dtype == np.int64 and words.ndim == 2 and words.strides[1] == 8 and words.strides[0] % 8 == 0
+    assert rows <= words.shape[0] and row_len <= words.shape[1]
+    check(_L().samx_host_mt19937_randint(_HOST_RNG[1], int(high), int(rows), int(row_len), words.ctypes.data,
+                                         words.strides[0] // 8))
 
 
 _POW_DEV_OK = {}

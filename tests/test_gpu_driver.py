@@ -1042,7 +1042,7 @@ def test_two_rank_plan_matches_oracle(cfg_name):
     assert drv.wide == (base in ('wsmall', 'C4'))
     assert drv.world == 2 and drv.inline_stats == fusable and drv.popart_split == bool(opt)
     # uniform replay on the whole-network / role-fused paths packs K steps
-    assert drv.K == ((16 if opt else 32) if base in ('C1', 'wsmall', 'C4') and fusable else 1)
+    assert drv.K == ((32 if opt else 64) if base in ('C1', 'wsmall', 'C4') and fusable else 1)
     drv.prepare()
     ref = OracleLearner(mu, d, pool, cfg['per'], world=2)
     K = 3 if base == 'C4' else 4
