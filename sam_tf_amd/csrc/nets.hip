@@ -158,16 +158,24 @@ __global__ __launch_bounds__(256) void disc_prep_draw_kernel(
         const int cw = isob ? ob : ac;
         float u[4];
         philox_uniform4(src.rng_seed, st, isob ? RNG_EPS_OB : RNG_EPS_AC, (uint64_t)grp, u);
+        // (row, column) of the group's first element by ONE division — 32-bit when the tensor allows it — and stepped
+        // from there (four 64-bit divisions per work item used to be most of this kernel's instructions)
+        const int64_t el0 = 4 * grp;
+        int64_t row = n <= 0x7fffffff ? (int64_t)((uint32_t)el0 / (uint32_t)cw) : el0 / cw;
+        int cc = (int)(el0 - row * cw);
+        int64_t pr = -1, pr_row = -1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t el = 4 * grp + i;
+            const int64_t el = el0 + i;
             if (el >= n) break;
-            const int64_t row = el / cw;
-            const int cc = (int)(el - row * cw);
-            int64_t pr = row;
-            if (src.p_idx) {
-                pr = src.ring_start + src.p_idx[row];
-                if (pr >= src.ring_len) pr -= src.ring_len;
+            if (i > 0 && ++cc == cw) { cc = 0; ++row; }
+            if (pr_row != row) {
+                pr_row = row;
+                pr = row;
+                if (src.p_idx) {
+                    pr = src.ring_start + src.p_idx[row];
+                    if (pr >= src.ring_len) pr -= src.ring_len;
+                }
             }
             const int64_t er = e0 + row;
             float pv, ev;
