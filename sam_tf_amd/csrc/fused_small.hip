@@ -993,6 +993,9 @@ __global__ __launch_bounds__(256) void apply_kernel(ApplyArgs f) {
 // hung behind tickets).  The arithmetic, and the order of every addition, is apply_kernel's: same bits.
 // Tags: the workspace keeps a launch counter (epoch[0]); a launch uses epoch + 1 and the extra block stores it back
 // once every slot carries it (so every block has read the counter, and the step counters, before they move).
+// A word left by an earlier launch never carries the current tag: tags only grow, a fresh workspace is zero (tag 1
+// != 0), and a stale word would have to be exactly 2^32 launches old to match (a slot that is not rewritten that
+// long belongs to a role subset that did not run in 2^32 launches).
 // Every block of the launch must be resident at once: the host refuses grids beyond 1024 blocks (an MI355X holds
 // 2048 of these), and the wait is bounded by the wall clock — on expiry the block poisons its parameters with NaN and
 // sets epoch[1] (loud, never silent; a healthy device does not get there).
