@@ -817,12 +817,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
     const int q = tid & 3;
     const int64_t step = (int64_t)s.nblocks * 64;
     int64_t i = (int64_t)b * 64 + (tid >> 2);
-    float t[8];
+    // (a segment of 33..48 slots — the discriminator's — requests its twelve per lane in ONE batch: the second batch
+    // was a second memory round trip; every other segment keeps eight, whose four extra predicated loads measured
+    // slower there.  Same additions in the same order either way, the zeros included: -0 + 0 = +0.)
+    float t[12];
+    const bool wide12 = s.nslots > 32 && s.nslots <= 48;
     auto issue = [&](int64_t e, int k0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + 4 * j;
             t[j] = (e < s.n && k < s.nslots) ? s.partials[e + (int64_t)k * s.slot_stride] : 0.f;
+        }
+        if (wide12) {
+#pragma unroll
+            for (int j = 8; j < 12; ++j) {
+                const int k = k0 + 4 * j;
+                t[j] = (e < s.n && k < s.nslots) ? s.partials[e + (int64_t)k * s.slot_stride] : 0.f;
+            }
         }
     };
     issue(i, q);
@@ -831,13 +842,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
     double acc = 0.0;
     for (; i < s.n; i += step) {
         float g0 = 0.f, g1 = 0.f;  // plain slots, gp-scaled slots
-        for (int k0 = q; k0 < s.nslots; k0 += 32) {
-            if (k0 != q) issue(i, k0);
+        if (wide12) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool plain = k0 + 4 * j < s.scaled_from;
-                g0 += plain ? t[j] : 0.f;
-                g1 += plain ? 0.f : t[j];
+            for (int j = 0; j < 16; ++j) {
+                const bool plain = q + 4 * j < s.scaled_from;
+                const float tj = j < 12 ? t[j] : 0.f;
+                g0 += plain ? tj : 0.f;
+                g1 += plain ? 0.f : tj;
+            }
+        } else {
+            for (int k0 = q; k0 < s.nslots; k0 += 32) {
+                if (k0 != q) issue(i, k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool plain = k0 + 4 * j < s.scaled_from;
+                    g0 += plain ? t[j] : 0.f;
+                    g1 += plain ? 0.f : t[j];
+                }
             }
         }
         g0 += __shfl_xor(g0, 1, 64); g0 += __shfl_xor(g0, 2, 64);
