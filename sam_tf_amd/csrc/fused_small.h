@@ -173,7 +173,8 @@ int launch_apply(const ApplyArgs& f, hipStream_t st);
 // live in the step workspace, zero before their first use
 int launch_finalize_apply(const FinalizeArgs& f, const ApplyArgs& a, unsigned long long* slots, unsigned* epoch,
                           hipStream_t st);
-int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st);
+// (ta / tb / tc: step counters advanced by the same launch, or null)
+int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st, int64_t* ta = nullptr, int64_t* tb = nullptr, int64_t* tc = nullptr);
 int launch_tick(int64_t* a, int64_t* b, int64_t* c, hipStream_t st);
 
 }  // namespace fused

@@ -1178,9 +1178,15 @@ __global__ void tick_kernel(int64_t* a, int64_t* b, int64_t* c) {
     }
 }
 
-__global__ __launch_bounds__(256) void seg_sumsq_kernel(ApplyArgs f) {
+// (ta / tb / tc: step counters to advance in the same launch — the layer-wise path's tick — or null)
+__global__ __launch_bounds__(256) void seg_sumsq_kernel(ApplyArgs f, int64_t* ta, int64_t* tb, int64_t* tc) {
     __shared__ double shd[4];
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (ta) ta[0] += 1;
+        if (tb) tb[0] += 1;
+        if (tc) tc[0] += 1;
+    }
     int seg = 0, b = blockIdx.x;
     while (seg < f.nseg - 1 && b >= f.seg[seg].nblocks) { b -= f.seg[seg].nblocks; ++seg; }
     const ApplySeg& s = f.seg[seg];
@@ -1343,10 +1349,10 @@ int launch_tick(int64_t* a, int64_t* b, int64_t* c, hipStream_t st) {
     return SAMX_OK;
 }
 
-int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st) {
+int launch_seg_sumsq(const ApplyArgs& f, hipStream_t st, int64_t* ta, int64_t* tb, int64_t* tc) {
     int blocks = 0;
     for (int i = 0; i < f.nseg; ++i) blocks += f.seg[i].nblocks;
-    seg_sumsq_kernel<<<blocks, 256, 0, st>>>(f);
+    seg_sumsq_kernel<<<blocks, 256, 0, st>>>(f, ta, tb, tc);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

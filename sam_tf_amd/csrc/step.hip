@@ -914,10 +914,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
     }
     if (!use_fused(L, B) && !wide && !(part & 1)) {  // reduction part only
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
-        rc = fused::launch_seg_sumsq(f, st);
-        if (rc != SAMX_OK || !tick) return rc;
-        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
-                                  do_d ? L->steps + 2 : nullptr, st);
+        // (the counters advance in the same launch: nothing in it reads them)
+        return fused::launch_seg_sumsq(f, st, (tick && do_a) ? L->steps : nullptr, (tick && do_a) ? L->steps + 1 : nullptr,
+                                       (tick && do_d) ? L->steps + 2 : nullptr);
     }
     if (wide) {
         // 256x256 nets: role-fused chains (fused_wide.hip) + batch reductions, all on the caller's stream
@@ -1097,10 +1096,9 @@ int samx_step_grads_part(const samx_learner* L, const samx_batch* b, const samx_
         }
         if (!(part & 2)) return SAMX_OK;
         fused::ApplyArgs f = make_apply(L, w, 0, 1.f, segs);
-        rc = fused::launch_seg_sumsq(f, st);
-        if (rc != SAMX_OK || !tick) return rc;
-        return fused::launch_tick(do_a ? L->steps : nullptr, do_a ? L->steps + 1 : nullptr,
-                                  do_d ? L->steps + 2 : nullptr, st);
+        // (the counters advance in the same launch: nothing in it reads them)
+        return fused::launch_seg_sumsq(f, st, (tick && do_a) ? L->steps : nullptr, (tick && do_a) ? L->steps + 1 : nullptr,
+                                       (tick && do_d) ? L->steps + 2 : nullptr);
     }
 
     const int tiles = (int)(B / fused::kRows);
