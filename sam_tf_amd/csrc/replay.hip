@@ -270,7 +270,33 @@ __global__ __launch_bounds__(256) void nstep_group_kernel(const float* __restric
 }
 }  // namespace
 
+namespace {
+// the host-drawn index words of a launch: pinned host memory -> HBM by a KERNEL (16 bytes per thread), so that the
+// upload stays on the compute queue between two graph launches (a stream-ordered hipMemcpyAsync hands over to the
+// copy engine and back: the GPU idles on both edges)
+__global__ __launch_bounds__(256) void copy_words_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst,
+                                                          int64_t n) {
+    const int64_t i = 2 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (i + 1 < n) {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        *(ll2*)(dst + i) = *(const ll2*)(src + i);
+    } else if (i < n) {
+        dst[i] = src[i];
+    }
+}
+}  // namespace
+
 extern "C" {
+
+int samx_copy_words(const int64_t* src, int64_t* dst, int64_t n, void* stream) {
+    SAMX_REQUIRE(src && dst && n >= 0, "samx_copy_words: null pointer or negative count");
+    SAMX_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "samx_copy_words: 16-byte aligned buffers");
+    if (n == 0) return SAMX_OK;
+    const int64_t blocks = ((n + 1) / 2 + 255) / 256;
+    copy_words_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, dst, n);
+    SAMX_LAUNCH_CHECK();
+    return SAMX_OK;
+}
 
 int samx_replay_gather(const float* obs0, const float* acs, const float* rews, const float* dones1,
                        const float* obs1, int64_t maxlen, int64_t start, int ob_dim, int ac_dim,

@@ -122,6 +122,7 @@ class UpdateStepDriver(object):
         self.wide = self.L.path(B) == 2
         # (SAMX_KEEP_IMAGES=0: every row packs its weight images itself, see _img_bits)
         self.keep_images = os.environ.get('SAMX_KEEP_IMAGES', '1') != '0'
+        self.upload_kernel = os.environ.get('SAMX_UPLOAD_KERNEL', '1') != '0'
         # the K-row launches' replay index draws through the library's restatement of numpy's randint (checked against
         # this numpy when the driver is built; the generator is left exactly where it was)
         self.host_rng = ops.host_rng_ready()
@@ -769,8 +770,11 @@ class UpdateStepDriver(object):
             self._pending = None
 
     def _upload(self, slot, K):
-        # ONE packed H2D copy per launch
-        if K == self.K:
+        # ONE packed H2D copy per launch — by a kernel that reads the pinned words (the rows of a slot are contiguous),
+        # so that nothing leaves the compute queue between two graph launches (SAMX_UPLOAD_KERNEL=0: hipMemcpyAsync)
+        if self.upload_kernel:
+            ops.copy_words(slot.words, self.words, K * self.W)
+        elif K == self.K:
             self.words.copy_(slot.words, non_blocking=True)
         else:
             self.words[:K].copy_(slot.words[:K], non_blocking=True)

@@ -860,6 +860,14 @@ def make_step_out(B, device='cuda'):
     return o
 
 
+def copy_words(src, dst, n):
+    """The first n int64 words of `src` (a pinned host tensor or a device tensor) into `dst` (device) by a kernel on
+    the current stream (samx_copy_words)."""
+    assert src.dtype == torch.int64 and dst.dtype == torch.int64 and dst.is_cuda
+    assert src.is_contiguous() and dst.is_contiguous() and n <= src.numel() and n <= dst.numel()
+    check(_L().samx_copy_words(src.data_ptr(), dst.data_ptr(), int(n), stream_ptr()))
+
+
 def step_grads(L, batch, out):
     ws = L.ws(batch.B)
     check(_L().samx_step_grads(C.byref(L.c), C.byref(batch), C.byref(out), ptr(ws), ws.numel(),
