@@ -56,7 +56,10 @@ class DevicePairPool(object):
             if self._turn >= 2:
                 self._events[t].synchronize()   # the copy that read this staging buffer two reshuffles ago
             self._stage[t].numpy()[:] = indices
-            self._idx_dev.copy_(self._stage[t], non_blocking=True)
+            # (by a kernel on the current stream, like the driver's index words: a hipMemcpyAsync between two graph
+            # launches hands over to the copy engine and back)
+            from . import ops
+            ops.copy_words(self._stage[t], self._idx_dev, self.num_entries)
             self._events[t].record()
             self._turn += 1
             torch.index_select(self.obs0, 0, self._idx_dev, out=self._tmp_obs)
