@@ -135,10 +135,12 @@ int samx_host_mt19937_randint(void* mt_state, uint64_t high, int64_t rows, int64
                               int64_t row_stride);
 
 /* ---- replay storage ------------------------------------------------------------------------ */
-/* n int64 words from (pinned, device-readable) host memory or HBM to HBM by a kernel on `stream`: the upload of a
- * launch's host-drawn index words (the reference passes them as feed_dict entries, sam.py:372-377,424) without a
- * hand-over to the copy engine between two graph launches.  Both buffers 16-byte aligned. */
-int samx_copy_words(const int64_t* src, int64_t* dst, int64_t n, void* stream);
+/* The first row_len int64 words of each of `rows` rows (row_stride words apart, the same layout on both sides) from
+ * (pinned, device-readable) host memory or HBM to HBM by a kernel on `stream`: the upload of a launch's host-drawn
+ * index words (the reference passes them as feed_dict entries, sam.py:372-377,424) without a hand-over to the copy
+ * engine between two graph launches, and without the words of a row the configuration does not use.  Both buffers
+ * 16-byte aligned. */
+int samx_copy_words(const int64_t* src, int64_t* dst, int64_t rows, int64_t row_len, int64_t row_stride, void* stream);
 
 /* RingBuffer.get_batch for the five atoms at once (memory.py:33-34,74-84): row = (start+idx)%maxlen.
  * Any output may be NULL. */

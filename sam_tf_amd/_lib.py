@@ -93,7 +93,7 @@ SIGNATURES = {
     'samx_host_mt19937_randint': (C.c_int, [_P, C.c_uint64, _I64, _I64, _P, _I64]),
     'samx_to_host_pair': (C.c_int, [_P, _P, _P, _P, _I64, _P]),
     'samx_per_leaves_from_td_host': (C.c_int, [_P, _P, _I64, _I64, _D, _I64, _D, _P, _P]),
-    'samx_copy_words': (C.c_int, [_P, _P, _I64, _P]),
+    'samx_copy_words': (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
     'samx_replay_gather': (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
                                      _P, _P, _P, _P, _P, _P]),
     'samx_replay_write': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _I64, _P]),

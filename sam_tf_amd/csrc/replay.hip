@@ -275,25 +275,30 @@ namespace {
 // upload stays on the compute queue between two graph launches (a stream-ordered hipMemcpyAsync hands over to the
 // copy engine and back: the GPU idles on both edges)
 __global__ __launch_bounds__(256) void copy_words_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst,
-                                                          int64_t n) {
-    const int64_t i = 2 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
-    if (i + 1 < n) {
+                                                          int64_t rows, int64_t row_len, int64_t row_stride) {
+    // pairs of words: row_len and row_stride are even or the row is copied word by word (host-chosen)
+    const int64_t per_row = (row_len + 1) / 2, t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= rows * per_row) return;
+    const int64_t r = t / per_row, i = 2 * (t - r * per_row), at = r * row_stride + i;
+    if (i + 1 < row_len && (at & 1) == 0) {
         typedef long long ll2 __attribute__((ext_vector_type(2)));
-        *(ll2*)(dst + i) = *(const ll2*)(src + i);
-    } else if (i < n) {
-        dst[i] = src[i];
+        *(ll2*)(dst + at) = *(const ll2*)(src + at);
+    } else {
+        dst[at] = src[at];
+        if (i + 1 < row_len) dst[at + 1] = src[at + 1];
     }
 }
 }  // namespace
 
 extern "C" {
 
-int samx_copy_words(const int64_t* src, int64_t* dst, int64_t n, void* stream) {
-    SAMX_REQUIRE(src && dst && n >= 0, "samx_copy_words: null pointer or negative count");
+int samx_copy_words(const int64_t* src, int64_t* dst, int64_t rows, int64_t row_len, int64_t row_stride, void* stream) {
+    SAMX_REQUIRE(src && dst && rows >= 0 && row_len >= 0 && row_stride >= row_len,
+                 "samx_copy_words: null pointer, negative count or row_stride < row_len");
     SAMX_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "samx_copy_words: 16-byte aligned buffers");
+    const int64_t n = rows * ((row_len + 1) / 2);
     if (n == 0) return SAMX_OK;
-    const int64_t blocks = ((n + 1) / 2 + 255) / 256;
-    copy_words_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, dst, n);
+    copy_words_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, dst, rows, row_len, row_stride);
     SAMX_LAUNCH_CHECK();
     return SAMX_OK;
 }

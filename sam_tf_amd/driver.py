@@ -123,6 +123,10 @@ class UpdateStepDriver(object):
         # (SAMX_KEEP_IMAGES=0: every row packs its weight images itself, see _img_bits)
         self.keep_images = os.environ.get('SAMX_KEEP_IMAGES', '1') != '0'
         self.upload_kernel = os.environ.get('SAMX_UPLOAD_KERNEL', '1') != '0'
+        # ... and only the words of a row this configuration reads: [idx_p | idx_a | e_start] + the two geometry words
+        # under uniform replay, + the B uniforms with the device-side priority refresh (whole rows otherwise)
+        B_ = int(mu.hps.batch_size)
+        self.upload_len = 5 * B_ + 1
         # the K-row launches' replay index draws through the library's restatement of numpy's randint (checked against
         # this numpy when the driver is built; the generator is left exactly where it was)
         self.host_rng = ops.host_rng_ready()
@@ -167,6 +171,8 @@ class UpdateStepDriver(object):
         # {start, num_entries} of the ring as a launch finds it (see _write_geom): two spare words of row 0 — the PER
         # uniforms' place under uniform replay, the host-refresh leaves' place under prioritized replay
         self.geom_at = (3 * B + 1) if self.per else (2 * B + 1)
+        if not self.per or self.per_dev:   # (the host-side priority refresh also sends the previous update: whole rows)
+            self.upload_len = self.geom_at + 2
         self.geom = self.words[0, self.geom_at:self.geom_at + 2]
         # PER: the previous step's priority update rides in this launch's upload and is applied by the
         # first kernel of the launch (the host libm pow that produces it is the only host work between
@@ -773,7 +779,7 @@ class UpdateStepDriver(object):
         # ONE packed H2D copy per launch — by a kernel that reads the pinned words (the rows of a slot are contiguous),
         # so that nothing leaves the compute queue between two graph launches (SAMX_UPLOAD_KERNEL=0: hipMemcpyAsync)
         if self.upload_kernel:
-            ops.copy_words(slot.words, self.words, K * self.W)
+            ops.copy_words(slot.words, self.words, K, self.upload_len, self.W)
         elif K == self.K:
             self.words.copy_(slot.words, non_blocking=True)
         else:

@@ -860,12 +860,16 @@ def make_step_out(B, device='cuda'):
     return o
 
 
-def copy_words(src, dst, n):
-    """The first n int64 words of `src` (a pinned host tensor or a device tensor) into `dst` (device) by a kernel on
+def copy_words(src, dst, rows, row_len=None, row_stride=None):
+    """The first row_len int64 words of `rows` rows (row_stride words apart; default: one contiguous run of `rows`
+    words) of `src` (a pinned host tensor or a device tensor) into the same places of `dst` (device), by a kernel on
     the current stream (samx_copy_words)."""
+    if row_len is None:
+        rows, row_len, row_stride = 1, int(rows), int(rows)
     assert src.dtype == torch.int64 and dst.dtype == torch.int64 and dst.is_cuda
-    assert src.is_contiguous() and dst.is_contiguous() and n <= src.numel() and n <= dst.numel()
-    check(_L().samx_copy_words(src.data_ptr(), dst.data_ptr(), int(n), stream_ptr()))
+    need = (rows - 1) * row_stride + row_len if rows else 0
+    assert src.is_contiguous() and dst.is_contiguous() and need <= src.numel() and need <= dst.numel()
+    check(_L().samx_copy_words(src.data_ptr(), dst.data_ptr(), int(rows), int(row_len), int(row_stride), stream_ptr()))
 
 
 def step_grads(L, batch, out):
