@@ -140,3 +140,23 @@ def test_layerwise_step_call_captures_on_the_origin_stream_and_serial_on_a_fork(
                            text=True, timeout=240)
         assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (variant, r.returncode, r.stdout[-300:],
                                                                        r.stderr[-300:])
+
+
+@pytest.mark.parametrize('rows,row_len,stride', [(1, 26, 26), (3, 5, 7), (4, 6, 8), (64, 515, 1281), (0, 4, 4), (2, 0, 3)])
+def test_copy_words_rows_from_pinned_staging(rows, row_len, stride):
+    """samx_copy_words: the first row_len words of each row, pinned host -> device by a kernel; the rest of a row and
+    the rows behind are not touched (odd strides take the word-by-word path, even ones the 16-byte one)."""
+    from sam_tf_amd import ops
+    n = max(rows, 1) * stride + 4
+    src = torch.arange(1, n + 1, dtype=torch.int64).pin_memory()
+    dst = torch.full((n,), -5, dtype=torch.int64, device='cuda')
+    ops.copy_words(src, dst, rows, row_len, stride)
+    torch.cuda.synchronize()
+    want = torch.full((n,), -5, dtype=torch.int64)
+    for r in range(rows):
+        want[r * stride:r * stride + row_len] = src[r * stride:r * stride + row_len]
+    assert torch.equal(dst.cpu(), want)
+    dev_src = src.cuda()
+    dst2 = torch.full((n,), -5, dtype=torch.int64, device='cuda')
+    ops.copy_words(dev_src, dst2, rows, row_len, stride)   # device -> device too
+    assert torch.equal(dst2.cpu(), want)
